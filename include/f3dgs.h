@@ -1,0 +1,211 @@
+/*
+ * f3dgs.h — C ABI of the MI355X-native differentiable Gaussian rasterizer
+ * (libf3dgs_hip.so).
+ *
+ * This is the drop-in boundary for the one hot path of Feature-3DGS: the
+ * tile-based forward/backward rasterizer.  Every entry point below replaces
+ * one static method of the reference's C++ class `CudaRasterizer::Rasterizer`
+ *   (reference: submodules/diff-gaussian-rasterization-feature/
+ *               cuda_rasterizer/rasterizer.h:20-94)
+ * which is what the reference's torch binding (rasterize_points.cu:35-236)
+ * calls.  Signatures use plain pointers and sizes only: no torch types, no
+ * C++ types.  All pointers are DEVICE pointers unless stated otherwise; all
+ * float tensors are contiguous fp32; matrices are the 16-float
+ * "transposed" matrices the reference passes (scene/cameras.py:55-58), i.e.
+ * element (row r, col c) of the mathematical matrix is m[4*c + r].
+ *
+ * Differences to the reference interface (all deliberate):
+ *   - `C` (number of semantic-feature channels) is a RUN-TIME argument.  The
+ *     reference bakes it in as the macro NUM_SEMANTIC_CHANNELS
+ *     (cuda_rasterizer/config.h:16) and must be recompiled per feature dim.
+ *     C == 0 is valid.
+ *   - The three `std::function<char*(size_t)>` resize hooks
+ *     (rasterizer.h:36-38) become (function pointer, context) pairs.
+ *   - Every call takes the HIP stream to enqueue on (the reference uses the
+ *     legacy default stream) and returns an int status instead of throwing.
+ *   - Optional inputs follow the reference's convention: NULL means "absent"
+ *     (forward.cu:204,240; backward.cu:398,402).
+ *   - backward() zero-initialises / fully overwrites every output itself; the
+ *     caller may pass uninitialised memory (the reference requires zeroed
+ *     buffers, rasterize_points.cu:163-173).
+ *
+ * Status codes: 0 = ok, negative = error; f3dgs_last_error() returns a
+ * thread-local human-readable message for the last failing call.
+ */
+#ifndef F3DGS_H_INCLUDED
+#define F3DGS_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F3DGS_OK 0
+#define F3DGS_ERR_INVALID_ARGUMENT (-1)
+#define F3DGS_ERR_HIP (-2)
+#define F3DGS_ERR_ALLOC (-3)
+#define F3DGS_ERR_UNSUPPORTED (-4)
+
+/* Resize hook: must return a device pointer to at least `nbytes` bytes that
+ * stays valid until the matching backward call has completed.  Mirrors
+ * `std::function<char*(size_t)>` of rasterizer.h:36-38 /
+ * resizeFunctional() of rasterize_points.cu:27-33. */
+typedef char* (*f3dgs_resize_fn)(void* ctx, size_t nbytes);
+
+/* Library / ABI version (major*10000 + minor*100 + patch). */
+int f3dgs_version(void);
+
+/* Thread-local message of the last error raised on this host thread. */
+const char* f3dgs_last_error(void);
+
+/*
+ * Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:24-29,
+ * rasterizer_impl.cu:141-153): present[i] = (view * p_i).z > 0.2.
+ * `present` is a device array of P bytes (0/1).
+ */
+int f3dgs_mark_visible(
+    int P,
+    const float* means3D,
+    const float* viewmatrix,
+    const float* projmatrix,
+    uint8_t* present,
+    void* stream /* hipStream_t */);
+
+/*
+ * Replaces CudaRasterizer::Rasterizer::forward (rasterizer.h:31-62,
+ * rasterizer_impl.cu:198-342).
+ *
+ *   P  number of Gaussians, D active SH degree (0..3), M SH coefficients per
+ *      colour channel held by `shs` (0 if absent), C semantic channels.
+ *   shs (P,M,3) | colors_precomp (P,3): exactly one non-NULL.
+ *   scales (P,3) + rotations (P,4) | cov3D_precomp (P,6): exactly one set.
+ *   semantic_feature (P,C) (may be NULL iff C == 0), opacities (P).
+ *   out_color (3,H,W), out_feature_map (C,H,W), out_depth (1,H,W), radii (P)
+ *   are fully written (radii may be NULL).
+ *
+ * The three opaque state buffers are sized through the resize hooks and must
+ * be handed back unchanged to f3dgs_backward.  Their layout is private to
+ * this library.  *num_rendered receives the number of (tile, Gaussian)
+ * instances (the reference's return value); reading it costs one 4-byte
+ * device-to-host copy + stream sync, exactly like rasterizer_impl.cu:283.
+ */
+int f3dgs_forward(
+    f3dgs_resize_fn geometry_resize, void* geometry_ctx,
+    f3dgs_resize_fn binning_resize, void* binning_ctx,
+    f3dgs_resize_fn image_resize, void* image_ctx,
+    int P, int D, int M, int C,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* semantic_feature,
+    const float* opacities,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* cam_pos,
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    float* out_color,
+    float* out_feature_map,
+    float* out_depth,
+    int* radii,
+    int debug,
+    void* stream /* hipStream_t */,
+    int* num_rendered /* host pointer, out */);
+
+/* Bytes of device scratch f3dgs_backward needs for P Gaussians (the
+ * reference cudaMalloc's its scratch inside the call,
+ * rasterizer_impl.cu:402-430; here the caller owns it). */
+size_t f3dgs_backward_scratch_bytes(int P, int C);
+
+/*
+ * Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:64-94,
+ * rasterizer_impl.cu:347-461).
+ *
+ *   R = num_rendered returned by the matching forward call; geom/binning/
+ *   image buffers are the ones that call filled.
+ *   dL_dpix (3,H,W), dL_dfeaturepix (C,H,W), dL_depths (1,H,W): upstream
+ *   gradients.
+ *   Outputs (all fully overwritten): dL_dmean2D (P,3) [x,y in NDC units, z=0],
+ *   dL_dopacity (P), dL_dcolor (P,3), dL_dsemantic_feature (P,C),
+ *   dL_dmean3D (P,3), dL_dcov3D (P,6), dL_dsh (P,M,3), dL_dscale (P,3),
+ *   dL_drot (P,4).  dL_dconic (P,4) and dL_dz (P) are OPTIONAL diagnostics
+ *   (NULL = not wanted); the reference allocates but never returns them.
+ *   dL_dsh may be NULL iff M == 0; dL_dscale/dL_drot may be NULL iff scales
+ *   is NULL.  `scratch` points to f3dgs_backward_scratch_bytes(P, C) bytes.
+ */
+int f3dgs_backward(
+    int P, int D, int M, int C, int R,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* semantic_feature,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* campos,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    const char* geom_buffer,
+    const char* binning_buffer,
+    const char* image_buffer,
+    const float* dL_dpix,
+    const float* dL_dfeaturepix,
+    const float* dL_depths,
+    float* dL_dmean2D,
+    float* dL_dconic,
+    float* dL_dopacity,
+    float* dL_dcolor,
+    float* dL_dsemantic_feature,
+    float* dL_dmean3D,
+    float* dL_dcov3D,
+    float* dL_dsh,
+    float* dL_dscale,
+    float* dL_drot,
+    float* dL_dz,
+    void* scratch,
+    int debug,
+    void* stream /* hipStream_t */);
+
+/*
+ * Test / profiling hooks (not part of the reference surface).  They expose
+ * the private state written by f3dgs_forward so that every stage can be
+ * compared with the oracle in isolation.  Each copies `count` elements
+ * starting at element 0 into a HOST buffer and synchronises the stream.
+ *   what: "means2D"(float2 per Gaussian) "depths" "conic_opacity"(float4)
+ *         "rgb"(float3) "clamped"(3 x u8) "tiles_touched"(u32)
+ *         "point_list"(u32 x R)  "ranges"(uint2 per tile)
+ *         "final_T"(float per pixel) "n_contrib"(u32 per pixel)
+ */
+int f3dgs_debug_read(
+    const char* what,
+    int P, int C, int R, int width, int height,
+    const char* geom_buffer,
+    const char* binning_buffer,
+    const char* image_buffer,
+    void* host_dst, size_t dst_bytes,
+    void* stream);
+
+/* Per-stage device time of the most recent forward/backward call on this
+ * host thread when the environment variable F3DGS_PROFILE=1 is set (HIP
+ * events recorded on the call's stream; forces a sync).  Returns the number
+ * of stages written; names[i] are static strings. */
+int f3dgs_last_stage_times(const char** names, float* ms, int max_stages);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* F3DGS_H_INCLUDED */

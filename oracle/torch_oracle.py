@@ -1,0 +1,239 @@
+"""PyTorch-CPU autograd restatement of the rasterizer (TEST INFRASTRUCTURE ONLY).
+
+Two jobs:
+  1. an INDEPENDENT check of the analytic backward in oracle/f3dgs_oracle.cpp: this file only
+     writes the forward; gradients come from torch.autograd, with the reference's deliberate
+     deviations from textbook autograd encoded as detach() tricks (quirks Q1, Q2, Q7);
+  2. the "PyTorch-CPU autograd reference path" that BASELINE.json config c1 is timed on
+     (the reference itself has no CPU rasterizer).
+
+Reference semantics followed (R = submodules/diff-gaussian-rasterization-feature/cuda_rasterizer):
+  R/forward.cu:20-72 (SH), :75-114 (EWA), :119-153 (cov3D), :156-256 (preprocess), :261-396 (blend),
+  R/rasterizer_impl.cu:70-138 (keys / sort / ranges); backward quirks R/backward.cu:168-176,262-264
+  (clamp-as-constant), :575 (features do not reach alpha), :600,616 (straight-through 0.99 clamp).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+TILE = 16
+C0 = 0.28209479177387814
+C1 = 0.4886025119029199
+C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+      1.445305721320277, -0.5900435899266435]
+
+
+def _sh_to_rgb(deg: int, sh: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """sh (P,M,3), dirs (P,3) normalised -> (P,3) before the +0.5 / clamp."""
+    x, y, z = dirs[:, 0:1], dirs[:, 1:2], dirs[:, 2:3]
+    res = C0 * sh[:, 0]
+    if deg > 0:
+        res = res - C1 * y * sh[:, 1] + C1 * z * sh[:, 2] - C1 * x * sh[:, 3]
+        if deg > 1:
+            xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+            res = (res + C2[0] * xy * sh[:, 4] + C2[1] * yz * sh[:, 5] + C2[2] * (2.0 * zz - xx - yy) * sh[:, 6]
+                   + C2[3] * xz * sh[:, 7] + C2[4] * (xx - yy) * sh[:, 8])
+            if deg > 2:
+                res = (res + C3[0] * y * (3.0 * xx - yy) * sh[:, 9] + C3[1] * xy * z * sh[:, 10]
+                       + C3[2] * y * (4.0 * zz - xx - yy) * sh[:, 11]
+                       + C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy) * sh[:, 12]
+                       + C3[4] * x * (4.0 * zz - xx - yy) * sh[:, 13] + C3[5] * z * (xx - yy) * sh[:, 14]
+                       + C3[6] * x * (xx - 3.0 * yy) * sh[:, 15])
+    return res
+
+
+def _quat_to_rot(q: torch.Tensor) -> torch.Tensor:
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]   # NOT normalised (forward.cu:128)
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.view(-1, 3, 3)
+
+
+def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, projmatrix, campos, tanfovx,
+              tanfovy, image_height, image_width, sh_degree=0, shs=None, colors_precomp=None, scales=None,
+              rotations=None, cov3D_precomp=None, scale_modifier=1.0, dtype=torch.float64) -> Dict[str, object]:
+    """Differentiable forward.  Inputs are torch tensors (leaf tensors may require grad)."""
+    H, W = int(image_height), int(image_width)
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    cast = lambda t: None if t is None else t.to(dtype)
+    bg, viewmatrix, projmatrix, campos = cast(bg), cast(viewmatrix), cast(projmatrix), cast(campos)
+    means3D, opacities = cast(means3D), cast(opacities)
+    P = means3D.shape[0]
+    C = semantic_feature.shape[-1]
+    feat = cast(semantic_feature).reshape(P, C)
+    fx, fy = W / (2.0 * tanfovx), H / (2.0 * tanfovy)
+
+    ones = torch.ones(P, 1, dtype=dtype)
+    p_view = (torch.cat([means3D, ones], 1) @ viewmatrix)[:, :3]
+    p_hom = torch.cat([means3D, ones], 1) @ projmatrix
+    p_w = 1.0 / (p_hom[:, 3] + 1e-7)
+    ndc = p_hom[:, :2] * p_w[:, None]
+    if means2D is not None:
+        ndc = ndc + cast(means2D)[:, :2]          # zero tensor; receives dL/d(ndc) (Q8)
+    vis = p_view[:, 2] > 0.2
+
+    if cov3D_precomp is not None and cov3D_precomp.numel():
+        c6 = cast(cov3D_precomp)
+        Sigma = torch.stack([c6[:, 0], c6[:, 1], c6[:, 2], c6[:, 1], c6[:, 3], c6[:, 4], c6[:, 2], c6[:, 4],
+                             c6[:, 5]], 1).view(P, 3, 3)
+    else:
+        R = _quat_to_rot(cast(rotations))
+        S = scale_modifier * cast(scales)
+        RS = R * S[:, None, :]
+        Sigma = RS @ RS.transpose(1, 2)
+
+    tz = p_view[:, 2]
+    tz_safe = torch.where(vis, tz, torch.ones_like(tz))
+    limx, limy = 1.3 * tanfovx, 1.3 * tanfovy
+    txtz, tytz = p_view[:, 0] / tz_safe, p_view[:, 1] / tz_safe
+    cx, cy = (txtz < -limx) | (txtz > limx), (tytz < -limy) | (tytz > limy)
+    # Q7: when the frustum clamp is active the clamped value is a CONSTANT for autograd.
+    tx = torch.where(cx, (txtz.clamp(-limx, limx) * tz_safe).detach(), p_view[:, 0])
+    ty = torch.where(cy, (tytz.clamp(-limy, limy) * tz_safe).detach(), p_view[:, 1])
+    zero = torch.zeros_like(tz)
+    J = torch.stack([fx / tz_safe, zero, -(fx * tx) / (tz_safe * tz_safe),
+                     zero, fy / tz_safe, -(fy * ty) / (tz_safe * tz_safe)], 1).view(P, 2, 3)
+    Rw2c = viewmatrix[:3, :3].t()
+    JW = J @ Rw2c
+    cov2 = JW @ Sigma @ JW.transpose(1, 2)
+    a = cov2[:, 0, 0] + 0.3
+    b = cov2[:, 1, 0]
+    c = cov2[:, 1, 1] + 0.3
+    det = a * c - b * b
+    det_safe = torch.where(det == 0, torch.ones_like(det), det)
+    conic = torch.stack([c / det_safe, -b / det_safe, a / det_safe], 1)
+    with torch.no_grad():
+        mid = 0.5 * (a + c)
+        root = torch.sqrt(torch.clamp(mid * mid - det, min=0.1))
+        radius = torch.ceil(3.0 * torch.sqrt(torch.maximum(mid + root, mid - root)))
+    pix = torch.stack([((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5], 1)
+    with torch.no_grad():
+        r_i = radius.to(torch.int64).to(dtype)
+        x0 = ((pix[:, 0] - r_i) / TILE).to(torch.int64).clamp(0, gx)
+        y0 = ((pix[:, 1] - r_i) / TILE).to(torch.int64).clamp(0, gy)
+        x1 = ((pix[:, 0] + r_i + TILE - 1) / TILE).to(torch.int64).clamp(0, gx)
+        y1 = ((pix[:, 1] + r_i + TILE - 1) / TILE).to(torch.int64).clamp(0, gy)
+        touched = (x1 - x0) * (y1 - y0)
+        visible = vis & (det != 0) & (touched > 0)
+        radii = torch.where(visible, radius, torch.zeros_like(radius)).to(torch.int32)
+
+    if colors_precomp is not None and colors_precomp.numel():
+        rgb = cast(colors_precomp)
+    else:
+        d = means3D - campos[None, :]
+        d = d / d.norm(dim=1, keepdim=True)
+        rgb = torch.clamp_min(_sh_to_rgb(int(sh_degree), cast(shs), d) + 0.5, 0.0)   # Q10
+
+    # ---- binning (integer work, numpy) --------------------------------------------------------------
+    vidx = torch.nonzero(visible).flatten().numpy()
+    depth32 = p_view[:, 2].detach().to(torch.float32).numpy()
+    x0n, x1n, y0n, y1n = x0.numpy(), x1.numpy(), y0.numpy(), y1.numpy()
+    keys, vals = [], []
+    for i in vidx:
+        ys, xs = np.meshgrid(np.arange(y0n[i], y1n[i]), np.arange(x0n[i], x1n[i]), indexing="ij")
+        t = (ys * gx + xs).reshape(-1).astype(np.uint64)
+        keys.append((t << np.uint64(32)) | np.uint64(depth32[i:i + 1].view(np.uint32)[0]))
+        vals.append(np.full(t.shape, i, np.int64))
+    if keys:
+        keys = np.concatenate(keys)
+        vals = np.concatenate(vals)
+        order = np.argsort(keys, kind="stable")
+        keys, vals = keys[order], vals[order]
+    else:
+        keys, vals = np.zeros(0, np.uint64), np.zeros(0, np.int64)
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    n_tiles = gx * gy
+    starts = np.searchsorted(tiles, np.arange(n_tiles), side="left")
+    ends = np.searchsorted(tiles, np.arange(n_tiles), side="right")
+
+    # ---- blend, one tile at a time -------------------------------------------------------------------
+    out_color = torch.zeros(3, H, W, dtype=dtype) + bg[:, None, None]
+    out_feat = torch.zeros(C, H, W, dtype=dtype)
+    out_depth = torch.zeros(1, H, W, dtype=dtype)
+    n_contrib = np.zeros((H, W), np.int64)
+    final_T = torch.ones(H, W, dtype=dtype)
+    color_tiles, feat_tiles, depth_tiles, slots = [], [], [], []
+    vals_t = torch.from_numpy(vals)
+    depth_all = p_view[:, 2]
+    for t in range(n_tiles):
+        lo, hi = int(starts[t]), int(ends[t])
+        if hi == lo:
+            continue
+        tx_, ty_ = t % gx, t // gx
+        xs = torch.arange(tx_ * TILE, min(W, (tx_ + 1) * TILE))
+        ys = torch.arange(ty_ * TILE, min(H, (ty_ + 1) * TILE))
+        py, px = torch.meshgrid(ys, xs, indexing="ij")
+        pxf, pyf = px.reshape(-1, 1).to(dtype), py.reshape(-1, 1).to(dtype)
+        g = vals_t[lo:hi]
+        dx = pix[g, 0][None, :] - pxf
+        dy = pix[g, 1][None, :] - pyf
+        con = conic[g]
+        power = -0.5 * (con[None, :, 0] * dx * dx + con[None, :, 2] * dy * dy) - con[None, :, 1] * dx * dy
+        Gv = torch.exp(power)
+        a_raw = opacities[g, 0][None, :] * Gv
+        alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()        # Q1 straight-through
+        with torch.no_grad():
+            valid = (power <= 0) & (alpha >= 1.0 / 255.0)
+        a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
+        cum = torch.cumprod(1.0 - a_eff, dim=1)
+        with torch.no_grad():
+            term = valid & (cum < 0.0001)
+            after = torch.cumsum(term.to(torch.int64), dim=1) > 0               # Q5
+            contrib = valid & ~after
+        T_before = torch.cat([torch.ones_like(cum[:, :1]), cum[:, :-1]], dim=1)
+        w = torch.where(contrib, alpha * T_before, torch.zeros_like(alpha))
+        T_fin = torch.prod(torch.where(contrib, 1.0 - alpha, torch.ones_like(alpha)), dim=1)
+        col = w @ rgb[g] + T_fin[:, None] * bg[None, :]
+        dep = w @ depth_all[g]
+        ft = w.detach() @ feat[g]                                              # Q2
+        idx = torch.arange(1, hi - lo + 1)[None, :] * contrib.to(torch.int64)
+        n_contrib[py.reshape(-1).numpy(), px.reshape(-1).numpy()] = idx.max(dim=1).values.numpy()
+        color_tiles.append(col); feat_tiles.append(ft); depth_tiles.append(dep)
+        slots.append((py.reshape(-1), px.reshape(-1), T_fin.detach()))
+    if slots:
+        PY = torch.cat([s[0] for s in slots]); PX = torch.cat([s[1] for s in slots])
+        out_color = out_color.index_put((torch.arange(3)[:, None], PY[None, :], PX[None, :]), torch.cat(color_tiles).t())
+        if C:
+            out_feat = out_feat.index_put((torch.arange(C)[:, None], PY[None, :], PX[None, :]), torch.cat(feat_tiles).t())
+        out_depth = out_depth.index_put((torch.zeros(1, dtype=torch.int64)[:, None], PY[None, :], PX[None, :]),
+                                        torch.cat(depth_tiles)[None, :])
+        final_T[PY, PX] = torch.cat([s[2] for s in slots])
+    return dict(color=out_color, feature_map=out_feat, depth=out_depth, radii=radii, num_rendered=int(len(vals)),
+                n_contrib=n_contrib, final_T=final_T, point_list=vals, ranges=np.stack([starts, ends], 1))
+
+
+def forward_backward(scene: dict, dtype=torch.float64, use_precomp_color=False, use_precomp_cov=False,
+                     want_grads=True) -> Dict[str, object]:
+    """Run forward (+ autograd backward against the scene's upstream gradients)."""
+    leaf = lambda t: t.detach().clone().to(dtype).requires_grad_(want_grads)
+    P = scene["means3D"].shape[0]
+    L = dict(means3D=leaf(scene["means3D"]), means2D=leaf(torch.zeros(P, 3)), opacities=leaf(scene["opacities"]),
+             semantic_feature=leaf(scene["semantic_feature"]))
+    kw = dict(bg=scene["bg"], viewmatrix=scene["viewmatrix"], projmatrix=scene["projmatrix"], campos=scene["campos"],
+              tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], image_height=scene["image_height"],
+              image_width=scene["image_width"], sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"],
+              dtype=dtype)
+    if use_precomp_color:
+        L["colors_precomp"] = leaf(scene["colors_precomp"])
+    else:
+        L["shs"] = leaf(scene["shs"])
+    if use_precomp_cov:
+        L["cov3D_precomp"] = leaf(scene["cov3D_precomp"])
+    else:
+        L["scales"], L["rotations"] = leaf(scene["scales"]), leaf(scene["rotations"])
+    out = rasterize(**L, **kw)
+    res = dict(out=out, leaves=L)
+    if want_grads:
+        loss = (out["color"] * scene["dL_dcolor"].to(dtype)).sum() + (out["depth"] * scene["dL_ddepth"].to(dtype)).sum()
+        if scene["semantic_feature"].shape[-1]:
+            loss = loss + (out["feature_map"] * scene["dL_dfeature"].to(dtype)).sum()
+        loss.backward()
+        res["grads"] = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in L.items()}
+    return res
