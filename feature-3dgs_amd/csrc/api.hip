@@ -1,0 +1,348 @@
+// api.hip — extern "C" entry points of libf3dgs_hip.so (declared in include/f3dgs.h).
+//
+// Host orchestration of the stages.  Replaces CudaRasterizer::Rasterizer::{markVisible,forward,backward}
+// (reference: submodules/diff-gaussian-rasterization-feature/cuda_rasterizer/rasterizer_impl.cu:141-153,
+// 198-342, 347-461).  Everything is enqueued on the caller's stream; the only host synchronisation is
+// the 4-byte read-back of num_rendered (same place as rasterizer_impl.cu:283).
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace f3dgs;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local std::vector<std::pair<const char*, float>> g_times;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(F3DGS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+bool profiling() {
+    static int on = -1;
+    if (on < 0) {
+        const char* v = getenv("F3DGS_PROFILE");
+        on = (v && atoi(v)) ? 1 : 0;
+    }
+    return on == 1;
+}
+
+// Optional per-stage timing with HIP events on the caller's stream.
+struct StageTimer {
+    hipStream_t s;
+    bool on;
+    std::vector<std::pair<const char*, hipEvent_t>> ev;
+    explicit StageTimer(hipStream_t st) : s(st), on(profiling()) { mark("start"); }
+    void mark(const char* name) {
+        if (!on) return;
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, s);
+        ev.push_back({name, e});
+    }
+    void finish() {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        g_times.clear();
+        for (size_t i = 1; i < ev.size(); i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[i - 1].second, ev[i].second);
+            g_times.push_back({ev[i].first, ms});
+        }
+        for (auto& p : ev) (void)hipEventDestroy(p.second);
+        ev.clear();
+    }
+};
+
+int check_debug(int debug, hipStream_t s, const char* stage) {
+    if (!debug) return F3DGS_OK;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail(F3DGS_ERR_HIP, "stage '%s' failed: %s", stage, hipGetErrorString(e));
+    return F3DGS_OK;
+}
+
+void fill_view(ViewParams& vp, const float* view, const float* proj, const float* campos, float tanx, float tany,
+               int W, int H, float mod) {
+    memcpy(vp.view, view, sizeof vp.view);
+    memcpy(vp.proj, proj, sizeof vp.proj);
+    if (campos) memcpy(vp.campos, campos, sizeof vp.campos);
+    vp.tanx = tanx; vp.tany = tany;
+    vp.fx = W / (2.0f * tanx); vp.fy = H / (2.0f * tany);
+    vp.W = W; vp.H = H;
+    vp.gx = (W + TILE - 1) / TILE; vp.gy = (H + TILE - 1) / TILE;
+    vp.scale_modifier = mod;
+}
+
+// The camera matrices arrive as device pointers (the reference passes device tensors).  They are tiny;
+// fetch them once per call into kernel-argument space so every kernel reads them from SGPRs.
+struct CamHost {
+    float view[16], proj[16], campos[3], bg[3];
+};
+int fetch_camera(CamHost& c, const float* view, const float* proj, const float* campos, const float* bg,
+                 hipStream_t s) {
+    HIP_TRY(hipMemcpyAsync(c.view, view, sizeof c.view, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c.proj, proj, sizeof c.proj, hipMemcpyDeviceToHost, s));
+    if (campos) HIP_TRY(hipMemcpyAsync(c.campos, campos, sizeof c.campos, hipMemcpyDeviceToHost, s));
+    if (bg) HIP_TRY(hipMemcpyAsync(c.bg, bg, sizeof c.bg, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return F3DGS_OK;
+}
+
+int tile_bits(int tiles) {
+    int b = 0;
+    while ((1 << b) < tiles) b++;
+    return b < 1 ? 1 : b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int f3dgs_version(void) { return 100; }
+
+const char* f3dgs_last_error(void) { return g_err.c_str(); }
+
+int f3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                       uint8_t* present, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (P < 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "P < 0");
+    if (P == 0) return F3DGS_OK;
+    if (!means3D || !viewmatrix || !present) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)projmatrix;
+    float view[16];
+    HIP_TRY(hipMemcpyAsync(view, viewmatrix, sizeof view, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    launch_mark_visible(P, means3D, view, present, s);
+    HIP_TRY(hipGetLastError());
+    return F3DGS_OK;
+}
+
+int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_resize_fn binning_resize,
+                  void* binning_ctx, f3dgs_resize_fn image_resize, void* image_ctx, int P, int D, int M, int C,
+                  const float* background, int width, int height, const float* means3D, const float* shs,
+                  const float* colors_precomp, const float* semantic_feature, const float* opacities,
+                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                  const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                  float tan_fovy, int prefiltered, float* out_color, float* out_feature_map, float* out_depth,
+                  int* radii, int debug, void* stream, int* num_rendered) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)prefiltered;  // the reference only uses it to __trap() on an impossible cull (auxiliary.h:162-166)
+    if (num_rendered) *num_rendered = 0;
+    if (P < 0 || C < 0 || width <= 0 || height <= 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (!geometry_resize || !binning_resize || !image_resize) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null resize hook");
+    if (!out_color || !out_depth || (C > 0 && !out_feature_map)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null output");
+    const size_t HW = (size_t)width * height;
+    if (P == 0) {  // rasterize_points.cu:84: outputs stay zero
+        HIP_TRY(hipMemsetAsync(out_color, 0, 3 * HW * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(out_depth, 0, HW * sizeof(float), s));
+        if (C) HIP_TRY(hipMemsetAsync(out_feature_map, 0, (size_t)C * HW * sizeof(float), s));
+        return F3DGS_OK;
+    }
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !background)
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "null input");
+    if (!colors_precomp && !shs) return fail(F3DGS_ERR_INVALID_ARGUMENT, "need shs or colors_precomp");
+    if (!colors_precomp && !cam_pos) return fail(F3DGS_ERR_INVALID_ARGUMENT, "SH colours need cam_pos");
+    if (!cov3D_precomp && (!scales || !rotations))
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "need scales+rotations or cov3D_precomp");
+    if (C > 0 && !semantic_feature) return fail(F3DGS_ERR_INVALID_ARGUMENT, "semantic_feature is null but C > 0");
+    if (shs && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "SH degree %d needs %d coefficients, M = %d", D, (D + 1) * (D + 1), M);
+
+    CamHost cam = {};
+    int rc = fetch_camera(cam, viewmatrix, projmatrix, cam_pos, background, s);
+    if (rc) return rc;
+    ViewParams vp;
+    fill_view(vp, cam.view, cam.proj, cam.campos, tan_fovx, tan_fovy, width, height, scale_modifier);
+    const size_t tiles = (size_t)vp.gx * vp.gy;
+
+    size_t geom_bytes = 0, img_bytes = 0, bin_bytes = 0;
+    GeomState::carve(nullptr, P, &geom_bytes);
+    char* geom_ptr = geometry_resize(geometry_ctx, geom_bytes);
+    if (!geom_ptr) return fail(F3DGS_ERR_ALLOC, "geometry buffer allocation of %zu bytes failed", geom_bytes);
+    GeomState geom = GeomState::carve(geom_ptr, P, nullptr);
+    ImageState::carve(nullptr, HW, tiles, &img_bytes);
+    char* img_ptr = image_resize(image_ctx, img_bytes);
+    if (!img_ptr) return fail(F3DGS_ERR_ALLOC, "image buffer allocation of %zu bytes failed", img_bytes);
+    ImageState img = ImageState::carve(img_ptr, HW, tiles, nullptr);
+
+    StageTimer tm(s);
+    // K1: projection, culling, SH colour, tile counts
+    launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, vp, radii,
+                      geom, s);
+    if ((rc = check_debug(debug, s, "preprocess"))) return rc;
+    tm.mark("preprocess");
+
+    // depth sort of the Gaussians (ids start in index order -> ties keep ascending id)
+    HIP_TRY(hipMemcpyAsync(geom.key_a, geom.depth_key, (size_t)P * 4, hipMemcpyDeviceToDevice, s));
+    launch_iota(geom.val_a, (size_t)P, s);
+    launch_radix_sort_pairs(geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, 32, geom.hist, true, s);
+    if ((rc = check_debug(debug, s, "depth sort"))) return rc;
+    tm.mark("depth_sort");
+    const uint32_t* order = geom.val_a;
+
+    // instance offsets in depth order + total
+    launch_exclusive_scan(geom.tiles_touched, order, geom.offsets, geom.counters, (size_t)P, geom.scan_tmp, s);
+    uint32_t N = 0;
+    HIP_TRY(hipMemcpyAsync(&N, geom.counters, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((int)N < 0) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^31 instances");
+    if (num_rendered) *num_rendered = (int)N;
+    tm.mark("scan+sync");
+
+    BinState::carve(nullptr, N, &bin_bytes);
+    char* bin_ptr = binning_resize(binning_ctx, bin_bytes);
+    if (!bin_ptr) return fail(F3DGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
+    BinState bin = BinState::carve(bin_ptr, N, nullptr);
+
+    if (N > 0) {
+        const int bits = tile_bits((int)tiles);
+        const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
+        // result must land in (tile_sorted, point_list) == the "A" side
+        uint32_t* in_tile = (passes % 2 == 0) ? bin.tile_sorted : bin.tile_tmp;
+        uint32_t* in_id = (passes % 2 == 0) ? bin.point_list : bin.id_tmp;
+        launch_emit_instances(P, geom, order, radii, vp.gx, vp.gy, in_tile, in_id, s);
+        if ((rc = check_debug(debug, s, "emit"))) return rc;
+        tm.mark("emit");
+        launch_radix_sort_pairs(bin.tile_sorted, bin.point_list, bin.tile_tmp, bin.id_tmp, N, bits, bin.hist, true, s);
+        if ((rc = check_debug(debug, s, "tile sort"))) return rc;
+        tm.mark("tile_sort");
+    }
+    launch_tile_ranges(N, bin.tile_sorted, img.ranges, tiles, s);
+    if ((rc = check_debug(debug, s, "ranges"))) return rc;
+    tm.mark("ranges");
+
+    launch_render_forward(vp, C, img.ranges, bin.point_list, geom.rec, semantic_feature, cam.bg, img.final_T,
+                          img.n_contrib, out_color, out_feature_map, out_depth, s);
+    if ((rc = check_debug(debug, s, "render"))) return rc;
+    tm.mark("render_fwd");
+    tm.finish();
+    HIP_TRY(hipGetLastError());
+    return F3DGS_OK;
+}
+
+size_t f3dgs_backward_scratch_bytes(int P, int C) {
+    (void)C;
+    return ((size_t)(P > 0 ? P : 0) * GREC * sizeof(float) + ALIGN - 1) & ~(ALIGN - 1);
+}
+
+int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, int width, int height,
+                   const float* means3D, const float* shs, const float* colors_precomp,
+                   const float* semantic_feature, const float* scales, float scale_modifier, const float* rotations,
+                   const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                   float tan_fovx, float tan_fovy, const int* radii, const char* geom_buffer,
+                   const char* binning_buffer, const char* image_buffer, const float* dL_dpix,
+                   const float* dL_dfeaturepix, const float* dL_depths, float* dL_dmean2D, float* dL_dconic,
+                   float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic_feature, float* dL_dmean3D,
+                   float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dz, void* scratch,
+                   int debug, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)semantic_feature;  // Q3: never read by the reference's backward either
+    (void)colors_precomp;    // colours were copied into the splat records by the forward pass
+    if (P < 0 || C < 0 || R < 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (P == 0) return F3DGS_OK;
+    if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "null state buffer");
+    if (!radii) return fail(F3DGS_ERR_INVALID_ARGUMENT, "radii is required");
+    if (!dL_dpix || !dL_depths || (C > 0 && !dL_dfeaturepix)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null upstream grad");
+    if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || (C > 0 && !dL_dsemantic_feature))
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "null output");
+    if (M > 0 && shs && !dL_dsh) return fail(F3DGS_ERR_INVALID_ARGUMENT, "dL_dsh is null");
+    if (scales && (!dL_dscale || !dL_drot || !rotations)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "scale/rot grads null");
+    if (!scratch) return fail(F3DGS_ERR_INVALID_ARGUMENT, "scratch is null");
+
+    CamHost cam = {};
+    int rc = fetch_camera(cam, viewmatrix, projmatrix, campos, background, s);
+    if (rc) return rc;
+    ViewParams vp;
+    fill_view(vp, cam.view, cam.proj, cam.campos, tan_fovx, tan_fovy, width, height, scale_modifier);
+    const size_t HW = (size_t)width * height, tiles = (size_t)vp.gx * vp.gy;
+    GeomState geom = GeomState::carve(const_cast<char*>(geom_buffer), P, nullptr);
+    BinState bin = BinState::carve(const_cast<char*>(binning_buffer), R, nullptr);
+    ImageState img = ImageState::carve(const_cast<char*>(image_buffer), HW, tiles, nullptr);
+    float* grec = static_cast<float*>(scratch);
+
+    StageTimer tm(s);
+    HIP_TRY(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
+    if (C > 0) HIP_TRY(hipMemsetAsync(dL_dsemantic_feature, 0, (size_t)P * C * sizeof(float), s));
+    tm.mark("zero");
+    if (R > 0)
+        launch_render_backward(vp, C, img.ranges, bin.point_list, geom.rec, cam.bg, img.final_T, img.n_contrib,
+                               dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, s);
+    if ((rc = check_debug(debug, s, "render backward"))) return rc;
+    tm.mark("render_bwd");
+    launch_preprocess_backward(P, D, M, C, means3D, radii, shs, scales, rotations, cov3D_precomp, vp, geom, grec,
+                               dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                               (M > 0 && shs) ? dL_dsh : nullptr, scales ? dL_dscale : nullptr,
+                               scales ? dL_drot : nullptr, dL_dz, s);
+    if ((rc = check_debug(debug, s, "preprocess backward"))) return rc;
+    tm.mark("preprocess_bwd");
+    tm.finish();
+    HIP_TRY(hipGetLastError());
+    return F3DGS_OK;
+}
+
+int f3dgs_debug_read(const char* what, int P, int C, int R, int width, int height, const char* geom_buffer,
+                     const char* binning_buffer, const char* image_buffer, void* host_dst, size_t dst_bytes,
+                     void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)C;
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    const size_t HW = (size_t)width * height, tiles = (size_t)gx * gy;
+    GeomState geom = GeomState::carve(const_cast<char*>(geom_buffer), P, nullptr);
+    BinState bin = BinState::carve(const_cast<char*>(binning_buffer), R, nullptr);
+    ImageState img = ImageState::carve(const_cast<char*>(image_buffer), HW, tiles, nullptr);
+    const std::string w(what);
+    const void* src = nullptr;
+    size_t bytes = 0;
+    if (w == "rec") { src = geom.rec; bytes = (size_t)P * sizeof(SplatRec); }
+    else if (w == "clamped") { src = geom.clamped; bytes = P; }
+    else if (w == "tiles_touched") { src = geom.tiles_touched; bytes = (size_t)P * 4; }
+    else if (w == "depth_key") { src = geom.depth_key; bytes = (size_t)P * 4; }
+    else if (w == "order") { src = geom.val_a; bytes = (size_t)P * 4; }
+    else if (w == "offsets") { src = geom.offsets; bytes = (size_t)P * 4; }
+    else if (w == "point_list") { src = bin.point_list; bytes = (size_t)R * 4; }
+    else if (w == "tile_sorted") { src = bin.tile_sorted; bytes = (size_t)R * 4; }
+    else if (w == "ranges") { src = img.ranges; bytes = tiles * 8; }
+    else if (w == "final_T") { src = img.final_T; bytes = HW * 4; }
+    else if (w == "n_contrib") { src = img.n_contrib; bytes = HW * 4; }
+    else return fail(F3DGS_ERR_INVALID_ARGUMENT, "unknown debug item '%s'", what);
+    if (bytes > dst_bytes) bytes = dst_bytes;
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return F3DGS_OK;
+}
+
+int f3dgs_last_stage_times(const char** names, float* ms, int max_stages) {
+    int n = 0;
+    for (auto& p : g_times) {
+        if (n >= max_stages) break;
+        names[n] = p.first;
+        ms[n] = p.second;
+        n++;
+    }
+    return n;
+}
+
+}  // extern "C"

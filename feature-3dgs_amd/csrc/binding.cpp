@@ -1,0 +1,189 @@
+// binding.cpp — pybind11 / libtorch front-end `diff_gaussian_rasterization._C`.
+//
+// Reproduces the three Python-visible entry points of the reference binding
+//   rasterize_gaussians            (reference: rasterize_points.cu:35-124,  ext.cpp:16)
+//   rasterize_gaussians_backward   (reference: rasterize_points.cu:126-215, ext.cpp:17)
+//   mark_visible                   (reference: rasterize_points.cu:217-236, ext.cpp:18)
+// with identical positional signatures and return tuples, on top of the C ABI of
+// libf3dgs_hip.so (include/f3dgs.h).  PyTorch is plumbing only: tensor allocation through the
+// caching allocator, the current HIP stream, and the three growable byte buffers.
+//
+// Differences to the reference binding, all deliberate:
+//   * the feature dimension C is read from semantic_feature.size(-1) instead of a compile-time macro;
+//   * work is enqueued on PyTorch's CURRENT stream (the reference uses the legacy default stream);
+//   * outputs / gradients are torch::empty (the kernels overwrite every element) — no zero-fill passes;
+//   * inputs that are not on a HIP device raise instead of silently reading host memory.
+
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/extension.h>
+
+#include <stdexcept>
+#include <string>
+#include <tuple>
+
+#include "../../include/f3dgs.h"
+
+namespace {
+
+const float* fptr(const torch::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
+
+char* resize_hook(void* ctx, size_t n) {
+    auto* t = static_cast<torch::Tensor*>(ctx);
+    t->resize_({(long long)n});
+    return reinterpret_cast<char*>(t->data_ptr());
+}
+
+void check_status(int rc, const char* where) {
+    if (rc != F3DGS_OK) throw std::runtime_error(std::string(where) + ": " + f3dgs_last_error());
+}
+
+torch::Tensor dev_f32(const torch::Tensor& t, const char* name) {
+    if (t.numel() == 0) return t;
+    TORCH_CHECK(t.is_cuda(), name, " must live on a HIP device (got ", t.device(), "): the MI355X rasterizer has no CPU path");
+    TORCH_CHECK(t.scalar_type() == torch::kFloat32, name, " must be float32");
+    return t.contiguous();
+}
+
+void* current_stream(const torch::Tensor& ref) {
+    return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(ref.device().index()).stream();
+}
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+                   const torch::Tensor& semantic_feature, const torch::Tensor& opacity, const torch::Tensor& scales,
+                   const torch::Tensor& rotations, const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                   const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+                   const float tan_fovy, const int image_height, const int image_width, const torch::Tensor& sh,
+                   const int degree, const torch::Tensor& campos, const bool prefiltered, const bool debug) {
+    if (means3D.ndimension() != 2 || means3D.size(1) != 3) {
+        AT_ERROR("means3D must have dimensions (num_points, 3)");  // rasterize_points.cu:58-60
+    }
+    TORCH_CHECK(means3D.is_cuda(), "means3D must live on a HIP device: the MI355X rasterizer has no CPU path");
+    const int P = means3D.size(0);
+    const int H = image_height, W = image_width;
+    const int C = semantic_feature.dim() >= 1 ? (int)semantic_feature.size(-1) : 0;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+
+    auto f32 = means3D.options().dtype(torch::kFloat32);
+    torch::Tensor out_color = torch::empty({3, H, W}, f32);
+    torch::Tensor out_depth = torch::empty({1, H, W}, f32);
+    torch::Tensor out_feature_map = torch::empty({C, H, W}, f32);
+    torch::Tensor radii = torch::empty({P}, means3D.options().dtype(torch::kInt32));
+    auto u8 = means3D.options().dtype(torch::kByte);
+    torch::Tensor geomBuffer = torch::empty({0}, u8);
+    torch::Tensor binningBuffer = torch::empty({0}, u8);
+    torch::Tensor imgBuffer = torch::empty({0}, u8);
+
+    auto bg = dev_f32(background, "bg"), m3 = dev_f32(means3D, "means3D"), col = dev_f32(colors, "colors_precomp"),
+         sf = dev_f32(semantic_feature, "semantic_feature"), op = dev_f32(opacity, "opacities"),
+         sc = dev_f32(scales, "scales"), rot = dev_f32(rotations, "rotations"), cov = dev_f32(cov3D_precomp, "cov3D_precomp"),
+         vm = dev_f32(viewmatrix, "viewmatrix"), pm = dev_f32(projmatrix, "projmatrix"), shs = dev_f32(sh, "sh"),
+         cp = dev_f32(campos, "campos");
+    int M = 0;
+    if (shs.numel() != 0) M = shs.size(1);
+
+    int rendered = 0;
+    const int rc = f3dgs_forward(resize_hook, &geomBuffer, resize_hook, &binningBuffer, resize_hook, &imgBuffer, P, degree,
+                                 M, C, fptr(bg), W, H, fptr(m3), fptr(shs), fptr(col), fptr(sf), fptr(op), fptr(sc),
+                                 scale_modifier, fptr(rot), fptr(cov), fptr(vm), fptr(pm), fptr(cp), tan_fovx, tan_fovy,
+                                 prefiltered ? 1 : 0, out_color.data_ptr<float>(),
+                                 C ? out_feature_map.data_ptr<float>() : nullptr, out_depth.data_ptr<float>(),
+                                 P ? radii.data_ptr<int>() : nullptr, debug ? 1 : 0, current_stream(means3D), &rendered);
+    check_status(rc, "rasterize_gaussians");
+    return std::make_tuple(rendered, out_color, out_feature_map, out_depth, radii, geomBuffer, binningBuffer, imgBuffer);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor>
+RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                           const torch::Tensor& colors, const torch::Tensor& semantic_feature,
+                           const torch::Tensor& scales, const torch::Tensor& rotations, const float scale_modifier,
+                           const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                           const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                           const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_feature,
+                           const torch::Tensor& dL_dout_depth, const torch::Tensor& sh, const int degree,
+                           const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                           const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug) {
+    TORCH_CHECK(means3D.is_cuda(), "means3D must live on a HIP device: the MI355X rasterizer has no CPU path");
+    const int P = means3D.size(0);
+    const int H = dL_dout_color.size(1), W = dL_dout_color.size(2);  // rasterize_points.cu:154-155
+    const int C = semantic_feature.dim() >= 1 ? (int)semantic_feature.size(-1) : 0;
+    const int F1 = semantic_feature.dim() >= 2 ? (int)semantic_feature.size(1) : 1;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+
+    auto shs = dev_f32(sh, "sh");
+    int M = 0;
+    if (shs.numel() != 0) M = shs.size(1);
+
+    auto o = means3D.options().dtype(torch::kFloat32);
+    torch::Tensor dL_dmeans3D = torch::empty({P, 3}, o);
+    torch::Tensor dL_dmeans2D = torch::empty({P, 3}, o);
+    torch::Tensor dL_dcolors = torch::empty({P, 3}, o);
+    torch::Tensor dL_dsemantic_feature = torch::empty({P, F1, C}, o);
+    torch::Tensor dL_dopacity = torch::empty({P, 1}, o);
+    torch::Tensor dL_dcov3D = torch::empty({P, 6}, o);
+    torch::Tensor dL_dsh = torch::empty({P, M, 3}, o);
+    torch::Tensor dL_dscales = torch::empty({P, 3}, o);
+    torch::Tensor dL_drotations = torch::empty({P, 4}, o);
+    auto sc = dev_f32(scales, "scales"), rot = dev_f32(rotations, "rotations");
+    if (sc.numel() == 0) {  // cov3D_precomp path: these grads are defined as zero (rasterize_points.cu:171-172)
+        dL_dscales.zero_();
+        dL_drotations.zero_();
+    }
+    torch::Tensor scratch = torch::empty({(long long)f3dgs_backward_scratch_bytes(P, C)}, means3D.options().dtype(torch::kByte));
+
+    auto bg = dev_f32(background, "bg"), m3 = dev_f32(means3D, "means3D"), col = dev_f32(colors, "colors_precomp"),
+         sf = dev_f32(semantic_feature, "semantic_feature"), cov = dev_f32(cov3D_precomp, "cov3D_precomp"),
+         vm = dev_f32(viewmatrix, "viewmatrix"), pm = dev_f32(projmatrix, "projmatrix"), cp = dev_f32(campos, "campos"),
+         gc = dev_f32(dL_dout_color, "dL_dout_color"), gf = dev_f32(dL_dout_feature, "dL_dout_feature"),
+         gd = dev_f32(dL_dout_depth, "dL_dout_depth");
+    TORCH_CHECK(radii.is_cuda() || P == 0, "radii must live on a HIP device");
+    auto rad = radii.contiguous();
+
+    const int rc = f3dgs_backward(
+        P, degree, M, C, R, fptr(bg), W, H, fptr(m3), fptr(shs), fptr(col), fptr(sf), fptr(sc), scale_modifier, fptr(rot),
+        fptr(cov), fptr(vm), fptr(pm), fptr(cp), tan_fovx, tan_fovy, P ? rad.data_ptr<int>() : nullptr,
+        reinterpret_cast<const char*>(geomBuffer.data_ptr()), reinterpret_cast<const char*>(binningBuffer.data_ptr()),
+        reinterpret_cast<const char*>(imageBuffer.data_ptr()), fptr(gc), fptr(gf), fptr(gd),
+        P ? dL_dmeans2D.data_ptr<float>() : nullptr, nullptr, P ? dL_dopacity.data_ptr<float>() : nullptr,
+        P ? dL_dcolors.data_ptr<float>() : nullptr, (P && C) ? dL_dsemantic_feature.data_ptr<float>() : nullptr,
+        P ? dL_dmeans3D.data_ptr<float>() : nullptr, P ? dL_dcov3D.data_ptr<float>() : nullptr,
+        (P && M) ? dL_dsh.data_ptr<float>() : nullptr, P ? dL_dscales.data_ptr<float>() : nullptr,
+        P ? dL_drotations.data_ptr<float>() : nullptr, nullptr, P ? scratch.data_ptr() : nullptr, debug ? 1 : 0,
+        current_stream(means3D));
+    check_status(rc, "rasterize_gaussians_backward");
+    return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dsemantic_feature, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
+                           dL_dscales, dL_drotations);
+}
+
+torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix) {
+    TORCH_CHECK(means3D.is_cuda(), "means3D must live on a HIP device: the MI355X rasterizer has no CPU path");
+    const int P = means3D.size(0);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+    torch::Tensor present = torch::empty({P}, means3D.options().dtype(at::kBool));
+    if (P != 0) {
+        auto m3 = dev_f32(means3D, "means3D"), vm = dev_f32(viewmatrix, "viewmatrix"), pm = dev_f32(projmatrix, "projmatrix");
+        const int rc = f3dgs_mark_visible(P, fptr(m3), fptr(vm), fptr(pm), reinterpret_cast<uint8_t*>(present.data_ptr<bool>()),
+                                          current_stream(means3D));
+        check_status(rc, "mark_visible");
+    }
+    return present;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_C, m) {
+    m.def("rasterize_gaussians", &RasterizeGaussians);
+    m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
+    m.def("mark_visible", &markVisible);
+    m.def("version", []() { return f3dgs_version(); });
+    m.def("last_stage_times", []() {
+        const char* names[32];
+        float ms[32];
+        const int n = f3dgs_last_stage_times(names, ms, 32);
+        std::vector<std::pair<std::string, float>> out;
+        for (int i = 0; i < n; i++) out.emplace_back(names[i], ms[i]);
+        return out;
+    });
+}

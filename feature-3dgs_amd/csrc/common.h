@@ -1,0 +1,181 @@
+// common.h — private declarations shared by the HIP translation units of libf3dgs_hip.so.
+//
+// gfx950 / CDNA4 only: wave64, 256 CUs in 8 XCDs, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/f3dgs.h"
+
+namespace f3dgs {
+
+constexpr int TILE = 16;             // binning tile edge (reference: config.h:18-19)
+constexpr int WAVE = 64;
+constexpr size_t ALIGN = 256;        // alignment of every carved sub-buffer
+
+// One packed splat record per Gaussian: everything the blend kernels need, gathered with three
+// 16-byte loads.  (reference keeps means2D / conic_opacity / rgb / depths in four arrays.)
+//   q0 = {mean_x, mean_y, conic_a, conic_b}   q1 = {conic_c, opacity, red, green}
+//   q2 = {blue, depth, radius (int bits), unused}
+struct SplatRec {
+    float4 q0, q1, q2;
+};
+
+// Per-Gaussian gradient record accumulated by the blend backward (one 48-byte line):
+//   [0] dL/dmean2D.x  [1] dL/dmean2D.y  [2..4] dL/dconic (a, b, c)  [5] dL/dopacity
+//   [6..8] dL/dcolor  [9] dL/dz  [10..11] pad
+constexpr int GREC = 12;
+
+// ---- carving of the three opaque state buffers ---------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off;
+    explicit Carver(char* b) : base(b), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        off = (off + ALIGN - 1) & ~(ALIGN - 1);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t total() const { return (off + ALIGN - 1) & ~(ALIGN - 1); }
+};
+
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX_BINS = 1 << RADIX_BITS;
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;                                  // items per thread
+constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;           // items per workgroup
+constexpr int SCAN_CHUNK = 256 * 16;
+
+inline size_t sort_blocks(size_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
+inline size_t scan_blocks(size_t n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK; }
+
+struct GeomState {
+    SplatRec* rec;            // P
+    uint8_t* clamped;         // P (bit0..2 = r,g,b clamped)
+    uint32_t* tiles_touched;  // P
+    uint32_t* depth_key;      // P   float bits of view-space depth, 0xFFFFFFFF when culled
+    uint32_t* key_a;          // P   ping-pong buffers of the depth sort
+    uint32_t* key_b;
+    uint32_t* val_a;
+    uint32_t* val_b;
+    uint32_t* offsets;        // P   exclusive scan of tiles_touched in depth order
+    uint32_t* hist;           // RADIX_BINS * sort_blocks(P) + RADIX_BINS
+    uint32_t* scan_tmp;       // scan_blocks(P) + 8
+    uint32_t* counters;       // 16 words: [0] = num_rendered
+    static GeomState carve(char* base, size_t P, size_t* bytes) {
+        Carver c(base);
+        GeomState g;
+        g.rec = c.take<SplatRec>(P);
+        g.clamped = c.take<uint8_t>(P);
+        g.tiles_touched = c.take<uint32_t>(P);
+        g.depth_key = c.take<uint32_t>(P);
+        g.key_a = c.take<uint32_t>(P);
+        g.key_b = c.take<uint32_t>(P);
+        g.val_a = c.take<uint32_t>(P);
+        g.val_b = c.take<uint32_t>(P);
+        g.offsets = c.take<uint32_t>(P);
+        g.hist = c.take<uint32_t>(RADIX_BINS * sort_blocks(P) + RADIX_BINS);
+        g.scan_tmp = c.take<uint32_t>(scan_blocks(P) + 8);
+        g.counters = c.take<uint32_t>(16);
+        if (bytes) *bytes = c.total();
+        return g;
+    }
+};
+
+struct BinState {
+    uint32_t* point_list;   // N  (final, sorted by tile then depth)
+    uint32_t* tile_sorted;  // N  tile id of every entry of point_list
+    uint32_t* id_tmp;       // N  ping-pong partners
+    uint32_t* tile_tmp;     // N
+    uint32_t* hist;         // RADIX_BINS * sort_blocks(N) + RADIX_BINS
+    static BinState carve(char* base, size_t N, size_t* bytes) {
+        Carver c(base);
+        BinState b;
+        b.point_list = c.take<uint32_t>(N);
+        b.tile_sorted = c.take<uint32_t>(N);
+        b.id_tmp = c.take<uint32_t>(N);
+        b.tile_tmp = c.take<uint32_t>(N);
+        b.hist = c.take<uint32_t>(RADIX_BINS * sort_blocks(N) + RADIX_BINS);
+        if (bytes) *bytes = c.total();
+        return b;
+    }
+};
+
+struct ImageState {
+    float* final_T;        // H*W
+    uint32_t* n_contrib;   // H*W
+    uint2* ranges;         // tiles
+    static ImageState carve(char* base, size_t HW, size_t tiles, size_t* bytes) {
+        Carver c(base);
+        ImageState s;
+        s.final_T = c.take<float>(HW);
+        s.n_contrib = c.take<uint32_t>(HW);
+        s.ranges = c.take<uint2>(tiles);
+        if (bytes) *bytes = c.total();
+        return s;
+    }
+};
+
+// ---- host-side launchers (one per translation unit) ----------------------------------------------
+struct ViewParams {
+    float view[16];
+    float proj[16];
+    float campos[3];
+    float tanx, tany, fx, fy;
+    int W, H, gx, gy;
+    float scale_modifier;
+};
+
+// preprocess.hip (built with -ffp-contract=off)
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
+                       const float* opacities, const float* shs, const float* cov3D_precomp,
+                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, hipStream_t s);
+void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D, const int* radii, const float* shs,
+                                const float* scales, const float* rotations, const float* cov3D_precomp,
+                                const ViewParams& vp, const GeomState& g, const float* grec, float* dL_dmean2D,
+                                float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dz,
+                                hipStream_t s);
+
+// binning.hip
+void launch_exclusive_scan(const uint32_t* in, const uint32_t* gather, uint32_t* out, uint32_t* total, size_t n,
+                           uint32_t* tmp, hipStream_t s);
+// Stable LSD radix sort of (key,val) u32 pairs on key bits [0, nbits).  Result lands in (key_out,val_out);
+// (key_in,val_in) and the *_tmp buffers are clobbered.  key_out/val_out may alias the tmp or in buffers
+// only as arranged by the caller through the pass parity (see binning.hip).
+void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
+                             uint32_t* hist, bool result_in_a, hipStream_t s);
+void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, const int* radii, int gx, int gy,
+                           uint32_t* inst_tile, uint32_t* inst_id, hipStream_t s);
+void launch_iota(uint32_t* dst, size_t n, hipStream_t s);
+void launch_tile_ranges(size_t N, const uint32_t* tile_sorted, uint2* ranges, size_t tiles, hipStream_t s);
+
+// render_fwd.hip / render_bwd.hip
+void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
+                           const SplatRec* rec, const float* feat, const float* bg, float* final_T,
+                           uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, hipStream_t s);
+void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
+                            const SplatRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                            const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
+                            float* dL_dfeature, hipStream_t s);
+
+// ---- device helpers --------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+// XCD-aware bijective remap of a linear workgroup id: workgroup b runs on XCD b % 8 (observed,
+// MI355X_MICROARCH.md), so give every XCD one contiguous run of tiles to keep neighbouring tiles
+// (which share splat records and feature vectors) behind the same L2.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    constexpr uint32_t X = 8;
+    const uint32_t q = n / X, r = n % X;
+    const uint32_t xcd = b % X, k = b / X;
+    const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+#endif
+
+}  // namespace f3dgs

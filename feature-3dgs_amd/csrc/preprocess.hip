@@ -1,0 +1,484 @@
+// preprocess.hip — per-Gaussian stages: frustum test, projection (forward) and the fused
+// cov2D / mean / SH / cov3D backward.
+//
+// BUILT WITH -ffp-contract=off: these kernels produce the integer artefacts (radii, tile rects,
+// depth sort keys) and must agree bit-for-bit with the oracle, which is built the same way.  They
+// are streaming, HBM-bound kernels; the lost FMA contraction is irrelevant for their speed.
+//
+// Semantics follow (R = submodules/diff-gaussian-rasterization-feature/cuda_rasterizer):
+//   R/auxiliary.h:145-170 (near cull), R/forward.cu:156-256 (preprocess), :119-153 (cov3D),
+//   :75-114 (EWA cov2D), :20-72 (SH colour); R/backward.cu:144-274 + :346-404 (fused here), :20-139, :278-341.
+// The code is written from the mathematics (standard row/column matrix algebra), not from the
+// reference's GLM expressions; operation order inside each 3x3 product is ((p0+p1)+p2).
+
+#include "common.h"
+
+namespace f3dgs {
+
+namespace {
+
+struct M3 {
+    float v[3][3];
+};
+__device__ __forceinline__ M3 mul3(const M3& A, const M3& B) {
+    M3 R;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) R.v[r][c] = A.v[r][0] * B.v[0][c] + A.v[r][1] * B.v[1][c] + A.v[r][2] * B.v[2][c];
+    return R;
+}
+__device__ __forceinline__ M3 tr3(const M3& A) {
+    M3 R;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) R.v[r][c] = A.v[c][r];
+    return R;
+}
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+__device__ __forceinline__ V3 xform3(const float* m, V3 p) {
+    return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
+}
+
+__device__ __forceinline__ float ndc_to_pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1,
+                                          int& y1) {
+    x0 = min(gx, max(0, (int)((px - radius) / TILE)));
+    y0 = min(gy, max(0, (int)((py - radius) / TILE)));
+    x1 = min(gx, max(0, (int)((px + radius + TILE - 1) / TILE)));
+    y1 = min(gy, max(0, (int)((py + radius + TILE - 1) / TILE)));
+}
+
+__device__ __forceinline__ M3 quat_to_rot(float4 q) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;  // no normalisation (forward.cu:128)
+    M3 R;
+    R.v[0][0] = 1.f - 2.f * (y * y + z * z); R.v[0][1] = 2.f * (x * y - r * z); R.v[0][2] = 2.f * (x * z + r * y);
+    R.v[1][0] = 2.f * (x * y + r * z); R.v[1][1] = 1.f - 2.f * (x * x + z * z); R.v[1][2] = 2.f * (y * z - r * x);
+    R.v[2][0] = 2.f * (x * z - r * y); R.v[2][1] = 2.f * (y * z + r * x); R.v[2][2] = 1.f - 2.f * (x * x + y * y);
+    return R;
+}
+
+// Sigma = R S^2 R^T as (S R^T)^T (S R^T); six unique entries.
+__device__ __forceinline__ void cov3d_from_scale_rot(V3 scale, float mod, float4 q, float* cov6) {
+    const float s[3] = {mod * scale.x, mod * scale.y, mod * scale.z};
+    const M3 R = quat_to_rot(q);
+    M3 Mm;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) Mm.v[k][i] = s[k] * R.v[i][k];
+    const M3 Sg = mul3(tr3(Mm), Mm);
+    cov6[0] = Sg.v[0][0]; cov6[1] = Sg.v[1][0]; cov6[2] = Sg.v[2][0];
+    cov6[3] = Sg.v[1][1]; cov6[4] = Sg.v[2][1]; cov6[5] = Sg.v[2][2];
+}
+
+struct Ewa {
+    M3 T, Vrk, Wm;
+    float t[3];
+    bool clamp_x, clamp_y;
+};
+__device__ __forceinline__ Ewa ewa_setup(V3 mean, const ViewParams& vp, const float* cov6) {
+    Ewa e;
+    const V3 tv = xform3(vp.view, mean);
+    e.t[0] = tv.x; e.t[1] = tv.y; e.t[2] = tv.z;
+    const float limx = 1.3f * vp.tanx, limy = 1.3f * vp.tany;
+    const float txtz = e.t[0] / e.t[2], tytz = e.t[1] / e.t[2];
+    e.t[0] = fminf(limx, fmaxf(-limx, txtz)) * e.t[2];
+    e.t[1] = fminf(limy, fmaxf(-limy, tytz)) * e.t[2];
+    e.clamp_x = (txtz < -limx || txtz > limx);
+    e.clamp_y = (tytz < -limy || tytz > limy);
+    M3 J;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) J.v[r][c] = 0.f;
+    J.v[0][0] = vp.fx / e.t[2];
+    J.v[2][0] = -(vp.fx * e.t[0]) / (e.t[2] * e.t[2]);
+    J.v[1][1] = vp.fy / e.t[2];
+    J.v[2][1] = -(vp.fy * e.t[1]) / (e.t[2] * e.t[2]);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) e.Wm.v[r][c] = vp.view[4 * r + c];
+    e.T = mul3(e.Wm, J);
+    e.Vrk.v[0][0] = cov6[0]; e.Vrk.v[0][1] = cov6[1]; e.Vrk.v[0][2] = cov6[2];
+    e.Vrk.v[1][0] = cov6[1]; e.Vrk.v[1][1] = cov6[3]; e.Vrk.v[1][2] = cov6[4];
+    e.Vrk.v[2][0] = cov6[2]; e.Vrk.v[2][1] = cov6[4]; e.Vrk.v[2][2] = cov6[5];
+    return e;
+}
+__device__ __forceinline__ void ewa_cov(const Ewa& e, float& a, float& b, float& c) {
+    const M3 cov = mul3(mul3(tr3(e.T), tr3(e.Vrk)), e.T);
+    a = cov.v[0][0] + 0.3f;
+    b = cov.v[1][0];
+    c = cov.v[1][1] + 0.3f;
+}
+
+__constant__ const float K0 = 0.28209479177387814f;
+__constant__ const float K1 = 0.4886025119029199f;
+__constant__ const float K2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                  -1.0925484305920792f, 0.5462742152960396f};
+__constant__ const float K3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                  0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                  -0.5900435899266435f};
+
+// The SH block of one Gaussian is M*3 contiguous floats; read as V3 (12-byte) elements.
+__device__ __forceinline__ V3 ldv3(const float* p, int k) { return {p[3 * k], p[3 * k + 1], p[3 * k + 2]}; }
+
+__device__ V3 sh_to_rgb(int deg, V3 mean, const float* campos, const float* sh, uint8_t& clamp_bits) {
+    V3 dir = {mean.x - campos[0], mean.y - campos[1], mean.z - campos[2]};
+    const float len = sqrtf(dot3(dir, dir));
+    dir = {dir.x / len, dir.y / len, dir.z / len};
+    V3 res = K0 * ldv3(sh, 0);
+    if (deg > 0) {
+        const float x = dir.x, y = dir.y, z = dir.z;
+        res = res - (K1 * y) * ldv3(sh, 1) + (K1 * z) * ldv3(sh, 2) - (K1 * x) * ldv3(sh, 3);
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = res + (K2[0] * xy) * ldv3(sh, 4) + (K2[1] * yz) * ldv3(sh, 5) +
+                  (K2[2] * (2.0f * zz - xx - yy)) * ldv3(sh, 6) + (K2[3] * xz) * ldv3(sh, 7) +
+                  (K2[4] * (xx - yy)) * ldv3(sh, 8);
+            if (deg > 2) {
+                res = res + ((K3[0] * y) * (3.0f * xx - yy)) * ldv3(sh, 9) + ((K3[1] * xy) * z) * ldv3(sh, 10) +
+                      ((K3[2] * y) * (4.0f * zz - xx - yy)) * ldv3(sh, 11) +
+                      ((K3[3] * z) * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * ldv3(sh, 12) +
+                      ((K3[4] * x) * (4.0f * zz - xx - yy)) * ldv3(sh, 13) + ((K3[5] * z) * (xx - yy)) * ldv3(sh, 14) +
+                      ((K3[6] * x) * (xx - 3.0f * yy)) * ldv3(sh, 15);
+            }
+        }
+    }
+    res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+    clamp_bits = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
+    return {fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f)};
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D, ViewParams vp,
+                                                           uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const V3 p = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+    present[i] = xform3(vp.view, p).z > 0.2f ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+                  const float* __restrict__ rotations, const float* __restrict__ opacities,
+                  const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                  const float* __restrict__ colors_precomp, ViewParams vp, int* __restrict__ radii,
+                  SplatRec* __restrict__ rec, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
+                  uint32_t* __restrict__ depth_key) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    int out_radius = 0;
+    uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu;
+    do {
+        const V3 p = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+        const V3 pv = xform3(vp.view, p);
+        if (pv.z <= 0.2f) break;
+        const float* pm = vp.proj;
+        const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
+        const float hy = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
+        const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+        const float pw = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * pw, projy = hy * pw;
+        float cov6[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov6[k] = cov3D_precomp[6 * (size_t)i + k];
+        } else {
+            const V3 sc = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+            cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov6);
+        }
+        const Ewa e = ewa_setup(p, vp, cov6);
+        float a, b, c;
+        ewa_cov(e, a, b, c);
+        const float det = a * c - b * b;
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float ca = c * det_inv, cb = -b * det_inv, cc = a * det_inv;
+        const float mid = 0.5f * (a + c);
+        const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float l1 = mid + root, l2 = mid - root;
+        const float rad = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+        const float px = ndc_to_pix(projx, vp.W), py = ndc_to_pix(projy, vp.H);
+        int x0, y0, x1, y1;
+        tile_rect(px, py, (int)rad, vp.gx, vp.gy, x0, y0, x1, y1);
+        if ((x1 - x0) * (y1 - y0) == 0) break;
+        V3 col;
+        uint8_t cl = 0;
+        if (colors_precomp) {
+            col = {colors_precomp[3 * (size_t)i], colors_precomp[3 * (size_t)i + 1], colors_precomp[3 * (size_t)i + 2]};
+        } else {
+            col = sh_to_rgb(D, p, vp.campos, shs + 3 * (size_t)M * i, cl);
+        }
+        SplatRec r;
+        r.q0 = make_float4(px, py, ca, cb);
+        r.q1 = make_float4(cc, opacities[i], col.x, col.y);
+        r.q2 = make_float4(col.z, pv.z, __int_as_float((int)rad), 0.f);  // q2.z = radius bits (for emit)
+        rec[i] = r;
+        clamped[i] = cl;
+        out_radius = (int)rad;
+        out_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+        out_key = __float_as_uint(pv.z);
+    } while (false);
+    if (radii) radii[i] = out_radius;
+    tiles_touched[i] = out_tiles;
+    depth_key[i] = out_key;
+    if (out_tiles == 0) clamped[i] = 0;
+}
+
+// ---- backward: K8 (cov2D) + K9 (mean / SH / cov3D) fused, one thread per Gaussian ---------------------
+__device__ void sh_grad(int deg, V3 mean, const float* campos, const float* sh, uint8_t clamp_bits, V3 dcol,
+                        V3& dmean, float* dsh) {
+    const V3 dir_o = {mean.x - campos[0], mean.y - campos[1], mean.z - campos[2]};
+    const float len = sqrtf(dot3(dir_o, dir_o));
+    const V3 dir = {dir_o.x / len, dir_o.y / len, dir_o.z / len};
+    const V3 g = {dcol.x * ((clamp_bits & 1) ? 0.f : 1.f), dcol.y * ((clamp_bits & 2) ? 0.f : 1.f),
+                  dcol.z * ((clamp_bits & 4) ? 0.f : 1.f)};
+    V3 ddx = {0, 0, 0}, ddy = {0, 0, 0}, ddz = {0, 0, 0};
+    const float x = dir.x, y = dir.y, z = dir.z;
+    auto put = [&](int k, V3 v) { dsh[3 * k] = v.x; dsh[3 * k + 1] = v.y; dsh[3 * k + 2] = v.z; };
+    put(0, K0 * g);
+    if (deg > 0) {
+        put(1, (-K1 * y) * g); put(2, (K1 * z) * g); put(3, (-K1 * x) * g);
+        ddx = (-K1) * ldv3(sh, 3); ddy = (-K1) * ldv3(sh, 1); ddz = K1 * ldv3(sh, 2);
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            put(4, (K2[0] * xy) * g); put(5, (K2[1] * yz) * g); put(6, (K2[2] * (2.f * zz - xx - yy)) * g);
+            put(7, (K2[3] * xz) * g); put(8, (K2[4] * (xx - yy)) * g);
+            ddx = ddx + ((K2[0] * y) * ldv3(sh, 4) + (K2[2] * 2.f * -x) * ldv3(sh, 6) + (K2[3] * z) * ldv3(sh, 7) +
+                         (K2[4] * 2.f * x) * ldv3(sh, 8));
+            ddy = ddy + ((K2[0] * x) * ldv3(sh, 4) + (K2[1] * z) * ldv3(sh, 5) + (K2[2] * 2.f * -y) * ldv3(sh, 6) +
+                         (K2[4] * 2.f * -y) * ldv3(sh, 8));
+            ddz = ddz + ((K2[1] * y) * ldv3(sh, 5) + (K2[2] * 2.f * 2.f * z) * ldv3(sh, 6) + (K2[3] * x) * ldv3(sh, 7));
+            if (deg > 2) {
+                put(9, ((K3[0] * y) * (3.f * xx - yy)) * g);
+                put(10, ((K3[1] * xy) * z) * g);
+                put(11, ((K3[2] * y) * (4.f * zz - xx - yy)) * g);
+                put(12, ((K3[3] * z) * (2.f * zz - 3.f * xx - 3.f * yy)) * g);
+                put(13, ((K3[4] * x) * (4.f * zz - xx - yy)) * g);
+                put(14, ((K3[5] * z) * (xx - yy)) * g);
+                put(15, ((K3[6] * x) * (xx - 3.f * yy)) * g);
+                ddx = ddx + ((((K3[0] * ldv3(sh, 9)) * 3.f) * 2.f) * xy + (K3[1] * ldv3(sh, 10)) * yz +
+                             ((K3[2] * ldv3(sh, 11)) * -2.f) * xy + (((K3[3] * ldv3(sh, 12)) * -3.f) * 2.f) * xz +
+                             (K3[4] * ldv3(sh, 13)) * (-3.f * xx + 4.f * zz - yy) + ((K3[5] * ldv3(sh, 14)) * 2.f) * xz +
+                             ((K3[6] * ldv3(sh, 15)) * 3.f) * (xx - yy));
+                ddy = ddy + (((K3[0] * ldv3(sh, 9)) * 3.f) * (xx - yy) + (K3[1] * ldv3(sh, 10)) * xz +
+                             (K3[2] * ldv3(sh, 11)) * (-3.f * yy + 4.f * zz - xx) +
+                             (((K3[3] * ldv3(sh, 12)) * -3.f) * 2.f) * yz + ((K3[4] * ldv3(sh, 13)) * -2.f) * xy +
+                             ((K3[5] * ldv3(sh, 14)) * -2.f) * yz + (((K3[6] * ldv3(sh, 15)) * -3.f) * 2.f) * xy);
+                ddz = ddz + ((K3[1] * ldv3(sh, 10)) * xy + (((K3[2] * ldv3(sh, 11)) * 4.f) * 2.f) * yz +
+                             ((K3[3] * ldv3(sh, 12)) * 3.f) * (2.f * zz - xx - yy) +
+                             (((K3[4] * ldv3(sh, 13)) * 4.f) * 2.f) * xz + (K3[5] * ldv3(sh, 14)) * (xx - yy));
+            }
+        }
+    }
+    const V3 ddir = {dot3(ddx, g), dot3(ddy, g), dot3(ddz, g)};
+    const V3 v = dir_o;
+    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dmean.x += ((+sum2 - v.x * v.x) * ddir.x - v.y * v.x * ddir.y - v.z * v.x * ddir.z) * inv32;
+    dmean.y += (-v.x * v.y * ddir.x + (sum2 - v.y * v.y) * ddir.y - v.z * v.y * ddir.z) * inv32;
+    dmean.z += (-v.x * v.z * ddir.x - v.y * v.z * ddir.y + (sum2 - v.z * v.z) * ddir.z) * inv32;
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
+                           const float* __restrict__ shs, const float* __restrict__ scales,
+                           const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, ViewParams vp,
+                           const uint8_t* __restrict__ clamped, const float* __restrict__ grec,
+                           float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+                           float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
+                           float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+                           float* __restrict__ dL_dscale, float* __restrict__ dL_drot, float* __restrict__ dL_dz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t si = (size_t)i;
+    const bool vis = radii[i] > 0;
+    float gr[GREC];
+    if (vis) {
+        const float4* g4 = reinterpret_cast<const float4*>(grec + si * GREC);
+        const float4 a = g4[0], b = g4[1], c = g4[2];
+        gr[0] = a.x; gr[1] = a.y; gr[2] = a.z; gr[3] = a.w; gr[4] = b.x; gr[5] = b.y; gr[6] = b.z; gr[7] = b.w;
+        gr[8] = c.x; gr[9] = c.y; gr[10] = c.z; gr[11] = c.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < GREC; k++) gr[k] = 0.f;
+    }
+    // pass-through outputs
+    dL_dmean2D[3 * si] = gr[0]; dL_dmean2D[3 * si + 1] = gr[1]; dL_dmean2D[3 * si + 2] = 0.f;
+    dL_dopacity[i] = gr[5];
+    dL_dcolor[3 * si] = gr[6]; dL_dcolor[3 * si + 1] = gr[7]; dL_dcolor[3 * si + 2] = gr[8];
+    if (dL_dconic) {
+        reinterpret_cast<float4*>(dL_dconic)[i] = make_float4(gr[2], gr[3], 0.f, gr[4]);
+    }
+    if (dL_dz) dL_dz[i] = gr[9];
+
+    float dcov6[6] = {0, 0, 0, 0, 0, 0};
+    V3 dmean = {0, 0, 0};
+    float dscale[3] = {0, 0, 0};
+    float drot[4] = {0, 0, 0, 0};
+    const V3 mean = {means3D[3 * si], means3D[3 * si + 1], means3D[3 * si + 2]};
+    if (vis) {
+        float cov6[6];
+        V3 sc = {0, 0, 0};
+        float4 q = make_float4(0, 0, 0, 0);
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov6[k] = cov3D_precomp[6 * si + k];
+        } else {
+            sc = {scales[3 * si], scales[3 * si + 1], scales[3 * si + 2]};
+            q = reinterpret_cast<const float4*>(rotations)[i];
+            cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov6);
+        }
+        // ---- conic -> cov2D -> (cov3D, t) --------------------------------------------------------
+        const Ewa e = ewa_setup(mean, vp, cov6);
+        float a, b, c;
+        ewa_cov(e, a, b, c);
+        const float dca = gr[2], dcb = gr[3], dcc = gr[4];
+        const float denom = a * c - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        // column i / row j of the reference's GLM matrices = (row j, col i) here
+#define TT(i, j) e.T.v[j][i]
+#define VV(i, j) e.Vrk.v[j][i]
+#define WW(i, j) e.Wm.v[j][i]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * dca + 2 * b * c * dcb + (denom - a * c) * dcc);
+            dL_dc = denom2inv * (-a * a * dcc + 2 * a * b * dcb + (denom - a * c) * dca);
+            dL_db = denom2inv * 2 * (b * c * dca - (denom + 2 * b * b) * dcb + a * b * dcc);
+            dcov6[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+            dcov6[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+            dcov6[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+            dcov6[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+            dcov6[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+            dcov6[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+        }
+        const float dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
+                           (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+        const float dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
+                           (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+        const float dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
+                           (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+        const float dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
+                           (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+        const float dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
+                           (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+        const float dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
+                           (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+        const float dJ00 = WW(0, 0) * dT00 + WW(0, 1) * dT01 + WW(0, 2) * dT02;
+        const float dJ02 = WW(2, 0) * dT00 + WW(2, 1) * dT01 + WW(2, 2) * dT02;
+        const float dJ11 = WW(1, 0) * dT10 + WW(1, 1) * dT11 + WW(1, 2) * dT12;
+        const float dJ12 = WW(2, 0) * dT10 + WW(2, 1) * dT11 + WW(2, 2) * dT12;
+#undef TT
+#undef VV
+#undef WW
+        const float tz = 1.f / e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float xm = e.clamp_x ? 0.f : 1.f, ym = e.clamp_y ? 0.f : 1.f;
+        const float dtx = xm * -vp.fx * tz2 * dJ02;
+        const float dty = ym * -vp.fy * tz2 * dJ12;
+        const float dtz = -vp.fx * tz2 * dJ00 - vp.fy * tz2 * dJ11 + (2 * vp.fx * e.t[0]) * tz3 * dJ02 +
+                          (2 * vp.fy * e.t[1]) * tz3 * dJ12;
+        const float* m = vp.view;
+        dmean.x = m[0] * dtx + m[1] * dty + m[2] * dtz;
+        dmean.y = m[4] * dtx + m[5] * dty + m[6] * dtz;
+        dmean.z = m[8] * dtx + m[9] * dty + m[10] * dtz;
+        // ---- screen-space mean + depth -> 3D mean -----------------------------------------------
+        const float* pr = vp.proj;
+        const float mhw = pr[3] * mean.x + pr[7] * mean.y + pr[11] * mean.z + pr[15];
+        const float mw = 1.0f / (mhw + 0.0000001f);
+        const float mul1 = (pr[0] * mean.x + pr[4] * mean.y + pr[8] * mean.z + pr[12]) * mw * mw;
+        const float mul2 = (pr[1] * mean.x + pr[5] * mean.y + pr[9] * mean.z + pr[13]) * mw * mw;
+        const float gx2 = gr[0], gy2 = gr[1];
+        V3 dm;
+        dm.x = (pr[0] * mw - pr[3] * mul1) * gx2 + (pr[1] * mw - pr[3] * mul2) * gy2;
+        dm.y = (pr[4] * mw - pr[7] * mul1) * gx2 + (pr[5] * mw - pr[7] * mul2) * gy2;
+        dm.z = (pr[8] * mw - pr[11] * mul1) * gx2 + (pr[9] * mw - pr[11] * mul2) * gy2;
+        const float dz = gr[9];
+        dm.x += dz * vp.view[2]; dm.y += dz * vp.view[6]; dm.z += dz * vp.view[10];
+        dmean.x += dm.x; dmean.y += dm.y; dmean.z += dm.z;
+        // ---- cov3D -> scale / rotation ------------------------------------------------------------
+        if (scales) {
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            const M3 R = quat_to_rot(q);
+            const float s[3] = {vp.scale_modifier * sc.x, vp.scale_modifier * sc.y, vp.scale_modifier * sc.z};
+            M3 M2, dS;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) M2.v[k][j] = 2.0f * (s[k] * R.v[j][k]);
+            dS.v[0][0] = dcov6[0]; dS.v[0][1] = 0.5f * dcov6[1]; dS.v[0][2] = 0.5f * dcov6[2];
+            dS.v[1][0] = 0.5f * dcov6[1]; dS.v[1][1] = dcov6[3]; dS.v[1][2] = 0.5f * dcov6[4];
+            dS.v[2][0] = 0.5f * dcov6[2]; dS.v[2][1] = 0.5f * dcov6[4]; dS.v[2][2] = dcov6[5];
+            M3 dM = mul3(M2, dS);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dscale[k] = R.v[0][k] * dM.v[k][0] + R.v[1][k] * dM.v[k][1] + R.v[2][k] * dM.v[k][2];
+#pragma unroll
+            for (int j = 0; j < 3; j++) { dM.v[0][j] *= s[0]; dM.v[1][j] *= s[1]; dM.v[2][j] *= s[2]; }
+#define DM(a, b) dM.v[a][b]
+            drot[0] = 2 * z * (DM(0, 1) - DM(1, 0)) + 2 * y * (DM(2, 0) - DM(0, 2)) + 2 * x * (DM(1, 2) - DM(2, 1));
+            drot[1] = 2 * y * (DM(1, 0) + DM(0, 1)) + 2 * z * (DM(2, 0) + DM(0, 2)) + 2 * r * (DM(1, 2) - DM(2, 1)) - 4 * x * (DM(2, 2) + DM(1, 1));
+            drot[2] = 2 * x * (DM(1, 0) + DM(0, 1)) + 2 * r * (DM(2, 0) - DM(0, 2)) + 2 * z * (DM(1, 2) + DM(2, 1)) - 4 * y * (DM(2, 2) + DM(0, 0));
+            drot[3] = 2 * r * (DM(0, 1) - DM(1, 0)) + 2 * x * (DM(2, 0) + DM(0, 2)) + 2 * y * (DM(1, 2) + DM(2, 1)) - 4 * z * (DM(1, 1) + DM(0, 0));
+#undef DM
+        }
+    }
+    // ---- SH gradients (writes all M coefficients; zero where unused / culled) ---------------------
+    if (dL_dsh && M > 0) {
+        float* dsh = dL_dsh + 3 * (size_t)M * si;
+        const int used = vis ? (D + 1) * (D + 1) : 0;
+        for (int k = 3 * (used < M ? used : M); k < 3 * M; k++) dsh[k] = 0.f;
+        if (vis) {
+            const V3 dcol = {gr[6], gr[7], gr[8]};
+            sh_grad(D, mean, vp.campos, shs + 3 * (size_t)M * si, clamped[i], dcol, dmean, dsh);
+        }
+    }
+    dL_dmean3D[3 * si] = dmean.x; dL_dmean3D[3 * si + 1] = dmean.y; dL_dmean3D[3 * si + 2] = dmean.z;
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * si + k] = dcov6[k];
+    if (dL_dscale) { dL_dscale[3 * si] = dscale[0]; dL_dscale[3 * si + 1] = dscale[1]; dL_dscale[3 * si + 2] = dscale[2]; }
+    if (dL_drot) reinterpret_cast<float4*>(dL_drot)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+}  // namespace
+
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {
+    ViewParams vp = {};
+    for (int k = 0; k < 16; k++) vp.view[k] = view[k];
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, vp, present);
+}
+
+void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
+                       const float* opacities, const float* shs, const float* cov3D_precomp,
+                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, hipStream_t s) {
+    hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales, rotations,
+                       opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped, g.tiles_touched,
+                       g.depth_key);
+}
+
+void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D, const int* radii, const float* shs,
+                                const float* scales, const float* rotations, const float* cov3D_precomp,
+                                const ViewParams& vp, const GeomState& g, const float* grec, float* dL_dmean2D,
+                                float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dz,
+                                hipStream_t s) {
+    (void)C;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii, shs,
+                       scales, rotations, cov3D_precomp, vp, g.clamped, grec, dL_dmean2D, dL_dconic, dL_dopacity,
+                       dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dz);
+}
+
+}  // namespace f3dgs

@@ -1,0 +1,55 @@
+// render_common.h — pieces shared by the forward and backward blend kernels.
+//
+// Work decomposition (both kernels): one 16x16 tile per workgroup; the tile is cut into four 8x8
+// quadrants.  A wave (64 lanes) owns PPL quadrants (PPL = pixels per lane in {1,2,4}) and walks the
+// tile's depth-sorted instance list autonomously in wavefront-sized chunks of 64 instances that it
+// stages into its private LDS slice — no workgroup barrier anywhere, waves retire independently as
+// soon as their own pixels are finished (ballot-based early-out).  Lane l of a wave handles pixel
+// (l & 7, l >> 3) of each of its quadrants, so a wave-uniform ballot per quadrant skips the whole
+// blend body for splats that miss the 8x8 block.
+#pragma once
+
+#include "common.h"
+
+namespace f3dgs {
+
+// Gaussian evaluation shared by forward and backward so both take identical skip decisions
+// (R/forward.cu:340-353, R/backward.cu:525-535).  Explicit fmaf keeps the instruction
+// sequence independent of the contraction choices of the surrounding code.
+__device__ __forceinline__ float splat_power(float dx, float dy, float ca, float cb, float cc) {
+    const float q = fmaf(ca * dx, dx, (cc * dy) * dy);
+    return fmaf(-0.5f, q, -((cb * dx) * dy));
+}
+
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float T_MIN = 0.0001f;
+
+// ---- DPP wave reduction (gfx9 row_bcast forms; result valid in lane 63) ---------------------------
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_get<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_get<0x141>(v);       // row_half_mirror
+    v += dpp_get<0x140>(v);       // row_mirror      -> every lane holds its row's sum
+    v += dpp_get<0x142, 0xA>(v);  // row_bcast:15    -> rows 1,3 += previous row
+    v += dpp_get<0x143, 0xC>(v);  // row_bcast:31    -> rows 2,3 += lane 31
+    return v;
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_lane63(v)), 63));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+struct TileGeom {
+    int tx, ty;        // tile coordinates
+};
+
+}  // namespace f3dgs

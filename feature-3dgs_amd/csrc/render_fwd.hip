@@ -1,0 +1,240 @@
+// render_fwd.hip — front-to-back alpha-composited RGB + N-dim feature + depth (forward blend).
+//
+// Semantics: R/cuda_rasterizer/forward.cu:261-396 (R = submodules/diff-gaussian-rasterization-feature),
+// including quirks Q4 (no background on depth/feature) and Q5 (the Gaussian that would push T below
+// 1e-4 is not blended and ends the pixel; n_contrib = list position of the last blended entry).
+//
+// CDNA4 design (see render_common.h for the decomposition):
+//   * per-wave autonomous walk over 64-instance chunks; splat records (48 B) are gathered with three
+//     16-byte loads per lane, the C-float feature vectors with coalesced 16-byte loads
+//     (8 lanes x 16 B = one 128-B vector at C = 32), both staged in the wave's private LDS slice;
+//   * the inner loop reads one instance's data as LDS broadcasts (same address in all lanes);
+//   * PPL pixels per lane amortise every broadcast read over PPL * 64 pixels and keep the blend
+//     VALU-bound instead of LDS-bound;
+//   * wave-uniform ballots skip the feature FMAs for quadrants a splat does not reach and end the
+//     wave as soon as all of its pixels are saturated;
+//   * channels beyond CH are handled by re-walking the list per 64-channel window.
+
+#include "render_common.h"
+
+namespace f3dgs {
+
+namespace {
+
+template <int CH>
+struct FwdChunk {
+    float4 geo[64];  // mean_x, mean_y, conic_a, conic_b
+    float2 co[64];   // conic_c, opacity
+    float4 cd[64];   // r, g, b, depth
+    uint32_t id[64];
+    float feat[64][CH > 0 ? CH : 4];
+};
+
+struct FwdArgs {
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const SplatRec* rec;
+    const float* feat;
+    float bg[3];
+    float* final_T;
+    uint32_t* n_contrib;
+    float* out_color;
+    float* out_feat;
+    float* out_depth;
+    int W, H, gx, gy;
+    int C;        // total feature channels (row stride of feat)
+    int c0, nc;   // channel window handled by this launch
+    int write_base;  // 1: also write colour / depth / final_T / n_contrib
+};
+
+template <int CH, int PPL>
+__global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
+    constexpr int NW = 4 / PPL;
+    constexpr int CHV = CH / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    FwdChunk<CH>& ck = reinterpret_cast<FwdChunk<CH>*>(smem)[NW > 1 ? wave : 0];
+
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const uint2 rg = a.ranges[tile];
+    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x), r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
+
+    const int lx = lane & 7, ly = lane >> 3;
+    float pxf[PPL], pyf[PPL];
+    int pix_id[PPL];
+    bool inside[PPL], done[PPL];
+    float T[PPL], col[PPL][3], dep[PPL];
+    float sf[PPL][CH > 0 ? CH : 1];
+    uint32_t last[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        const int q = wave * PPL + p;
+        const int x = tx * TILE + (q & 1) * 8 + lx, y = ty * TILE + (q >> 1) * 8 + ly;
+        pxf[p] = (float)x; pyf[p] = (float)y;
+        inside[p] = x < a.W && y < a.H;
+        pix_id[p] = y * a.W + x;
+        done[p] = !inside[p];
+        T[p] = 1.0f; dep[p] = 0.f; last[p] = 0;
+        col[p][0] = col[p][1] = col[p][2] = 0.f;
+#pragma unroll
+        for (int c = 0; c < (CH > 0 ? CH : 1); c++) sf[p][c] = 0.f;
+    }
+
+    for (uint32_t base = r_lo; base < r_hi; base += 64) {
+        bool alld = true;
+#pragma unroll
+        for (int p = 0; p < PPL; p++) alld = alld && done[p];
+        if (__all(alld)) break;
+        const int cnt = (int)min(64u, r_hi - base);
+        // ---- stage one chunk: records ...
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) {
+            const uint32_t g = a.point_list[base + lane];
+            const SplatRec* rp = a.rec + g;
+            const float4 q0 = rp->q0, q1 = rp->q1, q2 = rp->q2;
+            ck.geo[lane] = q0;
+            ck.co[lane] = make_float2(q1.x, q1.y);
+            ck.cd[lane] = make_float4(q1.z, q1.w, q2.x, q2.y);
+            ck.id[lane] = g;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- ... and feature vectors (coalesced: CHV lanes x 16 B per instance)
+        if constexpr (CH > 0) {
+            const bool vec_ok = (a.C & 3) == 0 && (a.c0 & 3) == 0;
+            for (int e = lane; e < cnt * CHV; e += 64) {
+                const int inst = e / CHV, v = e % CHV;
+                const uint32_t g = ck.id[inst];
+                const float* src = a.feat + (size_t)g * a.C + a.c0 + 4 * v;
+                float4 f;
+                if (vec_ok && 4 * v + 3 < a.nc) {
+                    f = *reinterpret_cast<const float4*>(src);
+                } else {
+                    f.x = 4 * v + 0 < a.nc ? src[0] : 0.f;
+                    f.y = 4 * v + 1 < a.nc ? src[1] : 0.f;
+                    f.z = 4 * v + 2 < a.nc ? src[2] : 0.f;
+                    f.w = 4 * v + 3 < a.nc ? src[3] : 0.f;
+                }
+                *reinterpret_cast<float4*>(&ck.feat[inst][4 * v]) = f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- blend the chunk
+        for (int j = 0; j < cnt; j++) {
+            const float4 g0 = ck.geo[j];
+            const float2 g1 = ck.co[j];
+            float w[PPL];
+            bool any_blend = false;
+#pragma unroll
+            for (int p = 0; p < PPL; p++) {
+                const float dx = g0.x - pxf[p], dy = g0.y - pyf[p];
+                const float power = splat_power(dx, dy, g0.z, g0.w, g1.x);
+                const float alpha = fminf(ALPHA_MAX, g1.y * __expf(power));
+                bool ok = !done[p] && !(power > 0.0f) && !(alpha < ALPHA_MIN);
+                const float test_T = T[p] * (1.0f - alpha);
+                if (ok && test_T < T_MIN) {
+                    done[p] = true;
+                    ok = false;
+                }
+                w[p] = ok ? alpha * T[p] : 0.0f;
+                if (ok) {
+                    T[p] = test_T;
+                    last[p] = base - r_lo + j + 1;
+                }
+                any_blend = any_blend || ok;
+            }
+            if (__any(any_blend)) {
+                const float4 cd = ck.cd[j];
+#pragma unroll
+                for (int p = 0; p < PPL; p++) {
+                    col[p][0] = fmaf(cd.x, w[p], col[p][0]);
+                    col[p][1] = fmaf(cd.y, w[p], col[p][1]);
+                    col[p][2] = fmaf(cd.z, w[p], col[p][2]);
+                    dep[p] = fmaf(cd.w, w[p], dep[p]);
+                }
+                if constexpr (CH > 0) {
+#pragma unroll
+                    for (int v = 0; v < CHV; v++) {
+                        const float4 f = *reinterpret_cast<const float4*>(&ck.feat[j][4 * v]);
+#pragma unroll
+                        for (int p = 0; p < PPL; p++) {
+                            sf[p][4 * v + 0] = fmaf(f.x, w[p], sf[p][4 * v + 0]);
+                            sf[p][4 * v + 1] = fmaf(f.y, w[p], sf[p][4 * v + 1]);
+                            sf[p][4 * v + 2] = fmaf(f.z, w[p], sf[p][4 * v + 2]);
+                            sf[p][4 * v + 3] = fmaf(f.w, w[p], sf[p][4 * v + 3]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const size_t HW = (size_t)a.W * a.H;
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        if (!inside[p]) continue;
+        const size_t pid = (size_t)pix_id[p];
+        if (a.write_base) {
+            a.final_T[pid] = T[p];
+            a.n_contrib[pid] = last[p];
+            a.out_color[pid] = col[p][0] + T[p] * a.bg[0];
+            a.out_color[HW + pid] = col[p][1] + T[p] * a.bg[1];
+            a.out_color[2 * HW + pid] = col[p][2] + T[p] * a.bg[2];
+            a.out_depth[pid] = dep[p];
+        }
+        if constexpr (CH > 0) {
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+                if (c < a.nc) a.out_feat[(size_t)(a.c0 + c) * HW + pid] = sf[p][c];
+        }
+    }
+}
+
+template <int CH, int PPL>
+void launch_one(const FwdArgs& a, hipStream_t s) {
+    constexpr int NW = 4 / PPL;
+    const size_t lds = NW * sizeof(FwdChunk<CH>);
+    hipLaunchKernelGGL((render_forward_kernel<CH, PPL>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
+                           const SplatRec* rec, const float* feat, const float* bg, float* final_T,
+                           uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, hipStream_t s) {
+    FwdArgs a;
+    a.ranges = ranges; a.point_list = point_list; a.rec = rec; a.feat = feat;
+    a.bg[0] = bg[0]; a.bg[1] = bg[1]; a.bg[2] = bg[2];
+    a.final_T = final_T; a.n_contrib = n_contrib; a.out_color = out_color; a.out_feat = out_feat;
+    a.out_depth = out_depth;
+    a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
+    const int ppl = env_int("F3DGS_FWD_PPL", 0);
+    if (C == 0) {
+        a.c0 = 0; a.nc = 0; a.write_base = 1;
+        if (ppl == 1) launch_one<0, 1>(a, s);
+        else if (ppl == 2) launch_one<0, 2>(a, s);
+        else launch_one<0, 4>(a, s);
+        return;
+    }
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        a.c0 = c0; a.nc = min(64, C - c0); a.write_base = (c0 == 0);
+        if (a.nc <= 4) {
+            if (ppl == 1) launch_one<4, 1>(a, s); else if (ppl == 2) launch_one<4, 2>(a, s); else launch_one<4, 4>(a, s);
+        } else if (a.nc <= 16) {
+            if (ppl == 1) launch_one<16, 1>(a, s); else if (ppl == 2) launch_one<16, 2>(a, s); else launch_one<16, 4>(a, s);
+        } else if (a.nc <= 32) {
+            if (ppl == 1) launch_one<32, 1>(a, s); else if (ppl == 4) launch_one<32, 4>(a, s); else launch_one<32, 2>(a, s);
+        } else {
+            if (ppl == 2) launch_one<64, 2>(a, s); else launch_one<64, 1>(a, s);
+        }
+    }
+}
+
+}  // namespace f3dgs

@@ -1,0 +1,91 @@
+"""Helpers shared by the parity tests: run a synth scene through the HIP op / the oracle and compare."""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "feature-3dgs_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GRAD_NAMES = ["dL_dmeans3D", "dL_dmeans2D", "dL_dsh", "dL_dcolors", "dL_dsemantic_feature", "dL_dopacity",
+              "dL_dscales", "dL_drotations", "dL_dcov3D"]
+
+
+def precompute_optionals(scene: dict) -> dict:
+    """Add colors_precomp / cov3D_precomp variants (plain torch fp32, same formulas the reference's Python
+    fall-backs use: gaussian_renderer/__init__.py:218-238)."""
+    from oracle.torch_oracle import _quat_to_rot, _sh_to_rgb
+    sc = dict(scene)
+    d = scene["means3D"] - scene["campos"][None]
+    d = d / d.norm(dim=1, keepdim=True)
+    sc["colors_precomp"] = torch.clamp_min(_sh_to_rgb(scene["sh_degree"], scene["shs"], d) + 0.5, 0.0).contiguous()
+    R = _quat_to_rot(scene["rotations"])
+    L = R * (scene["scale_modifier"] * scene["scales"])[:, None, :]
+    S = L @ L.transpose(1, 2)
+    sc["cov3D_precomp"] = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous()
+    return sc
+
+
+def run_oracle(scene: dict, use_precomp_color=False, use_precomp_cov=False, backward=True):
+    from oracle.oracle import Oracle, scene_kwargs
+    o = Oracle()
+    out = o.forward(**scene_kwargs(scene, use_precomp_color, use_precomp_cov))
+    grads = o.backward(scene["dL_dcolor"], scene["dL_dfeature"], scene["dL_ddepth"]) if backward else None
+    return o, out, grads
+
+
+def run_hip(scene: dict, use_precomp_color=False, use_precomp_cov=False, backward=True, device="cuda:0",
+            debug=False):
+    """Run through the reference-compatible Python surface (-> _C -> C ABI -> HIP kernels)."""
+    import diff_gaussian_rasterization as dgr
+    dev = torch.device(device)
+    t = lambda x: x.to(dev)
+    P = scene["means3D"].shape[0]
+    settings = dgr.GaussianRasterizationSettings(
+        image_height=scene["image_height"], image_width=scene["image_width"], tanfovx=scene["tanfovx"],
+        tanfovy=scene["tanfovy"], bg=t(scene["bg"]), scale_modifier=scene["scale_modifier"],
+        viewmatrix=t(scene["viewmatrix"]), projmatrix=t(scene["projmatrix"]), sh_degree=scene["sh_degree"],
+        campos=t(scene["campos"]), prefiltered=False, debug=debug)
+    leaf = lambda x: t(x).clone().requires_grad_(backward)
+    L = dict(means3D=leaf(scene["means3D"]), means2D=leaf(torch.zeros(P, 3)), opacities=leaf(scene["opacities"]),
+             semantic_feature=leaf(scene["semantic_feature"]))
+    if use_precomp_color:
+        L["colors_precomp"] = leaf(scene["colors_precomp"])
+    else:
+        L["shs"] = leaf(scene["shs"])
+    if use_precomp_cov:
+        L["cov3D_precomp"] = leaf(scene["cov3D_precomp"])
+    else:
+        L["scales"], L["rotations"] = leaf(scene["scales"]), leaf(scene["rotations"])
+    color, feat, radii, depth = dgr.GaussianRasterizer(settings)(**L)
+    out = dict(color=color.detach().cpu().numpy(), feature_map=feat.detach().cpu().numpy(),
+               depth=depth.detach().cpu().numpy(), radii=radii.cpu().numpy())
+    grads = None
+    if backward:
+        loss = (color * t(scene["dL_dcolor"])).sum() + (depth * t(scene["dL_ddepth"])).sum()
+        if scene["C"]:
+            loss = loss + (feat * t(scene["dL_dfeature"])).sum()
+        loss.backward()
+        g = lambda k: (L[k].grad.detach().cpu().numpy() if k in L and L[k].grad is not None else None)
+        grads = dict(dL_dmeans3D=g("means3D"), dL_dmeans2D=g("means2D"), dL_dsh=g("shs"),
+                     dL_dcolors=g("colors_precomp"), dL_dsemantic_feature=g("semantic_feature"),
+                     dL_dopacity=g("opacities"), dL_dscales=g("scales"), dL_drotations=g("rotations"),
+                     dL_dcov3D=g("cov3D_precomp"))
+    torch.cuda.synchronize()
+    return out, grads
+
+
+def grad_report(name, got, want, rel=1e-3):
+    """Error of `got` against `want` relative to the tensor's max magnitude; returns (max_rel, frac_bad)."""
+    want = np.asarray(want, np.float64).reshape(-1)
+    got = np.asarray(got, np.float64).reshape(-1)
+    scale = np.abs(want).max() + 1e-30
+    err = np.abs(got - want)
+    bad = err > rel * np.abs(want) + rel * 1e-2 * scale
+    return float(err.max() / scale), float(bad.mean())
