@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,7 +20,6 @@ using namespace f3dgs;
 namespace {
 
 thread_local std::string g_err;
-thread_local std::vector<std::pair<const char*, float>> g_times;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -37,6 +37,9 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(F3DGS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// ---- optional per-stage profiling (F3DGS_PROFILE=1) ----------------------------------------------------
+// HIP events are recorded on the caller's stream around every stage and resolved lazily when the
+// totals are read, so the timed region itself is never synchronised.
 bool profiling() {
     static int on = -1;
     if (on < 0) {
@@ -46,32 +49,59 @@ bool profiling() {
     return on == 1;
 }
 
-// Optional per-stage timing with HIP events on the caller's stream.
+struct PendingSpan {
+    const char* name;
+    hipEvent_t a, b;
+};
+std::mutex g_prof_mu;
+std::vector<PendingSpan> g_pending;
+std::vector<std::pair<const char*, std::pair<double, long>>> g_totals;  // name -> (ms, calls)
+
 struct StageTimer {
     hipStream_t s;
     bool on;
-    std::vector<std::pair<const char*, hipEvent_t>> ev;
-    explicit StageTimer(hipStream_t st) : s(st), on(profiling()) { mark("start"); }
+    hipEvent_t prev;
+    explicit StageTimer(hipStream_t st) : s(st), on(profiling()), prev(nullptr) {
+        if (on) {
+            (void)hipEventCreate(&prev);
+            (void)hipEventRecord(prev, s);
+        }
+    }
     void mark(const char* name) {
         if (!on) return;
         hipEvent_t e;
         (void)hipEventCreate(&e);
         (void)hipEventRecord(e, s);
-        ev.push_back({name, e});
+        hipEvent_t e2;  // the end event doubles as the next span's start: keep a second handle alive
+        (void)hipEventCreate(&e2);
+        (void)hipEventRecord(e2, s);
+        {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_pending.push_back({name, prev, e});
+        }
+        prev = e2;
     }
     void finish() {
-        if (!on) return;
-        (void)hipStreamSynchronize(s);
-        g_times.clear();
-        for (size_t i = 1; i < ev.size(); i++) {
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, ev[i - 1].second, ev[i].second);
-            g_times.push_back({ev[i].first, ms});
-        }
-        for (auto& p : ev) (void)hipEventDestroy(p.second);
-        ev.clear();
+        if (on && prev) (void)hipEventDestroy(prev);
+        prev = nullptr;
     }
 };
+
+void resolve_pending() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& p : g_pending) {
+        (void)hipEventSynchronize(p.b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, p.a, p.b);
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+        bool found = false;
+        for (auto& t : g_totals)
+            if (strcmp(t.first, p.name) == 0) { t.second.first += ms; t.second.second++; found = true; break; }
+        if (!found) g_totals.push_back({p.name, {ms, 1}});
+    }
+    g_pending.clear();
+}
 
 int check_debug(int debug, hipStream_t s, const char* stage) {
     if (!debug) return F3DGS_OK;
@@ -106,6 +136,13 @@ int fetch_camera(CamHost& c, const float* view, const float* proj, const float* 
     if (bg) HIP_TRY(hipMemcpyAsync(c.bg, bg, sizeof c.bg, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return F3DGS_OK;
+}
+
+// F3DGS_TILE_CULL=0 keeps the reference's bounding-rectangle instance lists (bit-identical intermediate
+// state, used by the parity tests); the default drops instances that cannot blend in a tile.
+int tile_cull_enabled() {
+    const char* v = getenv("F3DGS_TILE_CULL");
+    return (v && atoi(v) == 0) ? 0 : 1;
 }
 
 int tile_bits(int tiles) {
@@ -187,8 +224,9 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
 
     StageTimer tm(s);
     // K1: projection, culling, SH colour, tile counts
+    const int cull = tile_cull_enabled();
     launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, vp, radii,
-                      geom, s);
+                      geom, cull, s);
     if ((rc = check_debug(debug, s, "preprocess"))) return rc;
     tm.mark("preprocess");
 
@@ -201,12 +239,14 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     const uint32_t* order = geom.val_a;
 
     // instance offsets in depth order + total
-    launch_exclusive_scan(geom.tiles_touched, order, geom.offsets, geom.counters, (size_t)P, geom.scan_tmp, s);
-    uint32_t N = 0;
-    HIP_TRY(hipMemcpyAsync(&N, geom.counters, 4, hipMemcpyDeviceToHost, s));
+    launch_exclusive_scan(geom.tiles_touched, order, geom.offsets, geom.counters, (size_t)P, geom.scan_tmp,
+                          geom.ref_partial, (size_t)(P + 255) / 256, geom.counters + 1, s);
+    uint32_t counts[2] = {0, 0};   // [0] instances in our lists, [1] the reference's bounding-rectangle count
+    HIP_TRY(hipMemcpyAsync(counts, geom.counters, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if ((int)N < 0) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^31 instances");
-    if (num_rendered) *num_rendered = (int)N;
+    const uint32_t N = counts[0];
+    if ((int)N < 0 || (int)counts[1] < 0) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^31 instances");
+    if (num_rendered) *num_rendered = (int)counts[1];
     tm.mark("scan+sync");
 
     BinState::carve(nullptr, N, &bin_bytes);
@@ -220,7 +260,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
         // result must land in (tile_sorted, point_list) == the "A" side
         uint32_t* in_tile = (passes % 2 == 0) ? bin.tile_sorted : bin.tile_tmp;
         uint32_t* in_id = (passes % 2 == 0) ? bin.point_list : bin.id_tmp;
-        launch_emit_instances(P, geom, order, radii, vp.gx, vp.gy, in_tile, in_id, s);
+        launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, s);
         if ((rc = check_debug(debug, s, "emit"))) return rc;
         tm.mark("emit");
         launch_radix_sort_pairs(bin.tile_sorted, bin.point_list, bin.tile_tmp, bin.id_tmp, N, bits, bin.hist, true, s);
@@ -277,6 +317,7 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     fill_view(vp, cam.view, cam.proj, cam.campos, tan_fovx, tan_fovy, width, height, scale_modifier);
     const size_t HW = (size_t)width * height, tiles = (size_t)vp.gx * vp.gy;
     GeomState geom = GeomState::carve(const_cast<char*>(geom_buffer), P, nullptr);
+    // R is the reference-style count; our (possibly culled) list sits at offset 0 of the binning buffer.
     BinState bin = BinState::carve(const_cast<char*>(binning_buffer), R, nullptr);
     ImageState img = ImageState::carve(const_cast<char*>(image_buffer), HW, tiles, nullptr);
     float* grec = static_cast<float*>(scratch);
@@ -320,6 +361,7 @@ int f3dgs_debug_read(const char* what, int P, int C, int R, int width, int heigh
     else if (w == "depth_key") { src = geom.depth_key; bytes = (size_t)P * 4; }
     else if (w == "order") { src = geom.val_a; bytes = (size_t)P * 4; }
     else if (w == "offsets") { src = geom.offsets; bytes = (size_t)P * 4; }
+    else if (w == "counters") { src = geom.counters; bytes = 16 * 4; }
     else if (w == "point_list") { src = bin.point_list; bytes = (size_t)R * 4; }
     else if (w == "tile_sorted") { src = bin.tile_sorted; bytes = (size_t)R * 4; }
     else if (w == "ranges") { src = img.ranges; bytes = tiles * 8; }
@@ -334,15 +376,24 @@ int f3dgs_debug_read(const char* what, int P, int C, int R, int width, int heigh
     return F3DGS_OK;
 }
 
-int f3dgs_last_stage_times(const char** names, float* ms, int max_stages) {
+int f3dgs_profile_read(const char** names, double* total_ms, long* calls, int max_stages) {
+    resolve_pending();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     int n = 0;
-    for (auto& p : g_times) {
+    for (auto& t : g_totals) {
         if (n >= max_stages) break;
-        names[n] = p.first;
-        ms[n] = p.second;
+        names[n] = t.first;
+        total_ms[n] = t.second.first;
+        calls[n] = t.second.second;
         n++;
     }
     return n;
+}
+
+void f3dgs_profile_reset(void) {
+    resolve_pending();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_totals.clear();
 }
 
 }  // extern "C"

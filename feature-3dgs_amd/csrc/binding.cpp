@@ -21,6 +21,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "../../include/f3dgs.h"
 
@@ -178,12 +179,14 @@ PYBIND11_MODULE(_C, m) {
     m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
     m.def("mark_visible", &markVisible);
     m.def("version", []() { return f3dgs_version(); });
-    m.def("last_stage_times", []() {
-        const char* names[32];
-        float ms[32];
-        const int n = f3dgs_last_stage_times(names, ms, 32);
-        std::vector<std::pair<std::string, float>> out;
-        for (int i = 0; i < n; i++) out.emplace_back(names[i], ms[i]);
+    m.def("profile_reset", []() { f3dgs_profile_reset(); });
+    m.def("profile_read", []() {
+        const char* names[64];
+        double ms[64];
+        long calls[64];
+        const int n = f3dgs_profile_read(names, ms, calls, 64);
+        std::vector<std::tuple<std::string, double, long>> out;
+        for (int i = 0; i < n; i++) out.emplace_back(names[i], ms[i], calls[i]);
         return out;
     });
 }

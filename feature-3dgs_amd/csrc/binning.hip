@@ -66,8 +66,17 @@ __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* __rest
 }
 
 __global__ void __launch_bounds__(256) scan_spine_kernel(uint32_t* __restrict__ block_sums, size_t nb,
-                                                         uint32_t* __restrict__ total) {
+                                                         uint32_t* __restrict__ total,
+                                                         const uint32_t* __restrict__ extra, size_t n_extra,
+                                                         uint32_t* __restrict__ extra_total) {
     __shared__ uint32_t sh[8];
+    if (extra) {
+        uint32_t acc = 0;
+        for (size_t i = threadIdx.x; i < n_extra; i += 256) acc += extra[i];
+        uint32_t tot;
+        block_excl_scan_256(acc, sh, &tot);
+        if (threadIdx.x == 0) *extra_total = tot;
+    }
     uint32_t carry = 0;
     for (size_t base = 0; base < nb; base += 256) {
         const size_t i = base + threadIdx.x;
@@ -201,39 +210,6 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     }
 }
 
-// ---------------- instance emission (depth order) ------------------------------------------------------
-__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1,
-                                          int& y1) {
-    // same expression tree as preprocess.hip (R/auxiliary.h:46-56); no contraction is possible here
-    x0 = min(gx, max(0, (int)((px - radius) / TILE)));
-    y0 = min(gy, max(0, (int)((py - radius) / TILE)));
-    x1 = min(gx, max(0, (int)((px + radius + TILE - 1) / TILE)));
-    y1 = min(gy, max(0, (int)((py + radius + TILE - 1) / TILE)));
-}
-
-__global__ void __launch_bounds__(256)
-emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                      const uint32_t* __restrict__ tiles_touched, const SplatRec* __restrict__ rec,
-                      int gx, int gy, uint32_t* __restrict__ inst_tile,
-                      uint32_t* __restrict__ inst_id) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t g = order[i];
-    const uint32_t cnt = tiles_touched[g];
-    if (cnt == 0) return;
-    uint32_t off = offsets[i];
-    const float4 q0 = rec[g].q0;
-    const int radius = __float_as_int(rec[g].q2.z);  // integer bits stored by preprocess_kernel
-    int x0, y0, x1, y1;
-    tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            inst_tile[off] = (uint32_t)(y * gx + x);
-            inst_id[off] = g;
-            off++;
-        }
-}
-
 __global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = (uint32_t)i;
@@ -259,11 +235,11 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(size_t N, const uint32
 }  // namespace
 
 void launch_exclusive_scan(const uint32_t* in, const uint32_t* gather, uint32_t* out, uint32_t* total, size_t n,
-                           uint32_t* tmp, hipStream_t s) {
+                           uint32_t* tmp, const uint32_t* extra, size_t n_extra, uint32_t* extra_total, hipStream_t s) {
     const size_t nb = scan_blocks(n);
     if (nb == 0) return;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, in, gather, n, tmp);
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, s, tmp, nb, total);
+    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, s, tmp, nb, total, extra, n_extra, extra_total);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, in, gather, n, tmp, out);
 }
 
@@ -287,13 +263,6 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
                            hist, totals);
         in_a = !in_a;
     }
-}
-
-void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, const int* radii, int gx, int gy,
-                           uint32_t* inst_tile, uint32_t* inst_id, hipStream_t s) {
-    (void)radii;
-    hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.offsets,
-                       g.tiles_touched, g.rec, gx, gy, inst_tile, inst_id);
 }
 
 void launch_iota(uint32_t* dst, size_t n, hipStream_t s) {

@@ -65,7 +65,8 @@ struct GeomState {
     uint32_t* offsets;        // P   exclusive scan of tiles_touched in depth order
     uint32_t* hist;           // RADIX_BINS * sort_blocks(P) + RADIX_BINS
     uint32_t* scan_tmp;       // scan_blocks(P) + 8
-    uint32_t* counters;       // 16 words: [0] = num_rendered
+    uint32_t* ref_partial;    // one bounding-rectangle tile count per preprocess workgroup ((P+255)/256)
+    uint32_t* counters;       // 16 words: [0] = instances in the (culled) lists, [1] = reference num_rendered
     static GeomState carve(char* base, size_t P, size_t* bytes) {
         Carver c(base);
         GeomState g;
@@ -80,6 +81,7 @@ struct GeomState {
         g.offsets = c.take<uint32_t>(P);
         g.hist = c.take<uint32_t>(RADIX_BINS * sort_blocks(P) + RADIX_BINS);
         g.scan_tmp = c.take<uint32_t>(scan_blocks(P) + 8);
+        g.ref_partial = c.take<uint32_t>((P + 255) / 256 + 1);
         g.counters = c.take<uint32_t>(16);
         if (bytes) *bytes = c.total();
         return g;
@@ -134,7 +136,8 @@ struct ViewParams {
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
-                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, hipStream_t s);
+                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull,
+                       hipStream_t s);
 void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D, const int* radii, const float* shs,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
                                 const ViewParams& vp, const GeomState& g, const float* grec, float* dL_dmean2D,
@@ -143,14 +146,16 @@ void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D
                                 hipStream_t s);
 
 // binning.hip
+// Exclusive scan of in[gather[i]] (or in[i]); *total receives the grand total.  If `extra` is given its
+// `n_extra` values are summed into *extra_total by the spine kernel (rides along for free).
 void launch_exclusive_scan(const uint32_t* in, const uint32_t* gather, uint32_t* out, uint32_t* total, size_t n,
-                           uint32_t* tmp, hipStream_t s);
+                           uint32_t* tmp, const uint32_t* extra, size_t n_extra, uint32_t* extra_total, hipStream_t s);
 // Stable LSD radix sort of (key,val) u32 pairs on key bits [0, nbits).  Result lands in (key_out,val_out);
 // (key_in,val_in) and the *_tmp buffers are clobbered.  key_out/val_out may alias the tmp or in buffers
 // only as arranged by the caller through the pass parity (see binning.hip).
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
                              uint32_t* hist, bool result_in_a, hipStream_t s);
-void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, const int* radii, int gx, int gy,
+void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
                            uint32_t* inst_tile, uint32_t* inst_id, hipStream_t s);
 void launch_iota(uint32_t* dst, size_t n, hipStream_t s);
 void launch_tile_ranges(size_t N, const uint32_t* tile_sorted, uint2* ranges, size_t tiles, hipStream_t s);

@@ -61,6 +61,58 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
     y1 = min(gy, max(0, (int)((py + radius + TILE - 1) / TILE)));
 }
 
+
+// ---- exact-safe tile culling ---------------------------------------------------------------------------
+// A splat blends at a pixel only if alpha = opacity * exp(power) >= 1/255, i.e. iff
+//   q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 opacity)      (d = mean - pixel centre).
+// The reference emits one instance for EVERY tile of the 3-sigma bounding rectangle
+// (rasterizer_impl.cu:98-109); about half of those can never pass the test above for any pixel of the
+// tile.  tile_hit() minimises q over the tile's pixel-centre rectangle exactly (q is convex: the minimum
+// is 0 if the mean lies inside, otherwise it sits on one of the four edges at the clamped 1-D minimiser)
+// and keeps the tile unless the minimum exceeds the threshold by a safety margin that is orders of
+// magnitude above the round-off of the blend kernels' own power / expf evaluation.  Dropped instances
+// would have been skipped for every pixel, so images, gradients and radii are unchanged; only the private
+// instance lists get shorter.  The count and the emission run the same code in this translation unit
+// (no contraction), so they always agree.
+struct CullParams {
+    float mx, my, a, b, c, thresh;   // thresh = 2 * (ln(255 o) + margin); negative => never visible
+};
+__device__ __forceinline__ CullParams make_cull(float mx, float my, float ca, float cb, float cc, float opacity) {
+    CullParams k;
+    k.mx = mx; k.my = my; k.a = ca; k.b = cb; k.c = cc;
+    const float s = 255.0f * opacity;
+    k.thresh = s > 1.0f ? 2.0f * (logf(s) * 1.0001f + 1e-3f) : -1.0f;
+    return k;
+}
+__device__ __forceinline__ float quad_form(const CullParams& k, float dx, float dy) {
+    return (k.a * dx) * dx + 2.0f * ((k.b * dx) * dy) + (k.c * dy) * dy;
+}
+__device__ __forceinline__ bool tile_hit(const CullParams& k, int tx, int ty) {
+    if (k.thresh < 0.0f) return false;
+    const float xlo = k.mx - (float)(tx * TILE + TILE - 1), xhi = k.mx - (float)(tx * TILE);
+    const float ylo = k.my - (float)(ty * TILE + TILE - 1), yhi = k.my - (float)(ty * TILE);
+    if (xlo <= 0.0f && xhi >= 0.0f && ylo <= 0.0f && yhi >= 0.0f) return true;
+    const float ia = 1.0f / k.a, ic = 1.0f / k.c;
+    float best;
+    {
+        const float dy = fminf(yhi, fmaxf(ylo, -(k.b * xlo) * ic));
+        best = quad_form(k, xlo, dy);
+    }
+    {
+        const float dy = fminf(yhi, fmaxf(ylo, -(k.b * xhi) * ic));
+        best = fminf(best, quad_form(k, xhi, dy));
+    }
+    {
+        const float dx = fminf(xhi, fmaxf(xlo, -(k.b * ylo) * ia));
+        best = fminf(best, quad_form(k, dx, ylo));
+    }
+    {
+        const float dx = fminf(xhi, fmaxf(xlo, -(k.b * yhi) * ia));
+        best = fminf(best, quad_form(k, dx, yhi));
+    }
+    return !(best > k.thresh);   // NaN keeps the tile
+}
+
 __device__ __forceinline__ M3 quat_to_rot(float4 q) {
     const float r = q.x, x = q.y, y = q.z, z = q.w;  // no normalisation (forward.cu:128)
     M3 R;
@@ -177,12 +229,11 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
                   const float* __restrict__ colors_precomp, ViewParams vp, int* __restrict__ radii,
                   SplatRec* __restrict__ rec, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
-                  uint32_t* __restrict__ depth_key) {
+                  uint32_t* __restrict__ depth_key, int cull, uint32_t* __restrict__ ref_partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
     int out_radius = 0;
-    uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu;
-    do {
+    uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu, bbox_tiles = 0;
+    if (i < P) do {
         const V3 p = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
         const V3 pv = xform3(vp.view, p);
         if (pv.z <= 0.2f) break;
@@ -230,13 +281,56 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         rec[i] = r;
         clamped[i] = cl;
         out_radius = (int)rad;
-        out_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+        bbox_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+        if (cull) {
+            const CullParams ck = make_cull(px, py, ca, cb, cc, opacities[i]);
+            for (int ty = y0; ty < y1; ty++)
+                for (int tx = x0; tx < x1; tx++) out_tiles += tile_hit(ck, tx, ty) ? 1u : 0u;
+        } else {
+            out_tiles = bbox_tiles;
+        }
         out_key = __float_as_uint(pv.z);
     } while (false);
-    if (radii) radii[i] = out_radius;
-    tiles_touched[i] = out_tiles;
-    depth_key[i] = out_key;
-    if (out_tiles == 0) clamped[i] = 0;
+    if (i < P) {
+        if (radii) radii[i] = out_radius;
+        tiles_touched[i] = out_tiles;
+        depth_key[i] = out_key;
+        if (out_radius == 0) clamped[i] = 0;
+    }
+    // the reference's num_rendered = sum of bounding-rectangle tile counts (rasterizer_impl.cu:279-283)
+    // Same-address atomics serialise at ~12 ns each on MI355X, so every workgroup writes ONE partial sum and
+    // the scan's spine kernel adds the partials up.
+    __shared__ uint32_t wsum[4];
+    uint32_t v = bbox_tiles;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) ref_partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Emit (tile, id) instances in depth order (same tile test as the count above).
+__global__ void __launch_bounds__(256)
+emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                      const uint32_t* __restrict__ tiles_touched, const SplatRec* __restrict__ rec, int gx, int gy,
+                      int cull, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_id) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t g = order[i];
+    if (tiles_touched[g] == 0) return;
+    uint32_t off = offsets[i];
+    const float4 q0 = rec[g].q0, q1 = rec[g].q1;
+    const int radius = __float_as_int(rec[g].q2.z);  // integer bits stored by preprocess_kernel
+    int x0, y0, x1, y1;
+    tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
+    const CullParams ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            if (cull && !tile_hit(ck, x, y)) continue;
+            inst_tile[off] = (uint32_t)(y * gx + x);
+            inst_id[off] = g;
+            off++;
+        }
 }
 
 // ---- backward: K8 (cov2D) + K9 (mean / SH / cov3D) fused, one thread per Gaussian ---------------------
@@ -463,10 +557,17 @@ void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t
 
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
-                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, hipStream_t s) {
+                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull,
+                       hipStream_t s) {
     hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales, rotations,
                        opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped, g.tiles_touched,
-                       g.depth_key);
+                       g.depth_key, cull, g.ref_partial);
+}
+
+void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
+                           uint32_t* inst_tile, uint32_t* inst_id, hipStream_t s) {
+    hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.offsets,
+                       g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id);
 }
 
 void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D, const int* radii, const float* shs,

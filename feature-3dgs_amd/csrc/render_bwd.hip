@@ -4,26 +4,34 @@
 // with quirks Q1 (no gating by the 0.99 clamp), Q2 (feature loss never reaches alpha), Q3 (the
 // reference's dead collected_semantic_feature buffer is not reproduced), Q5 and Q8.
 //
-// The reference issues 10 + C global fp32 atomics per (pixel, Gaussian) pair, all lanes of a block on
-// the same address.  Here every wave first sums its PPL pixels per lane in registers, reduces across
-// the 64 lanes with DPP (row butterflies + row_bcast), lands the 10 geometric sums in lanes 0..9 and
-// the C feature sums in lanes 0..C-1 of one VGPR each, and issues ONE coalesced vector atomic per
-// group: one 48-byte gradient record per Gaussian plus one contiguous C-float run of
-// dL_dsemantic_feature.  Atomic count drops from (10+C) * 256 to 2 * (4/PPL) instructions per
-// (tile, Gaussian).
+// The reference keeps lane = pixel and issues 10 + C global fp32 atomics per (pixel, Gaussian) pair,
+// every lane of a block on the same address.  This kernel TRANSPOSES the problem for wave64:
+//
+//   * one wave owns NPIX pixels of a tile and walks the tile's list back to front in chunks of 64
+//     instances; lane l HOLDS instance hi-1-l of the chunk in registers (no LDS staging at all);
+//   * the wave loops over its pixels; everything that belongs to the pixel (coordinates, upstream
+//     gradients, running transmittance, running "colour behind") is wave-uniform and comes from LDS as a
+//     broadcast; the 10 + C per-Gaussian gradient sums are LANE-PRIVATE accumulators, so the pixel
+//     reduction that dominates the reference costs nothing;
+//   * the sequential dependence along the list turns into two DPP prefix scans per pixel and chunk
+//     (gfx9 row_shr / row_bcast forms): a product scan for the transmittance, T_g = T_in * prod 1/(1-a),
+//     and a sum scan for S_g = sum_{j behind g} w_j (c_j . dL/dpix + depth_j dL/ddepth), with
+//       dL/dalpha_g = T_g q_g - (S_g + T_final bg.dL/dpix) / (1 - alpha_g)
+//     which is the reference's (c - accum_rec) T recurrence summed over channels first;
+//   * pixels whose list ended before the chunk (early termination) are skipped through a scalar bit
+//     mask, so the pixel loop visits exactly sum_px ceil(n_contrib/64) bodies;
+//   * per chunk the accumulators are transposed through LDS and flushed with coalesced vector atomics:
+//     one contiguous C-float run of dL_dsemantic_feature and one 48-byte gradient record per Gaussian.
+//
+// Numerics: T is rebuilt with reciprocals instead of the reference's chain of divisions and the colour
+// recurrence is evaluated in closed form; both are algebraically identical and agree to fp32 round-off
+// (the gradient tolerance of the path is 1e-3 relative).
 
 #include "render_common.h"
 
 namespace f3dgs {
 
 namespace {
-
-struct BwdChunk {
-    float4 geo[64];  // mean_x, mean_y, conic_a, conic_b
-    float2 co[64];   // conic_c, opacity
-    float4 cd[64];   // r, g, b, depth
-    uint32_t id[64];
-};
 
 struct BwdArgs {
     const uint2* ranges;
@@ -40,153 +48,284 @@ struct BwdArgs {
     int W, H, gx, gy;
     int C, c0, nc;
     int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
+    int ablate;      // development only (F3DGS_BWD_ABLATE): bit0 = skip the flush, bit1 = skip the pixel bodies
 };
 
-template <int CH, int PPL>
-__global__ void __launch_bounds__(256 / PPL) render_backward_kernel(BwdArgs a) {
-    constexpr int NW = 4 / PPL;
-    __shared__ BwdChunk chunks[NW];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    BwdChunk& ck = chunks[NW > 1 ? wave : 0];
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_or(float v, float identity) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_incl_prod(float v) {
+    v *= dpp_or<0x111>(v, 1.0f);        // row_shr:1
+    v *= dpp_or<0x112>(v, 1.0f);        // row_shr:2
+    v *= dpp_or<0x114>(v, 1.0f);        // row_shr:4
+    v *= dpp_or<0x118>(v, 1.0f);        // row_shr:8
+    v *= dpp_or<0x142, 0xA>(v, 1.0f);   // row_bcast:15 -> rows 1,3
+    v *= dpp_or<0x143, 0xC>(v, 1.0f);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v) {
+    v += dpp_or<0x111>(v, 0.0f);
+    v += dpp_or<0x112>(v, 0.0f);
+    v += dpp_or<0x114>(v, 0.0f);
+    v += dpp_or<0x118>(v, 0.0f);
+    v += dpp_or<0x142, 0xA>(v, 0.0f);
+    v += dpp_or<0x143, 0xC>(v, 0.0f);
+    return v;
+}
+__device__ __forceinline__ float lane63(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = tile % a.gx, ty = tile / a.gx;
-    const uint2 rg = a.ranges[tile];
-    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
-    const size_t HW = (size_t)a.W * a.H;
+// LDS image of one wave: upstream feature gradients [CH/4][NPIX] float4 and a small flush tile.
+constexpr int FLUSH_GROUP = 16;               // accumulators transposed per flush round
+constexpr int FLUSH_STRIDE = FLUSH_GROUP + 1; // odd: conflict-free lane-major writes and column reads
+template <int CH, int NPIX>
+struct BwdLds {
+    float4 gf[(CH > 0 ? CH / 4 : 1)][NPIX];
+    float flush[64 * FLUSH_STRIDE];
+    uint32_t ids[64];
+    uint32_t touched[64];
+};
 
-    const int lx = lane & 7, ly = lane >> 3;
-    float pxf[PPL], pyf[PPL], T[PPL], Tfin[PPL], gpix[PPL][3], gdep[PPL], bgdot[PPL];
-    float gfeat[PPL][CH > 0 ? CH : 1];
-    float behind[PPL][3], behind_d[PPL], prev_alpha[PPL], prev_col[PPL][3], prev_d[PPL];
-    uint32_t last[PPL];
-    uint32_t max_last = 0;
-#pragma unroll
-    for (int p = 0; p < PPL; p++) {
-        const int q = wave * PPL + p;
-        const int x = tx * TILE + (q & 1) * 8 + lx, y = ty * TILE + (q >> 1) * 8 + ly;
-        const bool inside = x < a.W && y < a.H;
-        const size_t pid = (size_t)y * a.W + x;
-        pxf[p] = (float)x; pyf[p] = (float)y;
-        Tfin[p] = inside ? a.final_T[pid] : 0.f;
-        T[p] = Tfin[p];
-        last[p] = inside ? a.n_contrib[pid] : 0u;
-        max_last = max(max_last, last[p]);
-#pragma unroll
-        for (int c = 0; c < 3; c++) gpix[p][c] = inside ? a.dL_dpix[c * HW + pid] : 0.f;
-        gdep[p] = inside ? a.dL_ddepth[pid] : 0.f;
-        bgdot[p] = a.bg[0] * gpix[p][0] + a.bg[1] * gpix[p][1] + a.bg[2] * gpix[p][2];
-#pragma unroll
-        for (int c = 0; c < (CH > 0 ? CH : 1); c++)
-            gfeat[p][c] = (CH > 0 && inside && c < a.nc) ? a.dL_dfeat[(size_t)(a.c0 + c) * HW + pid] : 0.f;
-        behind_d[p] = 0.f; prev_alpha[p] = 0.f; prev_d[p] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; c++) { behind[p][c] = 0.f; prev_col[p][c] = 0.f; }
-    }
-    max_last = wave_max_u32(max_last);
-    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+// Wave-uniform read of lane `b` (b in an SGPR) of a VGPR.
+__device__ __forceinline__ float lane_bcast(float v, int b) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), b));
+}
 
-    // walk list positions max_last-1 .. 0, 64 at a time; chunk slot j holds position hi-1-j
-    for (int hi = (int)max_last; hi > 0; hi -= 64) {
-        const int cnt = min(64, hi);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < cnt) {
-            const uint32_t g = a.point_list[r_lo + (uint32_t)(hi - 1 - lane)];
-            const SplatRec* rp = a.rec + g;
-            const float4 q0 = rp->q0, q1 = rp->q1, q2 = rp->q2;
-            ck.geo[lane] = q0;
-            ck.co[lane] = make_float2(q1.x, q1.y);
-            ck.cd[lane] = make_float4(q1.z, q1.w, q2.x, q2.y);
-            ck.id[lane] = g;
-        }
-        __builtin_amdgcn_wave_barrier();
+struct PixelIn {   // wave-uniform per-pixel inputs of one body
+    float x, y, gr, gg, gb, gd, T, S;
+    uint32_t last;
+};
+struct SplatLane { // one chunk entry per lane
+    float mx, my, ca, cb, cc, op, cr, cg, cbl, dep;
+    uint32_t pos;
+    bool have;
+};
 
-        for (int j = 0; j < cnt; j++) {
-            const uint32_t pos = (uint32_t)(hi - 1 - j);
-            const float4 g0 = ck.geo[j];
-            const float2 g1 = ck.co[j];
-            const float4 cd = ck.cd[j];
-            float s[10];
+// One (pixel, 64-instance chunk) body: returns the pixel's new running (T, S) and adds this pixel's
+// contribution to the lane-private accumulators.
+template <int CH, int NPIX>
+__device__ __forceinline__ void pixel_body(const PixelIn& pi, const SplatLane& sl, const BwdLds<CH, NPIX>& L, int p,
+                                           float ddelx_dx, float ddely_dy, float* acc, float* fac, bool& touched,
+                                           float& T_out, float& S_out) {
+    const float dx = sl.mx - pi.x, dy = sl.my - pi.y;
+    const float power = splat_power(dx, dy, sl.ca, sl.cb, sl.cc);
+    const float G = __expf(power);
+    const float alpha = fminf(ALPHA_MAX, sl.op * G);
+    const bool ok = sl.have && sl.pos < pi.last && !(power > 0.0f) && !(alpha < ALPHA_MIN);
+    touched = touched || ok;
+    const float al = ok ? alpha : 0.f;
+    const float f = __builtin_amdgcn_rcpf(1.f - al);   // 1/(1-alpha); exactly 1 for skipped lanes
+    const float P = wave_incl_prod(f);
+    const float Tb = pi.T * P;                          // transmittance in front of this splat
+    const float w = al * Tb;
+    const float q = fmaf(sl.cr, pi.gr, fmaf(sl.cg, pi.gg, fmaf(sl.cbl, pi.gb, sl.dep * pi.gd)));
+    const float D = w * q;
+    const float Sinc = wave_incl_sum(D);
+    const float Sbehind = pi.S + (Sinc - D);
+    float dL_dalpha = fmaf(Tb, q, -(Sbehind * f));
+    dL_dalpha = ok ? dL_dalpha : 0.f;
+    T_out = pi.T * lane63(P);
+    S_out = pi.S + lane63(Sinc);
+    const float dL_dG = sl.op * dL_dalpha;
+    const float Gs = ok ? G : 0.f;                      // exp(power) may be inf where power > 0
+    const float gdx = Gs * dx, gdy = Gs * dy;
+    const float dG_ddelx = -gdx * sl.ca - gdy * sl.cb;
+    const float dG_ddely = -gdy * sl.cc - gdx * sl.cb;
+    acc[0] = fmaf(dL_dG * dG_ddelx, ddelx_dx, acc[0]);
+    acc[1] = fmaf(dL_dG * dG_ddely, ddely_dy, acc[1]);
+    const float hg = -0.5f * dL_dG;
+    acc[2] = fmaf(gdx * hg, dx, acc[2]);
+    acc[3] = fmaf(gdx * hg, dy, acc[3]);
+    acc[4] = fmaf(gdy * hg, dy, acc[4]);
+    acc[5] = fmaf(Gs, dL_dalpha, acc[5]);
+    acc[6] = fmaf(w, pi.gr, acc[6]);
+    acc[7] = fmaf(w, pi.gg, acc[7]);
+    acc[8] = fmaf(w, pi.gb, acc[8]);
+    acc[9] = fmaf(w, pi.gd, acc[9]);
+    if constexpr (CH > 0) {
 #pragma unroll
-            for (int k = 0; k < 10; k++) s[k] = 0.f;
-            float sfe[CH > 0 ? CH : 1];
-#pragma unroll
-            for (int c = 0; c < (CH > 0 ? CH : 1); c++) sfe[c] = 0.f;
-            bool any_blend = false;
-#pragma unroll
-            for (int p = 0; p < PPL; p++) {
-                const float dx = g0.x - pxf[p], dy = g0.y - pyf[p];
-                const float power = splat_power(dx, dy, g0.z, g0.w, g1.x);
-                const float G = __expf(power);
-                const float alpha = fminf(ALPHA_MAX, g1.y * G);
-                const bool ok = pos < last[p] && !(power > 0.0f) && !(alpha < ALPHA_MIN);
-                if (ok) {
-                    T[p] = T[p] / (1.f - alpha);
-                    const float w = alpha * T[p];
-                    float dL_dalpha = 0.f;
-                    const float cc[3] = {cd.x, cd.y, cd.z};
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        behind[p][c] = prev_alpha[p] * prev_col[p][c] + (1.f - prev_alpha[p]) * behind[p][c];
-                        prev_col[p][c] = cc[c];
-                        dL_dalpha += (cc[c] - behind[p][c]) * gpix[p][c];
-                        s[6 + c] += w * gpix[p][c];
-                    }
-                    behind_d[p] = prev_alpha[p] * prev_d[p] + (1.f - prev_alpha[p]) * behind_d[p];
-                    prev_d[p] = cd.w;
-                    dL_dalpha += (cd.w - behind_d[p]) * gdep[p];
-                    if constexpr (CH > 0) {
-#pragma unroll
-                        for (int c = 0; c < CH; c++) sfe[c] = fmaf(w, gfeat[p][c], sfe[c]);
-                    }
-                    dL_dalpha *= T[p];
-                    prev_alpha[p] = alpha;
-                    dL_dalpha += (-Tfin[p] / (1.f - alpha)) * bgdot[p];
-                    const float dL_dG = g1.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
-                    const float dG_ddely = -gdy * g1.x - gdx * g0.w;
-                    s[0] += dL_dG * dG_ddelx * ddelx_dx;
-                    s[1] += dL_dG * dG_ddely * ddely_dy;
-                    s[2] += -0.5f * gdx * dx * dL_dG;
-                    s[3] += -0.5f * gdx * dy * dL_dG;
-                    s[4] += -0.5f * gdy * dy * dL_dG;
-                    s[5] += G * dL_dalpha;
-                    s[9] += w * gdep[p];
-                    any_blend = true;
-                }
-            }
-            if (__any(any_blend)) {
-                const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)ck.id[j]);
-                if (a.write_base) {
-                    float out = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 10; k++) {
-                        const float tot = wave_sum_lane63(s[k]);
-                        const float u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 63));
-                        out = lane == k ? u : out;
-                    }
-                    if (lane < 10) unsafeAtomicAdd(a.grec + (size_t)g * GREC + lane, out);
-                }
-                if constexpr (CH > 0) {
-                    float outf = 0.f;
-#pragma unroll
-                    for (int c = 0; c < CH; c++) {
-                        const float tot = wave_sum_lane63(sfe[c]);
-                        const float u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 63));
-                        outf = lane == c ? u : outf;
-                    }
-                    if (lane < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)g * a.C + a.c0 + lane, outf);
-                }
-            }
+        for (int v = 0; v < CH / 4; v++) {
+            const float4 gf = L.gf[v][p];
+            fac[4 * v + 0] = fmaf(w, gf.x, fac[4 * v + 0]);
+            fac[4 * v + 1] = fmaf(w, gf.y, fac[4 * v + 1]);
+            fac[4 * v + 2] = fmaf(w, gf.z, fac[4 * v + 2]);
+            fac[4 * v + 3] = fmaf(w, gf.w, fac[4 * v + 3]);
         }
     }
 }
 
-template <int CH, int PPL>
+template <int CH, int NPIX>
+__global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
+    constexpr int CHV = CH / 4;
+    constexpr int PARTS = 256 / NPIX;          // waves (workgroups) per tile
+    constexpr int ROWS = NPIX / 16;            // pixel rows owned by this wave (NPIX = 256/128/64)
+    constexpr int NV = NPIX / 64;              // pixel-state registers per lane
+    using Lds = BwdLds<CH, NPIX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds& L = *reinterpret_cast<Lds*>(smem);
+    const int lane = threadIdx.x;
+
+    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t tile = wg / PARTS;
+    const int part = wg % PARTS;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const uint2 rg = a.ranges[tile];
+    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
+    const size_t HW = (size_t)a.W * a.H;
+    // pixel p of this wave: row (p / 16) + part*ROWS, column p % 16  (NPIX=64: quadrant split instead)
+    const int px0 = tx * TILE + (NPIX == 64 ? (part & 1) * 8 : 0);
+    const int py0 = ty * TILE + (NPIX == 64 ? (part >> 1) * 8 : part * ROWS);
+    constexpr int PW = NPIX == 64 ? 8 : 16;    // pixels per row of this wave's block
+
+    // ---- per-pixel state lives in registers, lane = pixel; bodies fetch it with v_readlane -------------
+    float v_gr[NV], v_gg[NV], v_gb[NV], v_gd[NV], v_T[NV], v_S[NV];
+    uint32_t v_last[NV];
+    uint32_t max_last = 0;
+#pragma unroll
+    for (int it = 0; it < NV; it++) {
+        const int p = it * 64 + lane;
+        const int x = px0 + p % PW, y = py0 + p / PW;
+        const bool inside = x < a.W && y < a.H;
+        const size_t pid = (size_t)y * a.W + x;
+        v_gr[it] = v_gg[it] = v_gb[it] = v_gd[it] = 0.f;
+        float Tf = 0.f;
+        v_last[it] = 0;
+        if (inside) {
+            v_gr[it] = a.dL_dpix[pid]; v_gg[it] = a.dL_dpix[HW + pid]; v_gb[it] = a.dL_dpix[2 * HW + pid];
+            v_gd[it] = a.dL_ddepth[pid];
+            Tf = a.final_T[pid];
+            v_last[it] = a.n_contrib[pid];
+        }
+        v_T[it] = Tf;
+        v_S[it] = Tf * (a.bg[0] * v_gr[it] + a.bg[1] * v_gg[it] + a.bg[2] * v_gb[it]);
+        max_last = max(max_last, v_last[it]);
+        if constexpr (CH > 0) {
+#pragma unroll
+            for (int v = 0; v < CHV; v++) {
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inside) {
+                    const size_t cb = (size_t)(a.c0 + 4 * v);
+                    if (4 * v + 0 < a.nc) f.x = a.dL_dfeat[(cb + 0) * HW + pid];
+                    if (4 * v + 1 < a.nc) f.y = a.dL_dfeat[(cb + 1) * HW + pid];
+                    if (4 * v + 2 < a.nc) f.z = a.dL_dfeat[(cb + 2) * HW + pid];
+                    if (4 * v + 3 < a.nc) f.w = a.dL_dfeat[(cb + 3) * HW + pid];
+                }
+                L.gf[v][p] = f;
+            }
+        }
+    }
+    max_last = wave_max_u32(max_last);
+    __builtin_amdgcn_wave_barrier();
+    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+
+    // ---- chunks of 64 list positions, back to front: chunk covers [k0, k0 + 64) --------------------
+    for (int k0 = (int)((max_last + 63) / 64) * 64 - 64; k0 >= 0; k0 -= 64) {
+        // lane l holds list position k0 + 63 - l (lane 0 = farthest back)
+        SplatLane sl;
+        sl.pos = (uint32_t)(k0 + 63 - lane);
+        sl.have = sl.pos < max_last;
+        sl.mx = sl.my = sl.ca = sl.cb = sl.cc = sl.op = sl.cr = sl.cg = sl.cbl = sl.dep = 0.f;
+        uint32_t gid = 0;
+        if (sl.have) {
+            gid = a.point_list[r_lo + sl.pos];
+            const SplatRec* rp = a.rec + gid;
+            const float4 q0 = rp->q0, q1 = rp->q1, q2 = rp->q2;
+            sl.mx = q0.x; sl.my = q0.y; sl.ca = q0.z; sl.cb = q0.w; sl.cc = q1.x; sl.op = q1.y;
+            sl.cr = q1.z; sl.cg = q1.w; sl.cbl = q2.x; sl.dep = q2.y;
+        }
+        float acc[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) acc[k] = 0.f;
+        float fac[CH > 0 ? CH : 1];
+#pragma unroll
+        for (int c = 0; c < (CH > 0 ? CH : 1); c++) fac[c] = 0.f;
+        bool touched = false;
+
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            // pixels still alive at this depth (lane = pixel for the ballot); two bodies per trip for ILP
+            unsigned long long live = __ballot(v_last[it] > (uint32_t)k0);
+            if (a.ablate & 2) { touched = sl.have; live = 0; }
+            while (live) {
+                const int b0 = __builtin_ctzll(live);
+                live &= live - 1;
+                const bool two = live != 0;
+                const int b1 = two ? __builtin_ctzll(live) : b0;
+                live &= live - 1;   // (0 & anything) stays 0
+                PixelIn p0, p1;
+                const int q0i = it * 64 + b0, q1i = it * 64 + b1;
+                p0.x = (float)(px0 + q0i % PW); p0.y = (float)(py0 + q0i / PW);
+                p1.x = (float)(px0 + q1i % PW); p1.y = (float)(py0 + q1i / PW);
+                p0.gr = lane_bcast(v_gr[it], b0); p1.gr = lane_bcast(v_gr[it], b1);
+                p0.gg = lane_bcast(v_gg[it], b0); p1.gg = lane_bcast(v_gg[it], b1);
+                p0.gb = lane_bcast(v_gb[it], b0); p1.gb = lane_bcast(v_gb[it], b1);
+                p0.gd = lane_bcast(v_gd[it], b0); p1.gd = lane_bcast(v_gd[it], b1);
+                p0.T = lane_bcast(v_T[it], b0); p1.T = lane_bcast(v_T[it], b1);
+                p0.S = lane_bcast(v_S[it], b0); p1.S = lane_bcast(v_S[it], b1);
+                p0.last = (uint32_t)__builtin_amdgcn_readlane((int)v_last[it], b0);
+                p1.last = two ? (uint32_t)__builtin_amdgcn_readlane((int)v_last[it], b1) : 0u;  // second body inert
+                float T0, S0, T1, S1;
+                pixel_body<CH, NPIX>(p0, sl, L, q0i, ddelx_dx, ddely_dy, acc, fac, touched, T0, S0);
+                pixel_body<CH, NPIX>(p1, sl, L, q1i, ddelx_dx, ddely_dy, acc, fac, touched, T1, S1);
+                v_T[it] = lane == b0 ? T0 : v_T[it];
+                v_S[it] = lane == b0 ? S0 : v_S[it];
+                if (two) {
+                    v_T[it] = lane == b1 ? T1 : v_T[it];
+                    v_S[it] = lane == b1 ? S1 : v_S[it];
+                }
+            }
+        }
+
+        // ---- flush this chunk: transpose through LDS in groups of 16 values, coalesced atomics -----------
+        if (!__any(touched) || (a.ablate & 1)) continue;
+        L.ids[lane] = gid;
+        L.touched[lane] = touched ? 1u : 0u;
+        constexpr int NG = (CH + 10 + FLUSH_GROUP - 1) / FLUSH_GROUP;
+        const int fsub = lane >> 4, fk = lane & 15;   // 4 instances per atomic instruction, 16 values each
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < FLUSH_GROUP; k++) {
+                const int idx = g * FLUSH_GROUP + k;   // compile-time: feature channel or geometric slot
+                float v = 0.f;
+                if (idx < CH) v = fac[idx < CH ? idx : 0];
+                else if (idx < CH + 10) v = acc[idx - CH < 10 ? (idx - CH >= 0 ? idx - CH : 0) : 0];
+                L.flush[lane * FLUSH_STRIDE + k] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int idx = g * FLUSH_GROUP + fk;       // this lane's value index within the instance
+#pragma unroll 4
+            for (int i0 = 0; i0 < 64; i0 += 4) {
+                const int inst = i0 + fsub;
+                if (!L.touched[inst]) continue;
+                const uint32_t gg = L.ids[inst];
+                const float v = L.flush[inst * FLUSH_STRIDE + fk];
+                if (idx < CH) {
+                    if (idx < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + idx, v);
+                } else if (idx < CH + 10) {
+                    if (a.write_base) unsafeAtomicAdd(a.grec + (size_t)gg * GREC + (idx - CH), v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int CH, int NPIX>
 void launch_one(const BwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((render_backward_kernel<CH, PPL>), dim3(a.gx * a.gy), dim3(256 / PPL), 0, s, a);
+    const size_t lds = sizeof(BwdLds<CH, NPIX>);
+    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX>), dim3(a.gx * a.gy * (256 / NPIX)), dim3(64), lds, s, a);
+}
+
+template <int CH>
+void launch_npix(const BwdArgs& a, int npix, hipStream_t s) {
+    if (npix == 256) launch_one<CH, 256>(a, s);
+    else if (npix == 64) launch_one<CH, 64>(a, s);
+    else launch_one<CH, 128>(a, s);
 }
 
 int env_int(const char* name, int dflt) {
@@ -206,21 +345,20 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     a.final_T = final_T; a.n_contrib = n_contrib; a.dL_dpix = dL_dpix; a.dL_dfeat = dL_dfeat;
     a.dL_ddepth = dL_ddepth; a.grec = grec; a.dL_dfeature = dL_dfeature;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
-    const int ppl = env_int("F3DGS_BWD_PPL", 0);
+    const int npix = env_int("F3DGS_BWD_NPIX", 64);
+    a.ablate = env_int("F3DGS_BWD_ABLATE", 0);
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
-        if (ppl == 1) launch_one<0, 1>(a, s); else if (ppl == 2) launch_one<0, 2>(a, s); else launch_one<0, 4>(a, s);
+        launch_npix<0>(a, npix, s);
         return;
     }
-    for (int c0 = 0; c0 < C; c0 += 32) {
-        a.c0 = c0; a.nc = min(32, C - c0); a.write_base = (c0 == 0);
-        if (a.nc <= 4) {
-            if (ppl == 1) launch_one<4, 1>(a, s); else if (ppl == 2) launch_one<4, 2>(a, s); else launch_one<4, 4>(a, s);
-        } else if (a.nc <= 16) {
-            if (ppl == 1) launch_one<16, 1>(a, s); else if (ppl == 4) launch_one<16, 4>(a, s); else launch_one<16, 2>(a, s);
-        } else {
-            if (ppl == 1) launch_one<32, 1>(a, s); else if (ppl == 4) launch_one<32, 4>(a, s); else launch_one<32, 2>(a, s);
-        }
+    // channel windows of up to 64; the geometric sums ride along with the first window only
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        a.c0 = c0; a.nc = min(64, C - c0); a.write_base = (c0 == 0);
+        if (a.nc <= 4) launch_npix<4>(a, npix, s);
+        else if (a.nc <= 16) launch_npix<16>(a, npix, s);
+        else if (a.nc <= 32) launch_npix<32>(a, npix, s);
+        else launch_npix<64>(a, npix == 256 ? 128 : npix, s);
     }
 }
 

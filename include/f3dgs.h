@@ -87,9 +87,13 @@ int f3dgs_mark_visible(
  *
  * The three opaque state buffers are sized through the resize hooks and must
  * be handed back unchanged to f3dgs_backward.  Their layout is private to
- * this library.  *num_rendered receives the number of (tile, Gaussian)
- * instances (the reference's return value); reading it costs one 4-byte
- * device-to-host copy + stream sync, exactly like rasterizer_impl.cu:283.
+ * this library.  *num_rendered receives the reference's return value: the
+ * number of (tile, Gaussian) instances of the 3-sigma bounding rectangles
+ * (rasterizer_impl.cu:279-283).  The private instance lists may be shorter:
+ * unless the environment variable F3DGS_TILE_CULL=0 is set, instances whose
+ * 1/255-alpha ellipse misses the tile are never emitted (they could not blend
+ * at any pixel, so outputs are unchanged).  Reading the counts costs one
+ * 8-byte device-to-host copy + stream sync, like rasterizer_impl.cu:283.
  */
 int f3dgs_forward(
     f3dgs_resize_fn geometry_resize, void* geometry_ctx,
@@ -184,10 +188,11 @@ int f3dgs_backward(
  * the private state written by f3dgs_forward so that every stage can be
  * compared with the oracle in isolation.  Each copies `count` elements
  * starting at element 0 into a HOST buffer and synchronises the stream.
- *   what: "means2D"(float2 per Gaussian) "depths" "conic_opacity"(float4)
- *         "rgb"(float3) "clamped"(3 x u8) "tiles_touched"(u32)
- *         "point_list"(u32 x R)  "ranges"(uint2 per tile)
- *         "final_T"(float per pixel) "n_contrib"(u32 per pixel)
+ *   what: "rec" (12 floats per Gaussian: mean_x, mean_y, conic a,b,c, opacity, r,g,b, depth, radius bits, pad;
+ *         defined only where radii > 0)  "clamped"(u8 bitmask)  "tiles_touched"(u32)  "depth_key"(u32)
+ *         "order"(u32 x P, depth order)  "offsets"(u32 x P)  "counters"(16 x u32: [0] = entries of point_list,
+ *         [1] = reference-style num_rendered)  "point_list"(u32 x R)  "tile_sorted"(u32 x R)
+ *         "ranges"(uint2 per tile)  "final_T"(float per pixel)  "n_contrib"(u32 per pixel)
  */
 int f3dgs_debug_read(
     const char* what,
@@ -198,11 +203,13 @@ int f3dgs_debug_read(
     void* host_dst, size_t dst_bytes,
     void* stream);
 
-/* Per-stage device time of the most recent forward/backward call on this
- * host thread when the environment variable F3DGS_PROFILE=1 is set (HIP
- * events recorded on the call's stream; forces a sync).  Returns the number
- * of stages written; names[i] are static strings. */
-int f3dgs_last_stage_times(const char** names, float* ms, int max_stages);
+/* Per-stage device-time accounting, active when the environment variable F3DGS_PROFILE=1 is set
+ * at first use.  HIP events are recorded on the call's stream around every stage (no
+ * synchronisation inside forward/backward); f3dgs_profile_read waits for the recorded events and
+ * returns, per stage name, the accumulated milliseconds and the number of spans since the last
+ * f3dgs_profile_reset.  Returns the number of stages written; names[i] are static strings. */
+int f3dgs_profile_read(const char** names, double* total_ms, long* calls, int max_stages);
+void f3dgs_profile_reset(void);
 
 #ifdef __cplusplus
 }

@@ -715,4 +715,55 @@ long f3dgs_oracle_read(void* h, const char* what, void* dst, long count) {
     return -1;
 }
 
+
+// Work statistics of the last forward (development aid for sizing the HIP kernels): for every 8x8
+// quadrant of every tile and every list entry the quadrant has to visit (position < the quadrant's
+// deepest n_contrib), count visited entries, entries where at least one pixel blends, and blending pixels.
+void f3dgs_oracle_work_stats(void* h, double* out /* [8] */) {
+    State& s = *static_cast<State*>(h);
+    double q_visit = 0, q_active = 0, px_blend = 0, t_visit = 0, t_active = 0, px_eval = 0, h_visit = 0, h_active = 0;
+    for (int ty = 0; ty < s.gy; ty++)
+        for (int tx = 0; tx < s.gx; tx++) {
+            const uint32_t lo = s.ranges[2 * ((size_t)ty * s.gx + tx)];
+            uint32_t tmax = 0, qmax[4] = {0, 0, 0, 0};
+            for (int py = ty * TILE; py < std::min(s.H, (ty + 1) * TILE); py++)
+                for (int px = tx * TILE; px < std::min(s.W, (tx + 1) * TILE); px++) {
+                    const uint32_t n = s.n_contrib[(size_t)py * s.W + px];
+                    const int q = ((py - ty * TILE) / 8) * 2 + ((px - tx * TILE) / 8);
+                    qmax[q] = std::max(qmax[q], n);
+                    tmax = std::max(tmax, n);
+                }
+            t_visit += tmax;
+            h_visit += std::max(qmax[0], qmax[1]) + std::max(qmax[2], qmax[3]);
+            for (uint32_t k = 0; k < tmax; k++) {
+                const uint32_t g = s.point_list[lo + k];
+                const float* co = &s.conic_opacity[4 * (size_t)g];
+                int qcnt[4] = {0, 0, 0, 0};
+                for (int py = ty * TILE; py < std::min(s.H, (ty + 1) * TILE); py++)
+                    for (int px = tx * TILE; px < std::min(s.W, (tx + 1) * TILE); px++) {
+                        const uint32_t n = s.n_contrib[(size_t)py * s.W + px];
+                        if (k >= n) continue;
+                        px_eval += 1;
+                        const float dx = s.means2D[2 * (size_t)g] - (float)px, dy = s.means2D[2 * (size_t)g + 1] - (float)py;
+                        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 0.0f) continue;
+                        const float alpha = std::min(0.99f, co[3] * std::exp(power));
+                        if (alpha < 1.0f / 255.0f) continue;
+                        qcnt[((py - ty * TILE) / 8) * 2 + ((px - tx * TILE) / 8)]++;
+                    }
+                int tot = 0;
+                for (int q = 0; q < 4; q++) {
+                    if (k < qmax[q]) { q_visit += 1; if (qcnt[q]) q_active += 1; }
+                    tot += qcnt[q];
+                }
+                px_blend += tot;
+                if (tot) t_active += 1;
+                if (k < std::max(qmax[0], qmax[1]) && (qcnt[0] + qcnt[1])) h_active += 1;
+                if (k < std::max(qmax[2], qmax[3]) && (qcnt[2] + qcnt[3])) h_active += 1;
+            }
+        }
+    out[0] = q_visit; out[1] = q_active; out[2] = px_blend; out[3] = t_visit; out[4] = t_active; out[5] = px_eval;
+    out[6] = h_visit; out[7] = h_active;
+}
+
 }  // extern "C"

@@ -57,7 +57,8 @@ def _read(lib, what, scene, res, dtype, count):
 
 
 @pytest.mark.parametrize("seed,P,W,H,C", [(1, 5000, 256, 256, 3), (2, 20000, 320, 200, 16), (3, 3000, 97, 61, 32)])
-def test_binning_is_bit_exact(seed, P, W, H, C):
+def test_binning_is_bit_exact(seed, P, W, H, C, monkeypatch):
+    monkeypatch.setenv("F3DGS_TILE_CULL", "0")   # reference-identical instance lists
     scene = _scene(P=P, C=C, width=W, height=H, seed=seed, scale_lo=0.005, scale_hi=0.08)
     o, want, _ = run_oracle(scene, backward=False)
     res = _raw_forward(scene)
@@ -203,3 +204,32 @@ def test_rotated_view_and_scale_modifier():
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
         mx, bad = grad_report(k, got_g[k], want_g[k])
         assert bad < 2e-3 and mx < 5e-3, (k, mx, bad)
+
+
+@pytest.mark.parametrize("seed,P,W,H,C", [(31, 30000, 320, 192, 8), (32, 4000, 64, 64, 4)])
+def test_tile_culling_changes_lists_not_results(seed, P, W, H, C, monkeypatch):
+    """Default mode drops instances whose 1/255 ellipse misses the tile: shorter private lists, the
+    reference's num_rendered, and BIT-identical images (same blends in the same order)."""
+    scene = _scene(P=P, C=C, width=W, height=H, seed=seed, scale_lo=0.005, scale_hi=0.15)
+    lib = _lib()
+    monkeypatch.setenv("F3DGS_TILE_CULL", "0")
+    ref = _raw_forward(scene)
+    ref_n = int(_read(lib, "counters", scene, ref, np.uint32, 16)[0])
+    monkeypatch.setenv("F3DGS_TILE_CULL", "1")
+    cul = _raw_forward(scene)
+    cnt = _read(lib, "counters", scene, cul, np.uint32, 16)
+    _, want, _ = run_oracle(scene, backward=False)
+    assert ref[0] == cul[0] == want["num_rendered"] == ref_n == int(cnt[1])
+    assert 0 < int(cnt[0]) < ref_n
+    for i in (1, 2, 3, 4):   # color, feature_map, depth, radii
+        assert torch.equal(ref[i], cul[i])
+    # the culled list is a subsequence of the reference list, tile by tile
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    pl_ref = _read(lib, "point_list", scene, ref, np.uint32, ref_n)
+    rg_ref = _read(lib, "ranges", scene, ref, np.uint32, 2 * tiles).reshape(-1, 2)
+    pl_cul = _read(lib, "point_list", scene, cul, np.uint32, int(cnt[0]))
+    rg_cul = _read(lib, "ranges", scene, cul, np.uint32, 2 * tiles).reshape(-1, 2)
+    for t_ in range(0, tiles, max(1, tiles // 40)):
+        a_, b_ = pl_ref[rg_ref[t_, 0]:rg_ref[t_, 1]], pl_cul[rg_cul[t_, 0]:rg_cul[t_, 1]]
+        it = iter(a_.tolist())
+        assert all(x in it for x in b_.tolist()), f"tile {t_}: culled list is not an ordered subsequence"
