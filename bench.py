@@ -127,6 +127,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import diff_gaussian_rasterization as dgr
+    import dp
     from diff_gaussian_rasterization import _C
     from synth import CONFIGS, make_scene
 
@@ -154,9 +155,7 @@ def main():
         color, feat, _radii, depth = rasterizer(**leaves)
         torch.autograd.backward([color, feat, depth], up)
         if dist is not None:
-            works = [dist.all_reduce(leaves[k].grad, async_op=True) for k in reduce_keys]
-            for w in works:
-                w.wait()
+            dp.all_reduce_gaussian_grads({k: leaves[k].grad for k in reduce_keys})
 
     stats = None
     if rank == 0:

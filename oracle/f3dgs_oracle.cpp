@@ -390,7 +390,7 @@ void stage_blend_grad(State& s, const float* bg, const float* colors, const floa
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // Q8
     for (int ty = 0; ty < s.gy; ty++)
         for (int tx = 0; tx < s.gx; tx++) {
-            const uint32_t lo = s.ranges[2 * ((size_t)ty * s.gx + tx)], hi = s.ranges[2 * ((size_t)ty * s.gx + tx) + 1];
+            const uint32_t lo = s.ranges[2 * ((size_t)ty * s.gx + tx)];
             for (int py = ty * TILE; py < std::min(H, (ty + 1) * TILE); py++)
                 for (int px = tx * TILE; px < std::min(W, (tx + 1) * TILE); px++) {
                     const size_t pid = (size_t)py * W + px;
@@ -764,6 +764,22 @@ void f3dgs_oracle_work_stats(void* h, double* out /* [8] */) {
         }
     out[0] = q_visit; out[1] = q_active; out[2] = px_blend; out[3] = t_visit; out[4] = t_active; out[5] = px_eval;
     out[6] = h_visit; out[7] = h_active;
+}
+
+// Sub-step entry points so that the reference's own Python fall-backs can pin them
+// (tests/golden/reference_fallbacks.npz).
+void f3dgs_oracle_sh_to_rgb(int P, int deg, int M, const float* means3D, const float* campos, const float* shs,
+                            float* rgb_out, uint8_t* clamped_out) {
+    for (int i = 0; i < P; i++) {
+        uint8_t cl[3];
+        V3 c = sh_to_rgb(deg, M, means3D + 3 * (size_t)i, campos, shs + 3 * (size_t)M * i, cl);
+        rgb_out[3 * (size_t)i] = c.x; rgb_out[3 * (size_t)i + 1] = c.y; rgb_out[3 * (size_t)i + 2] = c.z;
+        if (clamped_out) std::memcpy(clamped_out + 3 * (size_t)i, cl, 3);
+    }
+}
+void f3dgs_oracle_cov3d(int P, const float* scales, float mod, const float* rotations, float* cov6_out) {
+    for (int i = 0; i < P; i++)
+        cov3d_from_scale_rot(scales + 3 * (size_t)i, mod, rotations + 4 * (size_t)i, cov6_out + 6 * (size_t)i);
 }
 
 }  // extern "C"

@@ -156,6 +156,29 @@ def mark_visible(means3D, viewmatrix) -> np.ndarray:
     return out.astype(bool)
 
 
+def sh_to_rgb(deg: int, means3D, campos, shs) -> np.ndarray:
+    """SH -> clamped RGB sub-step of the oracle (pinned against the reference's eval_sh fall-back)."""
+    lib = _load()
+    m, c, s = _f32(means3D), _f32(campos), _f32(shs)
+    P = m.reshape(-1, 3).shape[0]
+    M = s.reshape(P, -1, 3).shape[1]
+    out = np.zeros((P, 3), np.float32)
+    lib.f3dgs_oracle_sh_to_rgb.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP, _FP, _U8P]
+    lib.f3dgs_oracle_sh_to_rgb(P, int(deg), M, _p(m), _p(c), _p(s), _p(out), ctypes.cast(None, _U8P))
+    return out
+
+
+def cov3d(scales, scale_modifier: float, rotations) -> np.ndarray:
+    """scale/rotation -> 6 unique covariance entries (pinned against the reference's Python fall-back)."""
+    lib = _load()
+    s, r = _f32(scales), _f32(rotations)
+    P = s.reshape(-1, 3).shape[0]
+    out = np.zeros((P, 6), np.float32)
+    lib.f3dgs_oracle_cov3d.argtypes = [ctypes.c_int, _FP, ctypes.c_float, _FP, _FP]
+    lib.f3dgs_oracle_cov3d(P, _p(s), float(scale_modifier), _p(r), _p(out))
+    return out
+
+
 def scene_kwargs(scene: dict, use_precomp_color=False, use_precomp_cov=False) -> dict:
     """Map a synth.make_scene() dict onto Oracle.forward keyword arguments."""
     kw = dict(bg=scene["bg"], means3D=scene["means3D"], opacities=scene["opacities"],
