@@ -111,31 +111,14 @@ int check_debug(int debug, hipStream_t s, const char* stage) {
     return F3DGS_OK;
 }
 
-void fill_view(ViewParams& vp, const float* view, const float* proj, const float* campos, float tanx, float tany,
-               int W, int H, float mod) {
-    memcpy(vp.view, view, sizeof vp.view);
-    memcpy(vp.proj, proj, sizeof vp.proj);
-    if (campos) memcpy(vp.campos, campos, sizeof vp.campos);
+void fill_view(ViewParams& vp, const float* view, const float* proj, const float* campos, const float* bg, float tanx,
+               float tany, int W, int H, float mod) {
+    vp.view = view; vp.proj = proj; vp.campos = campos; vp.bg = bg;
     vp.tanx = tanx; vp.tany = tany;
     vp.fx = W / (2.0f * tanx); vp.fy = H / (2.0f * tany);
     vp.W = W; vp.H = H;
     vp.gx = (W + TILE - 1) / TILE; vp.gy = (H + TILE - 1) / TILE;
     vp.scale_modifier = mod;
-}
-
-// The camera matrices arrive as device pointers (the reference passes device tensors).  They are tiny;
-// fetch them once per call into kernel-argument space so every kernel reads them from SGPRs.
-struct CamHost {
-    float view[16], proj[16], campos[3], bg[3];
-};
-int fetch_camera(CamHost& c, const float* view, const float* proj, const float* campos, const float* bg,
-                 hipStream_t s) {
-    HIP_TRY(hipMemcpyAsync(c.view, view, sizeof c.view, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c.proj, proj, sizeof c.proj, hipMemcpyDeviceToHost, s));
-    if (campos) HIP_TRY(hipMemcpyAsync(c.campos, campos, sizeof c.campos, hipMemcpyDeviceToHost, s));
-    if (bg) HIP_TRY(hipMemcpyAsync(c.bg, bg, sizeof c.bg, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return F3DGS_OK;
 }
 
 // F3DGS_TILE_CULL=0 keeps the reference's bounding-rectangle instance lists (bit-identical intermediate
@@ -166,10 +149,7 @@ int f3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, con
     if (P == 0) return F3DGS_OK;
     if (!means3D || !viewmatrix || !present) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
     (void)projmatrix;
-    float view[16];
-    HIP_TRY(hipMemcpyAsync(view, viewmatrix, sizeof view, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    launch_mark_visible(P, means3D, view, present, s);
+    launch_mark_visible(P, means3D, viewmatrix, present, s);
     HIP_TRY(hipGetLastError());
     return F3DGS_OK;
 }
@@ -205,11 +185,9 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     if (shs && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
         return fail(F3DGS_ERR_INVALID_ARGUMENT, "SH degree %d needs %d coefficients, M = %d", D, (D + 1) * (D + 1), M);
 
-    CamHost cam = {};
-    int rc = fetch_camera(cam, viewmatrix, projmatrix, cam_pos, background, s);
-    if (rc) return rc;
+    int rc = F3DGS_OK;
     ViewParams vp;
-    fill_view(vp, cam.view, cam.proj, cam.campos, tan_fovx, tan_fovy, width, height, scale_modifier);
+    fill_view(vp, viewmatrix, projmatrix, cam_pos, background, tan_fovx, tan_fovy, width, height, scale_modifier);
     const size_t tiles = (size_t)vp.gx * vp.gy;
 
     size_t geom_bytes = 0, img_bytes = 0, bin_bytes = 0;
@@ -271,7 +249,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     if ((rc = check_debug(debug, s, "ranges"))) return rc;
     tm.mark("ranges");
 
-    launch_render_forward(vp, C, img.ranges, bin.point_list, geom.rec, semantic_feature, cam.bg, img.final_T,
+    launch_render_forward(vp, C, img.ranges, bin.point_list, geom.rec, semantic_feature, img.final_T,
                           img.n_contrib, out_color, out_feature_map, out_depth, s);
     if ((rc = check_debug(debug, s, "render"))) return rc;
     tm.mark("render_fwd");
@@ -310,11 +288,9 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     if (scales && (!dL_dscale || !dL_drot || !rotations)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "scale/rot grads null");
     if (!scratch) return fail(F3DGS_ERR_INVALID_ARGUMENT, "scratch is null");
 
-    CamHost cam = {};
-    int rc = fetch_camera(cam, viewmatrix, projmatrix, campos, background, s);
-    if (rc) return rc;
+    int rc = F3DGS_OK;
     ViewParams vp;
-    fill_view(vp, cam.view, cam.proj, cam.campos, tan_fovx, tan_fovy, width, height, scale_modifier);
+    fill_view(vp, viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, width, height, scale_modifier);
     const size_t HW = (size_t)width * height, tiles = (size_t)vp.gx * vp.gy;
     GeomState geom = GeomState::carve(const_cast<char*>(geom_buffer), P, nullptr);
     // R is the reference-style count; our (possibly culled) list sits at offset 0 of the binning buffer.
@@ -327,7 +303,7 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     if (C > 0) HIP_TRY(hipMemsetAsync(dL_dsemantic_feature, 0, (size_t)P * C * sizeof(float), s));
     tm.mark("zero");
     if (R > 0)
-        launch_render_backward(vp, C, img.ranges, bin.point_list, geom.rec, cam.bg, img.final_T, img.n_contrib,
+        launch_render_backward(vp, C, img.ranges, bin.point_list, geom.rec, img.final_T, img.n_contrib,
                                dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, s);
     if ((rc = check_debug(debug, s, "render backward"))) return rc;
     tm.mark("render_bwd");

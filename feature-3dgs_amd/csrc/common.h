@@ -123,17 +123,20 @@ struct ImageState {
 };
 
 // ---- host-side launchers (one per translation unit) ----------------------------------------------
+// Camera matrices / position / background stay in DEVICE memory (that is where the reference's tensors
+// live); kernels read them through uniform (scalar) loads, so no call ever synchronises to fetch them.
 struct ViewParams {
-    float view[16];
-    float proj[16];
-    float campos[3];
+    const float* view;    // 16 floats, element (r, c) at [4c + r]
+    const float* proj;    // 16 floats
+    const float* campos;  // 3 floats (may be null when colours are precomputed)
+    const float* bg;      // 3 floats
     float tanx, tany, fx, fy;
     int W, H, gx, gy;
     float scale_modifier;
 };
 
 // preprocess.hip (built with -ffp-contract=off)
-void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* view_dev, uint8_t* present, hipStream_t s);
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull,
@@ -162,10 +165,10 @@ void launch_tile_ranges(size_t N, const uint32_t* tile_sorted, uint2* ranges, si
 
 // render_fwd.hip / render_bwd.hip
 void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
-                           const SplatRec* rec, const float* feat, const float* bg, float* final_T,
+                           const SplatRec* rec, const float* feat, float* final_T,
                            uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, hipStream_t s);
 void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
-                            const SplatRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                            const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                             const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
                             float* dL_dfeature, hipStream_t s);
 

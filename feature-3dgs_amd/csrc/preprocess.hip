@@ -549,9 +549,9 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
 
 }  // namespace
 
-void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {
+void launch_mark_visible(int P, const float* means3D, const float* view_dev, uint8_t* present, hipStream_t s) {
     ViewParams vp = {};
-    for (int k = 0; k < 16; k++) vp.view[k] = view[k];
+    vp.view = view_dev;
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, vp, present);
 }
 

@@ -37,7 +37,7 @@ struct BwdArgs {
     const uint2* ranges;
     const uint32_t* point_list;
     const SplatRec* rec;
-    float bg[3];
+    const float* bg;
     const float* final_T;
     const uint32_t* n_contrib;
     const float* dL_dpix;
@@ -51,119 +51,74 @@ struct BwdArgs {
     int ablate;      // development only (F3DGS_BWD_ABLATE): bit0 = skip the flush, bit1 = skip the pixel bodies
 };
 
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ float dpp_or(float v, float identity) {
-    return __int_as_float(
-        __builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
-__device__ __forceinline__ float wave_incl_prod(float v) {
-    v *= dpp_or<0x111>(v, 1.0f);        // row_shr:1
-    v *= dpp_or<0x112>(v, 1.0f);        // row_shr:2
-    v *= dpp_or<0x114>(v, 1.0f);        // row_shr:4
-    v *= dpp_or<0x118>(v, 1.0f);        // row_shr:8
-    v *= dpp_or<0x142, 0xA>(v, 1.0f);   // row_bcast:15 -> rows 1,3
-    v *= dpp_or<0x143, 0xC>(v, 1.0f);   // row_bcast:31 -> rows 2,3
-    return v;
-}
-__device__ __forceinline__ float wave_incl_sum(float v) {
-    v += dpp_or<0x111>(v, 0.0f);
-    v += dpp_or<0x112>(v, 0.0f);
-    v += dpp_or<0x114>(v, 0.0f);
-    v += dpp_or<0x118>(v, 0.0f);
-    v += dpp_or<0x142, 0xA>(v, 0.0f);
-    v += dpp_or<0x143, 0xC>(v, 0.0f);
-    return v;
-}
-__device__ __forceinline__ float lane63(float v) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
+// ---- paired DPP prefix scans --------------------------------------------------------------------------
+// Two independent inclusive scans over the 64 lanes run interleaved so that each DPP instruction's
+// 2-wait-state read-after-write hazard is covered by the partner's instruction plus one s_nop.  The
+// VOP2-DPP forms are fused (v = op(dpp(v), v)); lanes whose DPP source is out of range are disabled
+// (bound_ctrl:0), i.e. keep their value = combine with the identity.  Measured on MI355X: 4.5 cycles per
+// fused step vs 9.0 for the v_mov_b32_dpp + v_mul pair the compiler emits for update_dpp with identity 1.0.
+#define F3DGS_SCAN2(OP)                                                                          \
+    asm volatile("s_nop 1\n\t"                                                                   \
+                 OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                       \
+                 OP " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "s_nop 0\n\t"                                                                   \
+                 OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                       \
+                 OP " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "s_nop 0\n\t"                                                                   \
+                 OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                       \
+                 OP " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "s_nop 0\n\t"                                                                   \
+                 OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                       \
+                 OP " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "s_nop 0\n\t"                                                                   \
+                 OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
+                 OP " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
+                 "s_nop 0\n\t"                                                                   \
+                 OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                    \
+                 OP " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                    \
+                 "s_nop 1"                                                                       \
+                 : "+v"(a), "+v"(b))
+__device__ __forceinline__ void wave_incl_prod2(float& a, float& b) { F3DGS_SCAN2("v_mul_f32_dpp"); }
+__device__ __forceinline__ void wave_incl_sum2(float& a, float& b) { F3DGS_SCAN2("v_add_f32_dpp"); }
+#undef F3DGS_SCAN2
 
-// LDS image of one wave: upstream feature gradients [CH/4][NPIX] float4 and a small flush tile.
+// LDS image of one wave.  Per-pixel data is wave-uniform in the bodies and is fetched with broadcast
+// ds_reads (the LDS pipe is idle; v_readlane costs ~8 VALU cycles apiece on gfx950):
+//   pa[p] = {pixel x, pixel y, T_in, S_in}  (T/S are the running state, rewritten by lane 63 per chunk)
+//   pb[p] = {dL/dR, dL/dG, dL/dB, dL/ddepth}     plast[p] = n_contrib
 constexpr int FLUSH_GROUP = 16;               // accumulators transposed per flush round
 constexpr int FLUSH_STRIDE = FLUSH_GROUP + 1; // odd: conflict-free lane-major writes and column reads
-template <int CH, int NPIX>
+// MF = true: the feature-gradient contraction dF[g][c] += sum_px w[px][g] dO[px][c] runs on the matrix
+// pipe (exact-fp32 v_mfma_f32_32x32x2_f32) concurrently with the VALU work; dO is then kept row-major per
+// pixel with an odd row stride.  MF = false keeps it as float4 [c/4][pixel] for the VALU FMAs.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int CH, int NPIX, bool MF>
 struct BwdLds {
-    float4 gf[(CH > 0 ? CH / 4 : 1)][NPIX];
+    static constexpr int GS = CH + 1;   // row stride (floats) of the MF image
+    float4 pa[NPIX];
+    float4 pb[NPIX];
+    uint32_t plast[NPIX];
+    float4 gf[MF ? 1 : (CH > 0 ? CH / 4 : 1)][MF ? 1 : NPIX];
+    float gfm[MF ? NPIX * GS : 1];
     float flush[64 * FLUSH_STRIDE];
     uint32_t ids[64];
     uint32_t touched[64];
 };
 
-// Wave-uniform read of lane `b` (b in an SGPR) of a VGPR.
-__device__ __forceinline__ float lane_bcast(float v, int b) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), b));
-}
-
-struct PixelIn {   // wave-uniform per-pixel inputs of one body
-    float x, y, gr, gg, gb, gd, T, S;
-    uint32_t last;
-};
 struct SplatLane { // one chunk entry per lane
     float mx, my, ca, cb, cc, op, cr, cg, cbl, dep;
     uint32_t pos;
     bool have;
 };
 
-// One (pixel, 64-instance chunk) body: returns the pixel's new running (T, S) and adds this pixel's
-// contribution to the lane-private accumulators.
-template <int CH, int NPIX>
-__device__ __forceinline__ void pixel_body(const PixelIn& pi, const SplatLane& sl, const BwdLds<CH, NPIX>& L, int p,
-                                           float ddelx_dx, float ddely_dy, float* acc, float* fac, bool& touched,
-                                           float& T_out, float& S_out) {
-    const float dx = sl.mx - pi.x, dy = sl.my - pi.y;
-    const float power = splat_power(dx, dy, sl.ca, sl.cb, sl.cc);
-    const float G = __expf(power);
-    const float alpha = fminf(ALPHA_MAX, sl.op * G);
-    const bool ok = sl.have && sl.pos < pi.last && !(power > 0.0f) && !(alpha < ALPHA_MIN);
-    touched = touched || ok;
-    const float al = ok ? alpha : 0.f;
-    const float f = __builtin_amdgcn_rcpf(1.f - al);   // 1/(1-alpha); exactly 1 for skipped lanes
-    const float P = wave_incl_prod(f);
-    const float Tb = pi.T * P;                          // transmittance in front of this splat
-    const float w = al * Tb;
-    const float q = fmaf(sl.cr, pi.gr, fmaf(sl.cg, pi.gg, fmaf(sl.cbl, pi.gb, sl.dep * pi.gd)));
-    const float D = w * q;
-    const float Sinc = wave_incl_sum(D);
-    const float Sbehind = pi.S + (Sinc - D);
-    float dL_dalpha = fmaf(Tb, q, -(Sbehind * f));
-    dL_dalpha = ok ? dL_dalpha : 0.f;
-    T_out = pi.T * lane63(P);
-    S_out = pi.S + lane63(Sinc);
-    const float dL_dG = sl.op * dL_dalpha;
-    const float Gs = ok ? G : 0.f;                      // exp(power) may be inf where power > 0
-    const float gdx = Gs * dx, gdy = Gs * dy;
-    const float dG_ddelx = -gdx * sl.ca - gdy * sl.cb;
-    const float dG_ddely = -gdy * sl.cc - gdx * sl.cb;
-    acc[0] = fmaf(dL_dG * dG_ddelx, ddelx_dx, acc[0]);
-    acc[1] = fmaf(dL_dG * dG_ddely, ddely_dy, acc[1]);
-    const float hg = -0.5f * dL_dG;
-    acc[2] = fmaf(gdx * hg, dx, acc[2]);
-    acc[3] = fmaf(gdx * hg, dy, acc[3]);
-    acc[4] = fmaf(gdy * hg, dy, acc[4]);
-    acc[5] = fmaf(Gs, dL_dalpha, acc[5]);
-    acc[6] = fmaf(w, pi.gr, acc[6]);
-    acc[7] = fmaf(w, pi.gg, acc[7]);
-    acc[8] = fmaf(w, pi.gb, acc[8]);
-    acc[9] = fmaf(w, pi.gd, acc[9]);
-    if constexpr (CH > 0) {
-#pragma unroll
-        for (int v = 0; v < CH / 4; v++) {
-            const float4 gf = L.gf[v][p];
-            fac[4 * v + 0] = fmaf(w, gf.x, fac[4 * v + 0]);
-            fac[4 * v + 1] = fmaf(w, gf.y, fac[4 * v + 1]);
-            fac[4 * v + 2] = fmaf(w, gf.z, fac[4 * v + 2]);
-            fac[4 * v + 3] = fmaf(w, gf.w, fac[4 * v + 3]);
-        }
-    }
-}
-
-template <int CH, int NPIX>
+template <int CH, int NPIX, bool MF>
 __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
+    constexpr int NB = MF ? CH / 32 : 0;       // 32-channel column blocks on the matrix pipe
     constexpr int CHV = CH / 4;
     constexpr int PARTS = 256 / NPIX;          // waves (workgroups) per tile
     constexpr int ROWS = NPIX / 16;            // pixel rows owned by this wave (NPIX = 256/128/64)
     constexpr int NV = NPIX / 64;              // pixel-state registers per lane
-    using Lds = BwdLds<CH, NPIX>;
+    using Lds = BwdLds<CH, NPIX, MF>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds& L = *reinterpret_cast<Lds*>(smem);
     const int lane = threadIdx.x;
@@ -180,8 +135,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     const int py0 = ty * TILE + (NPIX == 64 ? (part >> 1) * 8 : part * ROWS);
     constexpr int PW = NPIX == 64 ? 8 : 16;    // pixels per row of this wave's block
 
-    // ---- per-pixel state lives in registers, lane = pixel; bodies fetch it with v_readlane -------------
-    float v_gr[NV], v_gg[NV], v_gb[NV], v_gd[NV], v_T[NV], v_S[NV];
+    // ---- stage the per-pixel data into LDS (lane = pixel here) -----------------------------------------
     uint32_t v_last[NV];
     uint32_t max_last = 0;
 #pragma unroll
@@ -190,17 +144,18 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         const int x = px0 + p % PW, y = py0 + p / PW;
         const bool inside = x < a.W && y < a.H;
         const size_t pid = (size_t)y * a.W + x;
-        v_gr[it] = v_gg[it] = v_gb[it] = v_gd[it] = 0.f;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float Tf = 0.f;
         v_last[it] = 0;
         if (inside) {
-            v_gr[it] = a.dL_dpix[pid]; v_gg[it] = a.dL_dpix[HW + pid]; v_gb[it] = a.dL_dpix[2 * HW + pid];
-            v_gd[it] = a.dL_ddepth[pid];
+            g.x = a.dL_dpix[pid]; g.y = a.dL_dpix[HW + pid]; g.z = a.dL_dpix[2 * HW + pid];
+            g.w = a.dL_ddepth[pid];
             Tf = a.final_T[pid];
             v_last[it] = a.n_contrib[pid];
         }
-        v_T[it] = Tf;
-        v_S[it] = Tf * (a.bg[0] * v_gr[it] + a.bg[1] * v_gg[it] + a.bg[2] * v_gb[it]);
+        L.pa[p] = make_float4((float)x, (float)y, Tf, Tf * (a.bg[0] * g.x + a.bg[1] * g.y + a.bg[2] * g.z));
+        L.pb[p] = g;
+        L.plast[p] = v_last[it];
         max_last = max(max_last, v_last[it]);
         if constexpr (CH > 0) {
 #pragma unroll
@@ -213,7 +168,12 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     if (4 * v + 2 < a.nc) f.z = a.dL_dfeat[(cb + 2) * HW + pid];
                     if (4 * v + 3 < a.nc) f.w = a.dL_dfeat[(cb + 3) * HW + pid];
                 }
-                L.gf[v][p] = f;
+                if constexpr (MF) {
+                    L.gfm[p * Lds::GS + 4 * v + 0] = f.x; L.gfm[p * Lds::GS + 4 * v + 1] = f.y;
+                    L.gfm[p * Lds::GS + 4 * v + 2] = f.z; L.gfm[p * Lds::GS + 4 * v + 3] = f.w;
+                } else {
+                    L.gf[v][p] = f;
+                }
             }
         }
     }
@@ -239,14 +199,22 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         float acc[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) acc[k] = 0.f;
-        float fac[CH > 0 ? CH : 1];
+        float fac[(CH > 0 && !MF) ? CH : 1];
 #pragma unroll
-        for (int c = 0; c < (CH > 0 ? CH : 1); c++) fac[c] = 0.f;
+        for (int c = 0; c < ((CH > 0 && !MF) ? CH : 1); c++) fac[c] = 0.f;
+        f32x16 macc[NB > 0 ? NB : 1][2];           // [column block][instances 0-31 | 32-63]
+#pragma unroll
+        for (int nb = 0; nb < (NB > 0 ? NB : 1); nb++)
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) macc[nb][hh][r] = 0.f;
         bool touched = false;
 
 #pragma unroll
         for (int it = 0; it < NV; it++) {
-            // pixels still alive at this depth (lane = pixel for the ballot); two bodies per trip for ILP
+            // pixels still alive at this depth (lane = pixel for the ballot); two bodies per trip: ILP for the
+            // scans, and the K = 2 of the MFMA
             unsigned long long live = __ballot(v_last[it] > (uint32_t)k0);
             if (a.ablate & 2) { touched = sl.have; live = 0; }
             while (live) {
@@ -255,26 +223,89 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 const bool two = live != 0;
                 const int b1 = two ? __builtin_ctzll(live) : b0;
                 live &= live - 1;   // (0 & anything) stays 0
-                PixelIn p0, p1;
-                const int q0i = it * 64 + b0, q1i = it * 64 + b1;
-                p0.x = (float)(px0 + q0i % PW); p0.y = (float)(py0 + q0i / PW);
-                p1.x = (float)(px0 + q1i % PW); p1.y = (float)(py0 + q1i / PW);
-                p0.gr = lane_bcast(v_gr[it], b0); p1.gr = lane_bcast(v_gr[it], b1);
-                p0.gg = lane_bcast(v_gg[it], b0); p1.gg = lane_bcast(v_gg[it], b1);
-                p0.gb = lane_bcast(v_gb[it], b0); p1.gb = lane_bcast(v_gb[it], b1);
-                p0.gd = lane_bcast(v_gd[it], b0); p1.gd = lane_bcast(v_gd[it], b1);
-                p0.T = lane_bcast(v_T[it], b0); p1.T = lane_bcast(v_T[it], b1);
-                p0.S = lane_bcast(v_S[it], b0); p1.S = lane_bcast(v_S[it], b1);
-                p0.last = (uint32_t)__builtin_amdgcn_readlane((int)v_last[it], b0);
-                p1.last = two ? (uint32_t)__builtin_amdgcn_readlane((int)v_last[it], b1) : 0u;  // second body inert
-                float T0, S0, T1, S1;
-                pixel_body<CH, NPIX>(p0, sl, L, q0i, ddelx_dx, ddely_dy, acc, fac, touched, T0, S0);
-                pixel_body<CH, NPIX>(p1, sl, L, q1i, ddelx_dx, ddely_dy, acc, fac, touched, T1, S1);
-                v_T[it] = lane == b0 ? T0 : v_T[it];
-                v_S[it] = lane == b0 ? S0 : v_S[it];
-                if (two) {
-                    v_T[it] = lane == b1 ? T1 : v_T[it];
-                    v_S[it] = lane == b1 ? S1 : v_S[it];
+                const int qi[2] = {it * 64 + b0, it * 64 + b1};
+                float4 pa[2], pb[2];
+                uint32_t lastq[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    pa[u] = L.pa[qi[u]];
+                    pb[u] = L.pb[qi[u]];
+                    lastq[u] = L.plast[qi[u]];
+                }
+                if (!two) lastq[1] = 0;   // second body inert
+                float dx[2], dy[2], G[2], al[2], f[2], q[2], D[2], P[2], Tb[2], w[2];
+                bool ok[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    dx[u] = sl.mx - pa[u].x; dy[u] = sl.my - pa[u].y;
+                    const float power = splat_power(dx[u], dy[u], sl.ca, sl.cb, sl.cc);
+                    G[u] = __expf(power);
+                    const float alpha = fminf(ALPHA_MAX, sl.op * G[u]);
+                    ok[u] = sl.have && sl.pos < lastq[u] && !(power > 0.0f) && !(alpha < ALPHA_MIN);
+                    al[u] = ok[u] ? alpha : 0.f;
+                    f[u] = __builtin_amdgcn_rcpf(1.f - al[u]);   // 1/(1-alpha); exactly 1 for skipped lanes
+                    P[u] = f[u];
+                    q[u] = fmaf(sl.cr, pb[u].x, fmaf(sl.cg, pb[u].y, fmaf(sl.cbl, pb[u].z, sl.dep * pb[u].w)));
+                }
+                touched = touched || ok[0] || ok[1];
+                wave_incl_prod2(P[0], P[1]);
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    Tb[u] = pa[u].z * P[u];           // transmittance in front of this splat
+                    w[u] = al[u] * Tb[u];
+                    D[u] = w[u] * q[u];
+                }
+                float Sinc[2] = {D[0], D[1]};
+                wave_incl_sum2(Sinc[0], Sinc[1]);
+                // lane 63 holds the chunk totals: it carries the pixel state to the next (nearer) chunk
+                if (lane == 63) {
+                    *reinterpret_cast<float2*>(&L.pa[qi[0]].z) = make_float2(Tb[0], pa[0].w + Sinc[0]);
+                    if (two) *reinterpret_cast<float2*>(&L.pa[qi[1]].z) = make_float2(Tb[1], pa[1].w + Sinc[1]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const float Sbehind = pa[u].w + (Sinc[u] - D[u]);
+                    float dL_dalpha = fmaf(Tb[u], q[u], -(Sbehind * f[u]));
+                    dL_dalpha = ok[u] ? dL_dalpha : 0.f;
+                    const float dL_dG = sl.op * dL_dalpha;
+                    const float Gs = ok[u] ? G[u] : 0.f;      // exp(power) may be inf where power > 0
+                    const float gdx = Gs * dx[u], gdy = Gs * dy[u];
+                    const float dG_ddelx = -gdx * sl.ca - gdy * sl.cb;
+                    const float dG_ddely = -gdy * sl.cc - gdx * sl.cb;
+                    acc[0] = fmaf(dL_dG * dG_ddelx, ddelx_dx, acc[0]);
+                    acc[1] = fmaf(dL_dG * dG_ddely, ddely_dy, acc[1]);
+                    const float hg = -0.5f * dL_dG;
+                    acc[2] = fmaf(gdx * hg, dx[u], acc[2]);
+                    acc[3] = fmaf(gdx * hg, dy[u], acc[3]);
+                    acc[4] = fmaf(gdy * hg, dy[u], acc[4]);
+                    acc[5] = fmaf(Gs, dL_dalpha, acc[5]);
+                    acc[6] = fmaf(w[u], pb[u].x, acc[6]);
+                    acc[7] = fmaf(w[u], pb[u].y, acc[7]);
+                    acc[8] = fmaf(w[u], pb[u].z, acc[8]);
+                    acc[9] = fmaf(w[u], pb[u].w, acc[9]);
+                    if constexpr (CH > 0 && !MF) {
+#pragma unroll
+                        for (int v = 0; v < CH / 4; v++) {
+                            const float4 gf = L.gf[v][qi[u]];
+                            fac[4 * v + 0] = fmaf(w[u], gf.x, fac[4 * v + 0]);
+                            fac[4 * v + 1] = fmaf(w[u], gf.y, fac[4 * v + 1]);
+                            fac[4 * v + 2] = fmaf(w[u], gf.z, fac[4 * v + 2]);
+                            fac[4 * v + 3] = fmaf(w[u], gf.w, fac[4 * v + 3]);
+                        }
+                    }
+                }
+                if constexpr (MF) {
+                    // A = W^T block: rows = instances, k = the two pixels.  One half-wave swap builds both
+                    // 32-instance operands:  X = [w0 lanes 0-31 | w1 lanes 0-31],  Y = [w0 lanes 32-63 | w1 lanes 32-63].
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[0]), __float_as_int(w[1]), false, false);
+                    const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
+                    const int prow = (lane < 32 ? qi[0] : qi[1]) * Lds::GS + (lane & 31);   // B[k][j] = dO[pixel k][channel j]
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        const float Bv = L.gfm[prow + 32 * nb];
+                        macc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv, macc[nb][0], 0, 0, 0);
+                        macc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv, macc[nb][1], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -283,7 +314,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         if (!__any(touched) || (a.ablate & 1)) continue;
         L.ids[lane] = gid;
         L.touched[lane] = touched ? 1u : 0u;
-        constexpr int NG = (CH + 10 + FLUSH_GROUP - 1) / FLUSH_GROUP;
+        constexpr int CHF = MF ? 0 : CH;            // feature channels that travel through the LDS transpose
+        constexpr int NG = (CHF + 10 + FLUSH_GROUP - 1) / FLUSH_GROUP;
         const int fsub = lane >> 4, fk = lane & 15;   // 4 instances per atomic instruction, 16 values each
 #pragma unroll
         for (int g = 0; g < NG; g++) {
@@ -292,8 +324,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
             for (int k = 0; k < FLUSH_GROUP; k++) {
                 const int idx = g * FLUSH_GROUP + k;   // compile-time: feature channel or geometric slot
                 float v = 0.f;
-                if (idx < CH) v = fac[idx < CH ? idx : 0];
-                else if (idx < CH + 10) v = acc[idx - CH < 10 ? (idx - CH >= 0 ? idx - CH : 0) : 0];
+                if (idx < CHF) v = fac[idx < CHF ? idx : 0];
+                else if (idx < CHF + 10) v = acc[idx - CHF < 10 ? (idx - CHF >= 0 ? idx - CHF : 0) : 0];
                 L.flush[lane * FLUSH_STRIDE + k] = v;
             }
             __builtin_amdgcn_wave_barrier();
@@ -304,28 +336,46 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 if (!L.touched[inst]) continue;
                 const uint32_t gg = L.ids[inst];
                 const float v = L.flush[inst * FLUSH_STRIDE + fk];
-                if (idx < CH) {
+                if (idx < CHF) {
                     if (idx < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + idx, v);
-                } else if (idx < CH + 10) {
-                    if (a.write_base) unsafeAtomicAdd(a.grec + (size_t)gg * GREC + (idx - CH), v);
+                } else if (idx < CHF + 10) {
+                    if (a.write_base) unsafeAtomicAdd(a.grec + (size_t)gg * GREC + (idx - CHF), v);
                 }
             }
+        }
+        if constexpr (MF) {
+            // D[i][j]: lane holds column j = lane & 31 (channel); register r holds row
+            // i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (instance = original lane index): every store is one
+            // contiguous 32-float run per half-wave.
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int inst = 32 * hh + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (!L.touched[inst]) continue;
+                    const uint32_t gg = L.ids[inst];
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        const int ch = 32 * nb + (lane & 31);
+                        if (ch < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + ch, macc[nb][hh][r]);
+                    }
+                }
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <int CH, int NPIX>
+template <int CH, int NPIX, bool MF>
 void launch_one(const BwdArgs& a, hipStream_t s) {
-    const size_t lds = sizeof(BwdLds<CH, NPIX>);
-    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX>), dim3(a.gx * a.gy * (256 / NPIX)), dim3(64), lds, s, a);
+    const size_t lds = sizeof(BwdLds<CH, NPIX, MF>);
+    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF>), dim3(a.gx * a.gy * (256 / NPIX)), dim3(64), lds, s, a);
 }
 
-template <int CH>
+template <int CH, bool MF>
 void launch_npix(const BwdArgs& a, int npix, hipStream_t s) {
-    if (npix == 256) launch_one<CH, 256>(a, s);
-    else if (npix == 64) launch_one<CH, 64>(a, s);
-    else launch_one<CH, 128>(a, s);
+    if (npix == 256) launch_one<CH, 256, MF>(a, s);
+    else if (npix == 128) launch_one<CH, 128, MF>(a, s);
+    else launch_one<CH, 64, MF>(a, s);
 }
 
 int env_int(const char* name, int dflt) {
@@ -336,29 +386,30 @@ int env_int(const char* name, int dflt) {
 }  // namespace
 
 void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
-                            const SplatRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                            const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                             const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
                             float* dL_dfeature, hipStream_t s) {
     BwdArgs a;
     a.ranges = ranges; a.point_list = point_list; a.rec = rec;
-    a.bg[0] = bg[0]; a.bg[1] = bg[1]; a.bg[2] = bg[2];
+    a.bg = vp.bg;
     a.final_T = final_T; a.n_contrib = n_contrib; a.dL_dpix = dL_dpix; a.dL_dfeat = dL_dfeat;
     a.dL_ddepth = dL_ddepth; a.grec = grec; a.dL_dfeature = dL_dfeature;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
     const int npix = env_int("F3DGS_BWD_NPIX", 64);
     a.ablate = env_int("F3DGS_BWD_ABLATE", 0);
+    const bool mf = env_int("F3DGS_FEATURE_MFMA", 1) != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
-        launch_npix<0>(a, npix, s);
+        launch_npix<0, false>(a, npix, s);
         return;
     }
     // channel windows of up to 64; the geometric sums ride along with the first window only
     for (int c0 = 0; c0 < C; c0 += 64) {
         a.c0 = c0; a.nc = min(64, C - c0); a.write_base = (c0 == 0);
-        if (a.nc <= 4) launch_npix<4>(a, npix, s);
-        else if (a.nc <= 16) launch_npix<16>(a, npix, s);
-        else if (a.nc <= 32) launch_npix<32>(a, npix, s);
-        else launch_npix<64>(a, npix == 256 ? 128 : npix, s);
+        if (a.nc <= 4) launch_npix<4, false>(a, npix, s);
+        else if (a.nc <= 16) launch_npix<16, false>(a, npix, s);
+        else if (a.nc <= 32) { if (mf) launch_npix<32, true>(a, npix, s); else launch_npix<32, false>(a, npix, s); }
+        else { if (mf) launch_npix<64, true>(a, 64, s); else launch_npix<64, false>(a, npix == 256 ? 128 : npix, s); }
     }
 }
 

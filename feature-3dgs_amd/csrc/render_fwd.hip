@@ -35,7 +35,7 @@ struct FwdArgs {
     const uint32_t* point_list;
     const SplatRec* rec;
     const float* feat;
-    float bg[3];
+    const float* bg;
     float* final_T;
     uint32_t* n_contrib;
     float* out_color;
@@ -207,11 +207,11 @@ int env_int(const char* name, int dflt) {
 }  // namespace
 
 void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
-                           const SplatRec* rec, const float* feat, const float* bg, float* final_T,
+                           const SplatRec* rec, const float* feat, float* final_T,
                            uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, hipStream_t s) {
     FwdArgs a;
     a.ranges = ranges; a.point_list = point_list; a.rec = rec; a.feat = feat;
-    a.bg[0] = bg[0]; a.bg[1] = bg[1]; a.bg[2] = bg[2];
+    a.bg = vp.bg;
     a.final_T = final_T; a.n_contrib = n_contrib; a.out_color = out_color; a.out_feat = out_feat;
     a.out_depth = out_depth;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;

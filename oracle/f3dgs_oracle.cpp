@@ -13,9 +13,10 @@
 // sub-steps (SH->RGB, scale/rot->cov3D), frozen in tests/golden/ by
 // tests/golden/make_reference_fallback_vectors.py; (ii) an independent
 // PyTorch-autograd restatement (oracle/torch_oracle.py) whose autograd
-// gradients must equal the analytic backward below; (iii) when available, the
-// reference CUDA sources compiled in place with hipcc into oracle/_ref/
-// (oracle/build_ref.sh) and run on the GPU box.
+// gradients must equal the analytic backward below.  There is no oracle/_ref:
+// compiling the reference in place with hipcc was tried and fails on constructs
+// that would need source rewriting ("<< <grid, block >> >" launch tokens,
+// __trap(), a NUM_CHANNELS macro colliding with hipCUB) - see DESIGN.md.
 //
 // Reference files restated (R = submodules/diff-gaussian-rasterization-feature):
 //   R/cuda_rasterizer/forward.cu:20-72    SH -> RGB              -> sh_to_rgb()
