@@ -81,6 +81,21 @@ struct BwdArgs {
 __device__ __forceinline__ void wave_incl_prod2(float& a, float& b) { F3DGS_SCAN2("v_mul_f32_dpp"); }
 __device__ __forceinline__ void wave_incl_sum2(float& a, float& b) { F3DGS_SCAN2("v_add_f32_dpp"); }
 #undef F3DGS_SCAN2
+// Four interleaved chains: three partner instructions cover the hazard, no s_nop needed between steps.
+#define F3DGS_STEP4(OP, CTRL)                                   \
+    OP " %0, %0, %0 " CTRL " bank_mask:0xf\n\t"                 \
+    OP " %1, %1, %1 " CTRL " bank_mask:0xf\n\t"                 \
+    OP " %2, %2, %2 " CTRL " bank_mask:0xf\n\t"                 \
+    OP " %3, %3, %3 " CTRL " bank_mask:0xf\n\t"
+#define F3DGS_SCAN4(OP)                                                                                     \
+    asm volatile("s_nop 1\n\t" F3DGS_STEP4(OP, "row_shr:1 row_mask:0xf") F3DGS_STEP4(OP, "row_shr:2 row_mask:0xf")  \
+                 F3DGS_STEP4(OP, "row_shr:4 row_mask:0xf") F3DGS_STEP4(OP, "row_shr:8 row_mask:0xf")            \
+                 F3DGS_STEP4(OP, "row_bcast:15 row_mask:0xa") F3DGS_STEP4(OP, "row_bcast:31 row_mask:0xc") "s_nop 1" \
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+__device__ __forceinline__ void wave_incl_prod4(float& a, float& b, float& c, float& d) { F3DGS_SCAN4("v_mul_f32_dpp"); }
+__device__ __forceinline__ void wave_incl_sum4(float& a, float& b, float& c, float& d) { F3DGS_SCAN4("v_add_f32_dpp"); }
+#undef F3DGS_SCAN4
+#undef F3DGS_STEP4
 
 // LDS image of one wave.  Per-pixel data is wave-uniform in the bodies and is fetched with broadcast
 // ds_reads (the LDS pipe is idle; v_readlane costs ~8 VALU cycles apiece on gfx950):
@@ -111,7 +126,7 @@ struct SplatLane { // one chunk entry per lane
     bool have;
 };
 
-template <int CH, int NPIX, bool MF>
+template <int CH, int NPIX, bool MF, int U>
 __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     constexpr int NB = MF ? CH / 32 : 0;       // 32-channel column blocks on the matrix pipe
     constexpr int CHV = CH / 4;
@@ -218,25 +233,28 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
             unsigned long long live = __ballot(v_last[it] > (uint32_t)k0);
             if (a.ablate & 2) { touched = sl.have; live = 0; }
             while (live) {
-                const int b0 = __builtin_ctzll(live);
-                live &= live - 1;
-                const bool two = live != 0;
-                const int b1 = two ? __builtin_ctzll(live) : b0;
-                live &= live - 1;   // (0 & anything) stays 0
-                const int qi[2] = {it * 64 + b0, it * 64 + b1};
-                float4 pa[2], pb[2];
-                uint32_t lastq[2];
+                // take up to U live pixels; missing ones repeat the first with n_contrib = 0 (inert bodies)
+                int qi[U];
+                bool act[U];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < U; u++) {
+                    act[u] = live != 0;
+                    const int b = act[u] ? __builtin_ctzll(live) : 0;
+                    live &= live - 1;   // (0 & anything) stays 0
+                    qi[u] = act[u] ? it * 64 + b : qi[0];
+                }
+                float4 pa[U], pb[U];
+                uint32_t lastq[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
                     pa[u] = L.pa[qi[u]];
                     pb[u] = L.pb[qi[u]];
-                    lastq[u] = L.plast[qi[u]];
+                    lastq[u] = act[u] ? L.plast[qi[u]] : 0u;
                 }
-                if (!two) lastq[1] = 0;   // second body inert
-                float dx[2], dy[2], G[2], al[2], f[2], q[2], D[2], P[2], Tb[2], w[2];
-                bool ok[2];
+                float dx[U], dy[U], G[U], al[U], f[U], q[U], D[U], P[U], Tb[U], w[U], Sinc[U];
+                bool ok[U];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < U; u++) {
                     dx[u] = sl.mx - pa[u].x; dy[u] = sl.my - pa[u].y;
                     const float power = splat_power(dx[u], dy[u], sl.ca, sl.cb, sl.cc);
                     G[u] = __expf(power);
@@ -246,24 +264,27 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     f[u] = __builtin_amdgcn_rcpf(1.f - al[u]);   // 1/(1-alpha); exactly 1 for skipped lanes
                     P[u] = f[u];
                     q[u] = fmaf(sl.cr, pb[u].x, fmaf(sl.cg, pb[u].y, fmaf(sl.cbl, pb[u].z, sl.dep * pb[u].w)));
+                    touched = touched || ok[u];
                 }
-                touched = touched || ok[0] || ok[1];
-                wave_incl_prod2(P[0], P[1]);
+                if constexpr (U == 4) wave_incl_prod4(P[0], P[1], P[2], P[3]);
+                else wave_incl_prod2(P[0], P[1]);
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < U; u++) {
                     Tb[u] = pa[u].z * P[u];           // transmittance in front of this splat
                     w[u] = al[u] * Tb[u];
                     D[u] = w[u] * q[u];
+                    Sinc[u] = D[u];
                 }
-                float Sinc[2] = {D[0], D[1]};
-                wave_incl_sum2(Sinc[0], Sinc[1]);
+                if constexpr (U == 4) wave_incl_sum4(Sinc[0], Sinc[1], Sinc[2], Sinc[3]);
+                else wave_incl_sum2(Sinc[0], Sinc[1]);
                 // lane 63 holds the chunk totals: it carries the pixel state to the next (nearer) chunk
                 if (lane == 63) {
-                    *reinterpret_cast<float2*>(&L.pa[qi[0]].z) = make_float2(Tb[0], pa[0].w + Sinc[0]);
-                    if (two) *reinterpret_cast<float2*>(&L.pa[qi[1]].z) = make_float2(Tb[1], pa[1].w + Sinc[1]);
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                        if (act[u]) *reinterpret_cast<float2*>(&L.pa[qi[u]].z) = make_float2(Tb[u], pa[u].w + Sinc[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < U; u++) {
                     const float Sbehind = pa[u].w + (Sinc[u] - D[u]);
                     float dL_dalpha = fmaf(Tb[u], q[u], -(Sbehind * f[u]));
                     dL_dalpha = ok[u] ? dL_dalpha : 0.f;
@@ -295,16 +316,19 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     }
                 }
                 if constexpr (MF) {
-                    // A = W^T block: rows = instances, k = the two pixels.  One half-wave swap builds both
-                    // 32-instance operands:  X = [w0 lanes 0-31 | w1 lanes 0-31],  Y = [w0 lanes 32-63 | w1 lanes 32-63].
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[0]), __float_as_int(w[1]), false, false);
-                    const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
-                    const int prow = (lane < 32 ? qi[0] : qi[1]) * Lds::GS + (lane & 31);   // B[k][j] = dO[pixel k][channel j]
+                    // A = W^T block: rows = instances, k = two pixels.  One half-wave swap builds both 32-instance
+                    // operands:  X = [w_a lanes 0-31 | w_b lanes 0-31],  Y = [w_a lanes 32-63 | w_b lanes 32-63].
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++) {
-                        const float Bv = L.gfm[prow + 32 * nb];
-                        macc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv, macc[nb][0], 0, 0, 0);
-                        macc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv, macc[nb][1], 0, 0, 0);
+                    for (int u = 0; u < U; u += 2) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[u]), __float_as_int(w[u + 1]), false, false);
+                        const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
+                        const int prow = (lane < 32 ? qi[u] : qi[u + 1]) * Lds::GS + (lane & 31);   // B[k][j] = dO[pixel k][channel j]
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) {
+                            const float Bv = L.gfm[prow + 32 * nb];
+                            macc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv, macc[nb][0], 0, 0, 0);
+                            macc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv, macc[nb][1], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -365,10 +389,19 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     }
 }
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 template <int CH, int NPIX, bool MF>
 void launch_one(const BwdArgs& a, hipStream_t s) {
     const size_t lds = sizeof(BwdLds<CH, NPIX, MF>);
-    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF>), dim3(a.gx * a.gy * (256 / NPIX)), dim3(64), lds, s, a);
+    const dim3 grid(a.gx * a.gy * (256 / NPIX));
+    if (env_int("F3DGS_BWD_U", 4) == 2)
+        hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 2>), grid, dim3(64), lds, s, a);
+    else
+        hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4>), grid, dim3(64), lds, s, a);
 }
 
 template <int CH, bool MF>
@@ -378,10 +411,6 @@ void launch_npix(const BwdArgs& a, int npix, hipStream_t s) {
     else launch_one<CH, 64, MF>(a, s);
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 }  // namespace
 

@@ -21,6 +21,11 @@ namespace f3dgs {
 
 namespace {
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 template <int CH>
 struct FwdChunk {
     float4 geo[64];  // mean_x, mean_y, conic_a, conic_b
@@ -45,6 +50,7 @@ struct FwdArgs {
     int C;        // total feature channels (row stride of feat)
     int c0, nc;   // channel window handled by this launch
     int write_base;  // 1: also write colour / depth / final_T / n_contrib
+    int ablate;      // development only (F3DGS_FWD_ABLATE): bit0 skip blend loop, bit1 skip feature staging, bit2 skip epilogue stores
 };
 
 template <int CH, int PPL>
@@ -192,6 +198,233 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Variant with the feature blend on the matrix pipe.  out[px][c] += sum_g w[px][g] f[g][c] is a contraction
+// over the instances of the list; measured on MI355X the blend kernels are VALU-issue bound (SQ counters in
+// profiles/), not HBM bound, so the C FMAs per (pixel, instance) move to exact-fp32 v_mfma_f32_32x32x2_f32
+// (same rounding as an fmaf chain) and run concurrently with the VALU alpha evaluation.  Instances are taken
+// two at a time (K = 2): A[i][k] = w of pixel i for instance j+k, built from the two per-lane weights with
+// one v_permlane32_swap; B[k][n] = feature n of instance j+k, one ds_read_b32 per lane.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CH>
+struct FwdChunkMF {
+    float4 geo[64];   // mean_x, mean_y, conic_a, conic_b
+    float2 co[64];    // conic_c, opacity
+    float4 cd[64];    // r, g, b, depth
+    uint32_t id[64 + 8];
+    static constexpr int FT = (64 * CH > 32 * 65) ? 64 * CH : 32 * 65;
+    float feat[FT];        // row-major [instance][channel]; reused as the epilogue transpose tile [channel][65]
+};
+
+// The next chunk's ids and splat records are prefetched into registers while the current chunk is blended.
+// (Fetching the B operand straight from global memory, prefetched two groups ahead, was measured slower
+// than staging the chunk's feature rows in LDS: 0.62 vs 0.57 ms at config c3.)
+template <int CH, int PPL>
+__global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs a) {
+    constexpr int NW = 4 / PPL;
+    constexpr int NB = CH / 32;
+    constexpr int GI = 4;             // instances per straight-line group
+    constexpr int NP = GI / 2;        // instance pairs (MFMA K = 2) per group
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    FwdChunkMF<CH>& ck = reinterpret_cast<FwdChunkMF<CH>*>(smem)[NW > 1 ? wave : 0];
+
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const uint2 rg = a.ranges[tile];
+    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x), r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
+
+    const int lx = lane & 7, ly = lane >> 3;
+    float pxf[PPL], pyf[PPL];
+    int pix_id[PPL];
+    bool inside[PPL], done[PPL];
+    float T[PPL], col[PPL][3], dep[PPL];
+    uint32_t last[PPL];
+    f32x16 acc[PPL][2][NB];
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        const int q = wave * PPL + p;
+        const int x = tx * TILE + (q & 1) * 8 + lx, y = ty * TILE + (q >> 1) * 8 + ly;
+        pxf[p] = (float)x; pyf[p] = (float)y;
+        inside[p] = x < a.W && y < a.H;
+        pix_id[p] = y * a.W + x;
+        done[p] = !inside[p];
+        T[p] = 1.0f; dep[p] = 0.f; last[p] = 0;
+        col[p][0] = col[p][1] = col[p][2] = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[p][h][nb][r] = 0.f;
+    }
+
+    // software pipeline, stage 0: ids + records of the first chunk
+    uint32_t n_id = 0;
+    float4 n_q0 = make_float4(0, 0, 0, 0), n_q1 = n_q0, n_q2 = n_q0;
+    if (r_lo + lane < r_hi) {
+        n_id = a.point_list[r_lo + lane];
+        const SplatRec* rp = a.rec + n_id;
+        n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
+    }
+
+    for (uint32_t base = r_lo; base < r_hi; base += 64) {
+        bool alld = true;
+#pragma unroll
+        for (int p = 0; p < PPL; p++) alld = alld && done[p];
+        if (__all(alld)) break;
+        const int cnt = (int)min(64u, r_hi - base);
+        __builtin_amdgcn_wave_barrier();
+        ck.geo[lane] = n_q0;
+        ck.co[lane] = make_float2(n_q1.x, n_q1.y);
+        ck.cd[lane] = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
+        ck.id[lane] = n_id;
+        __builtin_amdgcn_wave_barrier();
+        // prefetch the next chunk (registers) while this one is blended
+        if (base + 64 + lane < r_hi) {
+            n_id = a.point_list[base + 64 + lane];
+            const SplatRec* rp = a.rec + n_id;
+            n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
+        }
+
+        // feature rows of the chunk -> LDS (coalesced: CH/4 lanes x 16 B per instance)
+        if (!(a.ablate & 2)) {
+            constexpr int CHV = CH / 4;
+            const bool vec_ok = (a.C & 3) == 0 && (a.c0 & 3) == 0;
+            for (int e = lane; e < cnt * CHV; e += 64) {
+                const int inst = e / CHV, v = e % CHV;
+                const uint32_t g = ck.id[inst];
+                const float* src = a.feat + (size_t)g * a.C + a.c0 + 4 * v;
+                float4 f;
+                if (vec_ok && 4 * v + 3 < a.nc) {
+                    f = *reinterpret_cast<const float4*>(src);
+                } else {
+                    f.x = 4 * v + 0 < a.nc ? src[0] : 0.f;
+                    f.y = 4 * v + 1 < a.nc ? src[1] : 0.f;
+                    f.z = 4 * v + 2 < a.nc ? src[2] : 0.f;
+                    f.w = 4 * v + 3 < a.nc ? src[3] : 0.f;
+                }
+                *reinterpret_cast<float4*>(&ck.feat[inst * CH + 4 * v]) = f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        for (int j = 0; j < ((a.ablate & 1) ? 0 : cnt); j += GI) {
+            float4 g0[GI], cdv[GI];
+            float2 g1[GI];
+            bool live_e[GI];
+#pragma unroll
+            for (int e = 0; e < GI; e++) {
+                live_e[e] = j + e < cnt;
+                const int je = live_e[e] ? j + e : j;
+                g0[e] = ck.geo[je];
+                g1[e] = ck.co[je];
+                cdv[e] = ck.cd[je];
+            }
+            float araw[GI][PPL];
+            bool valid[GI][PPL];
+#pragma unroll
+            for (int e = 0; e < GI; e++)
+#pragma unroll
+                for (int p = 0; p < PPL; p++) {
+                    const float dx = g0[e].x - pxf[p], dy = g0[e].y - pyf[p];
+                    const float power = splat_power(dx, dy, g0[e].z, g0[e].w, g1[e].x);
+                    araw[e][p] = fminf(ALPHA_MAX, g1[e].y * __expf(power));
+                    valid[e][p] = live_e[e] && !(power > 0.0f) && !(araw[e][p] < ALPHA_MIN);
+                }
+            float w[GI][PPL];
+            bool any_blend = false;
+#pragma unroll
+            for (int e = 0; e < GI; e++)
+#pragma unroll
+                for (int p = 0; p < PPL; p++) {
+                    bool ok = valid[e][p] && !done[p];
+                    const float test_T = T[p] * (1.0f - araw[e][p]);
+                    if (ok && test_T < T_MIN) {
+                        done[p] = true;
+                        ok = false;
+                    }
+                    const float wv = ok ? araw[e][p] * T[p] : 0.0f;
+                    w[e][p] = wv;
+                    if (ok) {
+                        T[p] = test_T;
+                        last[p] = base - r_lo + j + e + 1;
+                    }
+                    col[p][0] = fmaf(cdv[e].x, wv, col[p][0]);
+                    col[p][1] = fmaf(cdv[e].y, wv, col[p][1]);
+                    col[p][2] = fmaf(cdv[e].z, wv, col[p][2]);
+                    dep[p] = fmaf(cdv[e].w, wv, dep[p]);
+                    any_blend = any_blend || ok;
+                }
+            if (__any(any_blend)) {
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    // B rows: instance j+2k for lanes 0-31, j+2k+1 for lanes 32-63 (a missing instance has w = 0 and
+                    // re-reads row j so that stale LDS contents can never inject a NaN)
+                    const int e0 = 2 * k;
+                    const int rsel = (lane >> 5) ? (live_e[e0 + 1] ? j + e0 + 1 : j) : (live_e[e0] ? j + e0 : j);
+                    const int brow = rsel * CH + (lane & 31);
+#pragma unroll
+                    for (int p = 0; p < PPL; p++) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[e0][p]),
+                                                                         __float_as_int(w[e0 + 1][p]), false, false);
+                        const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) {
+                            const float Bv = ck.feat[brow + 32 * nb];
+                            acc[p][0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv, acc[p][0][nb], 0, 0, 0);
+                            acc[p][1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv, acc[p][1][nb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const size_t HW = (size_t)a.W * a.H;
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        if (a.write_base && inside[p]) {
+            const size_t pid = (size_t)pix_id[p];
+            a.final_T[pid] = T[p];
+            a.n_contrib[pid] = last[p];
+            a.out_color[pid] = col[p][0] + T[p] * a.bg[0];
+            a.out_color[HW + pid] = col[p][1] + T[p] * a.bg[1];
+            a.out_color[2 * HW + pid] = col[p][2] + T[p] * a.bg[2];
+            a.out_depth[pid] = dep[p];
+        }
+        // D[i][n]: lane holds column n = lane & 31 (channel), register r holds row i = (r&3) + 8(r>>2) + 4(lane>>5)
+        // (pixel 32h + i of this slot).  Transpose through LDS ([channel][65]) so that lanes are pixels again.
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int i = 32 * h + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    ck.feat[(lane & 31) * 65 + i] = acc[p][h][nb][r];
+                }
+            __builtin_amdgcn_wave_barrier();
+            if (inside[p] && !(a.ablate & 4)) {
+#pragma unroll 8
+                for (int n = 0; n < 32; n++)
+                    if (32 * nb + n < a.nc)
+                        a.out_feat[(size_t)(a.c0 + 32 * nb + n) * HW + (size_t)pix_id[p]] = ck.feat[n * 65 + lane];
+            }
+        }
+    }
+}
+
+template <int CH, int PPL>
+void launch_one_mf(const FwdArgs& a, hipStream_t s) {
+    constexpr int NW = 4 / PPL;
+    const size_t lds = NW * sizeof(FwdChunkMF<CH>);
+    hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
+}
+
 template <int CH, int PPL>
 void launch_one(const FwdArgs& a, hipStream_t s) {
     constexpr int NW = 4 / PPL;
@@ -199,10 +432,6 @@ void launch_one(const FwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((render_forward_kernel<CH, PPL>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 }  // namespace
 
@@ -215,7 +444,9 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges, con
     a.final_T = final_T; a.n_contrib = n_contrib; a.out_color = out_color; a.out_feat = out_feat;
     a.out_depth = out_depth;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
+    a.ablate = env_int("F3DGS_FWD_ABLATE", 0);
     const int ppl = env_int("F3DGS_FWD_PPL", 0);
+    const bool mf = env_int("F3DGS_FEATURE_MFMA", 1) != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
         if (ppl == 1) launch_one<0, 1>(a, s);
@@ -230,9 +461,11 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges, con
         } else if (a.nc <= 16) {
             if (ppl == 1) launch_one<16, 1>(a, s); else if (ppl == 2) launch_one<16, 2>(a, s); else launch_one<16, 4>(a, s);
         } else if (a.nc <= 32) {
-            if (ppl == 1) launch_one<32, 1>(a, s); else if (ppl == 4) launch_one<32, 4>(a, s); else launch_one<32, 2>(a, s);
+            if (mf) { if (ppl == 1) launch_one_mf<32, 1>(a, s); else launch_one_mf<32, 2>(a, s); }
+            else if (ppl == 1) launch_one<32, 1>(a, s); else if (ppl == 4) launch_one<32, 4>(a, s); else launch_one<32, 2>(a, s);
         } else {
-            if (ppl == 2) launch_one<64, 2>(a, s); else launch_one<64, 1>(a, s);
+            if (mf) { if (ppl == 2) launch_one_mf<64, 2>(a, s); else launch_one_mf<64, 1>(a, s); }
+            else if (ppl == 2) launch_one<64, 2>(a, s); else launch_one<64, 1>(a, s);
         }
     }
 }
