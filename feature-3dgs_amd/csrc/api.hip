@@ -326,7 +326,13 @@ int f3dgs_debug_read(const char* what, int P, int C, int R, int width, int heigh
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
     const size_t HW = (size_t)width * height, tiles = (size_t)gx * gy;
     GeomState geom = GeomState::carve(const_cast<char*>(geom_buffer), P, nullptr);
-    BinState bin = BinState::carve(const_cast<char*>(binning_buffer), R, nullptr);
+    // the binning buffer was carved with the length of OUR instance list (counters[0]), not with R
+    uint32_t n_list = (uint32_t)R;
+    if (P > 0 && geom_buffer) {
+        HIP_TRY(hipMemcpyAsync(&n_list, geom.counters, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    BinState bin = BinState::carve(const_cast<char*>(binning_buffer), n_list, nullptr);
     ImageState img = ImageState::carve(const_cast<char*>(image_buffer), HW, tiles, nullptr);
     const std::string w(what);
     const void* src = nullptr;
@@ -338,8 +344,8 @@ int f3dgs_debug_read(const char* what, int P, int C, int R, int width, int heigh
     else if (w == "order") { src = geom.val_a; bytes = (size_t)P * 4; }
     else if (w == "offsets") { src = geom.offsets; bytes = (size_t)P * 4; }
     else if (w == "counters") { src = geom.counters; bytes = 16 * 4; }
-    else if (w == "point_list") { src = bin.point_list; bytes = (size_t)R * 4; }
-    else if (w == "tile_sorted") { src = bin.tile_sorted; bytes = (size_t)R * 4; }
+    else if (w == "point_list") { src = bin.point_list; bytes = (size_t)n_list * 4; }
+    else if (w == "tile_sorted") { src = bin.tile_sorted; bytes = (size_t)n_list * 4; }
     else if (w == "ranges") { src = img.ranges; bytes = tiles * 8; }
     else if (w == "final_T") { src = img.final_T; bytes = HW * 4; }
     else if (w == "n_contrib") { src = img.n_contrib; bytes = HW * 4; }

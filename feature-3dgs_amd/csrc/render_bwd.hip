@@ -396,7 +396,7 @@ int env_int(const char* name, int dflt) {
 
 template <int CH, int NPIX, bool MF>
 void launch_one(const BwdArgs& a, hipStream_t s) {
-    const size_t lds = sizeof(BwdLds<CH, NPIX, MF>);
+    const size_t lds = sizeof(BwdLds<CH, NPIX, MF>) + (size_t)env_int("F3DGS_BWD_EXTRA_LDS", 0);   // extra: occupancy experiments
     const dim3 grid(a.gx * a.gy * (256 / NPIX));
     if (env_int("F3DGS_BWD_U", 4) == 2)
         hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 2>), grid, dim3(64), lds, s, a);
