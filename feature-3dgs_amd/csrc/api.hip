@@ -209,9 +209,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     tm.mark("preprocess");
 
     // depth sort of the Gaussians (ids start in index order -> ties keep ascending id)
-    HIP_TRY(hipMemcpyAsync(geom.key_a, geom.depth_key, (size_t)P * 4, hipMemcpyDeviceToDevice, s));
-    launch_iota(geom.val_a, (size_t)P, s);
-    launch_radix_sort_pairs(geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, 32, geom.hist, true, s);
+    launch_depth_sort(geom.depth_key, geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, geom.hist, s);
     if ((rc = check_debug(debug, s, "depth sort"))) return rc;
     tm.mark("depth_sort");
     const uint32_t* order = geom.val_a;

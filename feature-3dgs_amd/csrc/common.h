@@ -43,8 +43,10 @@ struct Carver {
     size_t total() const { return (off + ALIGN - 1) & ~(ALIGN - 1); }
 };
 
-constexpr int RADIX_BITS = 8;
+constexpr int RADIX_BITS = 8;                 // tile-id passes
 constexpr int RADIX_BINS = 1 << RADIX_BITS;
+constexpr int DEPTH_RADIX_BITS = 11;          // depth-key passes: 11 + 11 + 10 bits
+constexpr int DEPTH_RADIX_BINS = 1 << DEPTH_RADIX_BITS;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 16;                                  // items per thread
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;           // items per workgroup
@@ -79,7 +81,7 @@ struct GeomState {
         g.val_a = c.take<uint32_t>(P);
         g.val_b = c.take<uint32_t>(P);
         g.offsets = c.take<uint32_t>(P);
-        g.hist = c.take<uint32_t>(RADIX_BINS * sort_blocks(P) + RADIX_BINS);
+        g.hist = c.take<uint32_t>(DEPTH_RADIX_BINS * sort_blocks(P) + DEPTH_RADIX_BINS);
         g.scan_tmp = c.take<uint32_t>(scan_blocks(P) + 8);
         g.ref_partial = c.take<uint32_t>((P + 255) / 256 + 1);
         g.counters = c.take<uint32_t>(16);
@@ -160,6 +162,8 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
                              uint32_t* hist, bool result_in_a, hipStream_t s);
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
                            uint32_t* inst_tile, uint32_t* inst_id, hipStream_t s);
+void launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
+                       uint32_t* hist, hipStream_t s);
 void launch_iota(uint32_t* dst, size_t n, hipStream_t s);
 void launch_tile_ranges(size_t N, const uint32_t* tile_sorted, uint2* ranges, size_t tiles, hipStream_t s);
 

@@ -48,6 +48,7 @@ struct BwdArgs {
     int W, H, gx, gy;
     int C, c0, nc;
     int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
+    int part_major;  // workgroup -> (tile, part) order, see kernel
     int ablate;      // development only (F3DGS_BWD_ABLATE): bit0 = skip the flush, bit1 = skip the pixel bodies
 };
 
@@ -132,23 +133,27 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     constexpr int CHV = CH / 4;
     constexpr int PARTS = 256 / NPIX;          // waves (workgroups) per tile
     constexpr int ROWS = NPIX / 16;            // pixel rows owned by this wave (NPIX = 256/128/64)
-    constexpr int NV = NPIX / 64;              // pixel-state registers per lane
+    constexpr int NV = NPIX >= 64 ? NPIX / 64 : 1;   // pixel-state registers per lane (NPIX = 32: lanes 32-63 idle here)
     using Lds = BwdLds<CH, NPIX, MF>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds& L = *reinterpret_cast<Lds*>(smem);
     const int lane = threadIdx.x;
 
     const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t tile = wg / PARTS;
-    const int part = wg % PARTS;
+    // a.part_major: the PARTS waves of one tile are scheduled far apart (fewer simultaneous atomics on the same
+    // gradient lines) instead of back to back (better L2 reuse of the tile's splat records)
+    const uint32_t ntiles = gridDim.x / PARTS;
+    const uint32_t tile = a.part_major ? wg % ntiles : wg / PARTS;
+    const int part = a.part_major ? wg / ntiles : wg % PARTS;
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 rg = a.ranges[tile];
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
     const size_t HW = (size_t)a.W * a.H;
-    // pixel p of this wave: row (p / 16) + part*ROWS, column p % 16  (NPIX=64: quadrant split instead)
-    const int px0 = tx * TILE + (NPIX == 64 ? (part & 1) * 8 : 0);
-    const int py0 = ty * TILE + (NPIX == 64 ? (part >> 1) * 8 : part * ROWS);
-    constexpr int PW = NPIX == 64 ? 8 : 16;    // pixels per row of this wave's block
+    // pixel block of this wave: NPIX >= 128 -> ROWS full rows; 64 -> one 8x8 quadrant; 32 -> half a quadrant (8x4)
+    const int qd = NPIX == 32 ? part >> 1 : part;
+    const int px0 = tx * TILE + (NPIX <= 64 ? (qd & 1) * 8 : 0);
+    const int py0 = ty * TILE + (NPIX <= 64 ? (qd >> 1) * 8 + (NPIX == 32 ? (part & 1) * 4 : 0) : part * ROWS);
+    constexpr int PW = NPIX <= 64 ? 8 : 16;    // pixels per row of this wave's block
 
     // ---- stage the per-pixel data into LDS (lane = pixel here) -----------------------------------------
     uint32_t v_last[NV];
@@ -157,7 +162,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     for (int it = 0; it < NV; it++) {
         const int p = it * 64 + lane;
         const int x = px0 + p % PW, y = py0 + p / PW;
-        const bool inside = x < a.W && y < a.H;
+        const bool inside = p < NPIX && x < a.W && y < a.H;
         const size_t pid = (size_t)y * a.W + x;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float Tf = 0.f;
@@ -168,11 +173,13 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
             Tf = a.final_T[pid];
             v_last[it] = a.n_contrib[pid];
         }
-        L.pa[p] = make_float4((float)x, (float)y, Tf, Tf * (a.bg[0] * g.x + a.bg[1] * g.y + a.bg[2] * g.z));
-        L.pb[p] = g;
-        L.plast[p] = v_last[it];
+        if (p < NPIX) {
+            L.pa[p] = make_float4((float)x, (float)y, Tf, Tf * (a.bg[0] * g.x + a.bg[1] * g.y + a.bg[2] * g.z));
+            L.pb[p] = g;
+            L.plast[p] = v_last[it];
+        }
         max_last = max(max_last, v_last[it]);
-        if constexpr (CH > 0) {
+        if (CH > 0 && p < NPIX) {
 #pragma unroll
             for (int v = 0; v < CHV; v++) {
                 float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -408,6 +415,7 @@ template <int CH, bool MF>
 void launch_npix(const BwdArgs& a, int npix, hipStream_t s) {
     if (npix == 256) launch_one<CH, 256, MF>(a, s);
     else if (npix == 128) launch_one<CH, 128, MF>(a, s);
+    else if (npix == 32) launch_one<CH, 32, MF>(a, s);
     else launch_one<CH, 64, MF>(a, s);
 }
 
@@ -426,6 +434,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
     const int npix = env_int("F3DGS_BWD_NPIX", 64);
     a.ablate = env_int("F3DGS_BWD_ABLATE", 0);
+    a.part_major = env_int("F3DGS_BWD_PART_MAJOR", 0);
     const bool mf = env_int("F3DGS_FEATURE_MFMA", 1) != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
