@@ -272,7 +272,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         if (colors_precomp) {
             col = {colors_precomp[3 * (size_t)i], colors_precomp[3 * (size_t)i + 1], colors_precomp[3 * (size_t)i + 2]};
         } else {
-            col = sh_to_rgb(D, p, vp.campos, shs + 3 * (size_t)M * i, cl);
+            col = sh_to_rgb(D, p, vp.campos, shs + 3 * (size_t)M * i, cl);   // (LDS staging measured slower here)
         }
         SplatRec r;
         r.q0 = make_float4(px, py, ca, cb);
@@ -398,9 +398,30 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
                            float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
                            float* __restrict__ dL_dscale, float* __restrict__ dL_drot, float* __restrict__ dL_dz) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const size_t si = (size_t)i;
-    const bool vis = radii[i] > 0;
+    // SH coefficients in, SH gradients out: both are contiguous per workgroup and go through one LDS tile
+    // (coalesced 16-byte global accesses; per-thread rows with an odd stride).
+    extern __shared__ __attribute__((aligned(16))) float sh_lds[];
+    const int row = 3 * M + 1;
+    const bool use_sh = dL_dsh && M > 0;
+    const size_t sh_first = (size_t)blockIdx.x * 256 * 3 * M;
+    const int sh_count = use_sh ? (int)min((size_t)256 * 3 * M, (size_t)P * 3 * M - sh_first) : 0;
+    const int m3 = 3 * M;                           // LDS index of element e: e + e / m3 (row stride m3 + 1)
+    const bool sh_vec = (m3 & 3) == 0;              // rows are whole float4s (sh_first = 768 M is always 16-B aligned)
+    if (use_sh) {
+        if (sh_vec) {
+            for (int e = 4 * threadIdx.x; e < sh_count; e += 4 * 256) {
+                const float4 q = *reinterpret_cast<const float4*>(shs + sh_first + e);
+                float* d = sh_lds + e + e / m3;
+                d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+            }
+        } else {
+            for (int e = threadIdx.x; e < sh_count; e += 256) sh_lds[e + e / m3] = shs[sh_first + e];
+        }
+        __syncthreads();
+    }
+    const bool in_range = i < P;
+    const size_t si = (size_t)(in_range ? i : 0);
+    const bool vis = in_range && radii[si] > 0;
     float gr[GREC];
     if (vis) {
         const float4* g4 = reinterpret_cast<const float4*>(grec + si * GREC);
@@ -412,13 +433,13 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
         for (int k = 0; k < GREC; k++) gr[k] = 0.f;
     }
     // pass-through outputs
-    dL_dmean2D[3 * si] = gr[0]; dL_dmean2D[3 * si + 1] = gr[1]; dL_dmean2D[3 * si + 2] = 0.f;
-    dL_dopacity[i] = gr[5];
-    dL_dcolor[3 * si] = gr[6]; dL_dcolor[3 * si + 1] = gr[7]; dL_dcolor[3 * si + 2] = gr[8];
-    if (dL_dconic) {
-        reinterpret_cast<float4*>(dL_dconic)[i] = make_float4(gr[2], gr[3], 0.f, gr[4]);
+    if (in_range) {
+        dL_dmean2D[3 * si] = gr[0]; dL_dmean2D[3 * si + 1] = gr[1]; dL_dmean2D[3 * si + 2] = 0.f;
+        dL_dopacity[si] = gr[5];
+        dL_dcolor[3 * si] = gr[6]; dL_dcolor[3 * si + 1] = gr[7]; dL_dcolor[3 * si + 2] = gr[8];
+        if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[si] = make_float4(gr[2], gr[3], 0.f, gr[4]);
+        if (dL_dz) dL_dz[si] = gr[9];
     }
-    if (dL_dz) dL_dz[i] = gr[9];
 
     float dcov6[6] = {0, 0, 0, 0, 0, 0};
     V3 dmean = {0, 0, 0};
@@ -434,7 +455,7 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
             for (int k = 0; k < 6; k++) cov6[k] = cov3D_precomp[6 * si + k];
         } else {
             sc = {scales[3 * si], scales[3 * si + 1], scales[3 * si + 2]};
-            q = reinterpret_cast<const float4*>(rotations)[i];
+            q = reinterpret_cast<const float4*>(rotations)[si];
             cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov6);
         }
         // ---- conic -> cov2D -> (cov3D, t) --------------------------------------------------------
@@ -531,20 +552,37 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
         }
     }
     // ---- SH gradients (writes all M coefficients; zero where unused / culled) ---------------------
-    if (dL_dsh && M > 0) {
-        float* dsh = dL_dsh + 3 * (size_t)M * si;
+    if (use_sh) {
+        // the thread's LDS row holds its SH coefficients; the gradients overwrite it in place: sh_grad reads
+        // coefficient k only for direction terms, which are accumulated into ddx/ddy/ddz BEFORE put(k) of a
+        // higher band can alias... (they do alias: keep a private copy of the row first)
+        float* rowp = sh_lds + threadIdx.x * row;
+        float shc[48];                                 // private copy: the gradients overwrite the row in place
+#pragma unroll
+        for (int k = 0; k < 48; k++) shc[k] = k < m3 ? rowp[k] : 0.f;
         const int used = vis ? (D + 1) * (D + 1) : 0;
-        for (int k = 3 * (used < M ? used : M); k < 3 * M; k++) dsh[k] = 0.f;
+        const int usedc = used < M ? used : M;
+        for (int k = 3 * usedc; k < m3; k++) rowp[k] = 0.f;
         if (vis) {
             const V3 dcol = {gr[6], gr[7], gr[8]};
-            sh_grad(D, mean, vp.campos, shs + 3 * (size_t)M * si, clamped[i], dcol, dmean, dsh);
+            sh_grad(D, mean, vp.campos, shc, clamped[si], dcol, dmean, rowp);
+        }
+        __syncthreads();
+        if (sh_vec) {
+            for (int e = 4 * threadIdx.x; e < sh_count; e += 4 * 256) {
+                const float* d = sh_lds + e + e / m3;
+                *reinterpret_cast<float4*>(dL_dsh + sh_first + e) = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        } else {
+            for (int e = threadIdx.x; e < sh_count; e += 256) dL_dsh[sh_first + e] = sh_lds[e + e / m3];
         }
     }
+    if (!in_range) return;
     dL_dmean3D[3 * si] = dmean.x; dL_dmean3D[3 * si + 1] = dmean.y; dL_dmean3D[3 * si + 2] = dmean.z;
 #pragma unroll
     for (int k = 0; k < 6; k++) dL_dcov3D[6 * si + k] = dcov6[k];
     if (dL_dscale) { dL_dscale[3 * si] = dscale[0]; dL_dscale[3 * si + 1] = dscale[1]; dL_dscale[3 * si + 2] = dscale[2]; }
-    if (dL_drot) reinterpret_cast<float4*>(dL_drot)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    if (dL_drot) reinterpret_cast<float4*>(dL_drot)[si] = make_float4(drot[0], drot[1], drot[2], drot[3]);
 }
 
 }  // namespace
@@ -577,7 +615,8 @@ void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dz,
                                 hipStream_t s) {
     (void)C;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii, shs,
+    const size_t lds = (dL_dsh && M > 0) ? (size_t)256 * (3 * M + 1) * sizeof(float) : 0;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + 255) / 256), dim3(256), lds, s, P, D, M, means3D, radii, shs,
                        scales, rotations, cov3D_precomp, vp, g.clamped, grec, dL_dmean2D, dL_dconic, dL_dopacity,
                        dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dz);
 }
