@@ -116,7 +116,8 @@ struct BwdLds {
     uint32_t plast[NPIX];
     float4 gf[MF ? 1 : (CH > 0 ? CH / 4 : 1)][MF ? 1 : NPIX];
     float gfm[MF ? NPIX * GS : 1];
-    float flush[64 * FLUSH_STRIDE];
+    static constexpr int FS = MF ? 11 : FLUSH_STRIDE;   // MF: only the 10 geometric sums travel through LDS
+    float flush[64 * FS];
     uint32_t ids[64];
     uint32_t touched[64];
 };
@@ -354,10 +355,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
 #pragma unroll
             for (int k = 0; k < FLUSH_GROUP; k++) {
                 const int idx = g * FLUSH_GROUP + k;   // compile-time: feature channel or geometric slot
+                if (k >= Lds::FS - 1) continue;        // MF tile holds 10 values per instance
                 float v = 0.f;
                 if (idx < CHF) v = fac[idx < CHF ? idx : 0];
                 else if (idx < CHF + 10) v = acc[idx - CHF < 10 ? (idx - CHF >= 0 ? idx - CHF : 0) : 0];
-                L.flush[lane * FLUSH_STRIDE + k] = v;
+                L.flush[lane * Lds::FS + k] = v;
             }
             __builtin_amdgcn_wave_barrier();
             const int idx = g * FLUSH_GROUP + fk;       // this lane's value index within the instance
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 const int inst = i0 + fsub;
                 if (!L.touched[inst]) continue;
                 const uint32_t gg = L.ids[inst];
-                const float v = L.flush[inst * FLUSH_STRIDE + fk];
+                const float v = fk < Lds::FS - 1 ? L.flush[inst * Lds::FS + fk] : 0.f;
                 if (idx < CHF) {
                     if (idx < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + idx, v);
                 } else if (idx < CHF + 10) {
