@@ -48,6 +48,26 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+// Exact-safe footprint test of one splat against a pixel-centre rectangle [x0, x1] x [y0, y1] (same
+// construction as tile_hit() in preprocess.hip, see there): the splat can reach alpha >= 1/255 at some
+// pixel of the rectangle only if the minimum of its quadratic form over the rectangle is below
+// 2 ln(255 opacity); a safety margin far above fp32 round-off keeps every borderline splat.
+__device__ __forceinline__ bool rect_hit(float mx, float my, float ca, float cb, float cc, float opacity, float x0,
+                                         float x1, float y0, float y1) {
+    const float s = 255.0f * opacity;
+    if (!(s > 1.0f)) return false;
+    const float thresh = 2.0f * (__logf(s) * 1.0001f + 2e-3f);
+    const float xlo = mx - x1, xhi = mx - x0, ylo = my - y1, yhi = my - y0;
+    if (xlo <= 0.0f && xhi >= 0.0f && ylo <= 0.0f && yhi >= 0.0f) return true;
+    const float ia = __builtin_amdgcn_rcpf(ca), ic = __builtin_amdgcn_rcpf(cc);
+    auto qf = [&](float dx, float dy) { return (ca * dx) * dx + 2.0f * ((cb * dx) * dy) + (cc * dy) * dy; };
+    float best = qf(xlo, fminf(yhi, fmaxf(ylo, -(cb * xlo) * ic)));
+    best = fminf(best, qf(xhi, fminf(yhi, fmaxf(ylo, -(cb * xhi) * ic))));
+    best = fminf(best, qf(fminf(xhi, fmaxf(xlo, -(cb * ylo) * ia)), ylo));
+    best = fminf(best, qf(fminf(xhi, fmaxf(xlo, -(cb * yhi) * ia)), yhi));
+    return !(best > thresh * 1.001f);   // NaN keeps the splat; extra 0.1 % for the approximate log / rcp
+}
+
 struct TileGeom {
     int tx, ty;        // tile coordinates
 };

@@ -207,35 +207,42 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
 // one v_permlane32_swap; B[k][n] = feature n of instance j+k, one ds_read_b32 per lane.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CH>
+template <int CH, int CHK>
 struct FwdChunkMF {
-    float4 geo[64];   // mean_x, mean_y, conic_a, conic_b
-    float2 co[64];    // conic_c, opacity
-    float4 cd[64];    // r, g, b, depth
-    uint32_t id[64 + 8];
-    static constexpr int FT = (64 * CH > 32 * 65) ? 64 * CH : 32 * 65;
+    float4 geo[CHK];   // mean_x, mean_y, conic_a, conic_b
+    float2 co[CHK];    // conic_c, opacity
+    float4 cd[CHK];    // r, g, b, depth
+    uint32_t id[CHK + 8];
+    uint32_t pos[CHK];   // 1-based list position of every (compacted) entry: n_contrib bookkeeping
+    static constexpr int FT = (CHK * CH > 32 * 65) ? CHK * CH : 32 * 65;
     float feat[FT];        // row-major [instance][channel]; reused as the epilogue transpose tile [channel][65]
 };
 
 // The next chunk's ids and splat records are prefetched into registers while the current chunk is blended.
 // (Fetching the B operand straight from global memory, prefetched two groups ahead, was measured slower
 // than staging the chunk's feature rows in LDS: 0.62 vs 0.57 ms at config c3.)
-template <int CH, int PPL>
+template <int CH, int PPL, int CHK, int GI>
 __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs a) {
     constexpr int NW = 4 / PPL;
     constexpr int NB = CH / 32;
-    constexpr int GI = 4;             // instances per straight-line group
     constexpr int NP = GI / 2;        // instance pairs (MFMA K = 2) per group
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    FwdChunkMF<CH>& ck = reinterpret_cast<FwdChunkMF<CH>*>(smem)[NW > 1 ? wave : 0];
+    FwdChunkMF<CH, CHK>& ck = reinterpret_cast<FwdChunkMF<CH, CHK>*>(smem)[NW > 1 ? wave : 0];
 
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 rg = a.ranges[tile];
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x), r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
 
+    // pixel-centre rectangle covered by this wave (PPL quadrants): used by the wave-level footprint test
+    float wx0, wx1, wy0, wy1;
+    {
+        const int q0 = wave * PPL, q1 = wave * PPL + PPL - 1;
+        wx0 = (float)(tx * TILE + (q0 & 1) * 8); wx1 = (float)(tx * TILE + (q1 & 1) * 8 + 7);
+        wy0 = (float)(ty * TILE + (q0 >> 1) * 8); wy1 = (float)(ty * TILE + (q1 >> 1) * 8 + 7);
+    }
     const int lx = lane & 7, ly = lane >> 3;
     float pxf[PPL], pyf[PPL];
     int pix_id[PPL];
@@ -264,27 +271,35 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
     // software pipeline, stage 0: ids + records of the first chunk
     uint32_t n_id = 0;
     float4 n_q0 = make_float4(0, 0, 0, 0), n_q1 = n_q0, n_q2 = n_q0;
-    if (r_lo + lane < r_hi) {
+    if (lane < CHK && r_lo + lane < r_hi) {
         n_id = a.point_list[r_lo + lane];
         const SplatRec* rp = a.rec + n_id;
         n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
     }
 
-    for (uint32_t base = r_lo; base < r_hi; base += 64) {
+    for (uint32_t base = r_lo; base < r_hi; base += CHK) {
         bool alld = true;
 #pragma unroll
         for (int p = 0; p < PPL; p++) alld = alld && done[p];
         if (__all(alld)) break;
-        const int cnt = (int)min(64u, r_hi - base);
+        const int cnt_in = (int)min((uint32_t)CHK, r_hi - base);
+        // wave-level culling: drop splats whose 1/255 footprint misses this wave's pixel block, compact the rest
+        const bool hit = lane < cnt_in && rect_hit(n_q0.x, n_q0.y, n_q0.z, n_q0.w, n_q1.x, n_q1.y, wx0, wx1, wy0, wy1);
+        const unsigned long long hmask = __ballot(hit);
+        const int cnt = __popcll(hmask);
+        const int slot = __popcll(hmask & ((1ull << lane) - 1ull));
         __builtin_amdgcn_wave_barrier();
-        ck.geo[lane] = n_q0;
-        ck.co[lane] = make_float2(n_q1.x, n_q1.y);
-        ck.cd[lane] = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
-        ck.id[lane] = n_id;
+        if (hit) {
+            ck.geo[slot] = n_q0;
+            ck.co[slot] = make_float2(n_q1.x, n_q1.y);
+            ck.cd[slot] = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
+            ck.id[slot] = n_id;
+            ck.pos[slot] = base - r_lo + lane + 1;
+        }
         __builtin_amdgcn_wave_barrier();
         // prefetch the next chunk (registers) while this one is blended
-        if (base + 64 + lane < r_hi) {
-            n_id = a.point_list[base + 64 + lane];
+        if (lane < CHK && base + CHK + lane < r_hi) {
+            n_id = a.point_list[base + CHK + lane];
             const SplatRec* rp = a.rec + n_id;
             n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
         }
@@ -314,6 +329,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
         for (int j = 0; j < ((a.ablate & 1) ? 0 : cnt); j += GI) {
             float4 g0[GI], cdv[GI];
             float2 g1[GI];
+            uint32_t pos_e[GI];
             bool live_e[GI];
 #pragma unroll
             for (int e = 0; e < GI; e++) {
@@ -322,6 +338,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
                 g0[e] = ck.geo[je];
                 g1[e] = ck.co[je];
                 cdv[e] = ck.cd[je];
+                pos_e[e] = ck.pos[je];
             }
             float araw[GI][PPL];
             bool valid[GI][PPL];
@@ -350,7 +367,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
                     w[e][p] = wv;
                     if (ok) {
                         T[p] = test_T;
-                        last[p] = base - r_lo + j + e + 1;
+                        last[p] = pos_e[e];
                     }
                     col[p][0] = fmaf(cdv[e].x, wv, col[p][0]);
                     col[p][1] = fmaf(cdv[e].y, wv, col[p][1]);
@@ -358,7 +375,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
                     dep[p] = fmaf(cdv[e].w, wv, dep[p]);
                     any_blend = any_blend || ok;
                 }
-            if (__any(any_blend)) {
+            if (__any(any_blend) && !(a.ablate & 8)) {
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
                     // B rows: instance j+2k for lanes 0-31, j+2k+1 for lanes 32-63 (a missing instance has w = 0 and
@@ -418,11 +435,19 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
     }
 }
 
+template <int CH, int PPL, int CHK, int GI>
+void launch_one_mf2(const FwdArgs& a, hipStream_t s) {
+    constexpr int NW = 4 / PPL;
+    const size_t lds = NW * sizeof(FwdChunkMF<CH, CHK>);
+    hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
+}
 template <int CH, int PPL>
 void launch_one_mf(const FwdArgs& a, hipStream_t s) {
-    constexpr int NW = 4 / PPL;
-    const size_t lds = NW * sizeof(FwdChunkMF<CH>);
-    hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
+    const int v = env_int("F3DGS_FWD_VARIANT", 0);   // tuning knob: chunk size / group size
+    if (v == 1) launch_one_mf2<CH, PPL, 64, 4>(a, s);
+    else if (v == 2) launch_one_mf2<CH, PPL, 32, 2>(a, s);
+    else if (v == 3) launch_one_mf2<CH, PPL, 64, 2>(a, s);
+    else launch_one_mf2<CH, PPL, 32, 4>(a, s);   // default: 32-instance chunks, 4-instance groups (measured best at c3)
 }
 
 template <int CH, int PPL>
