@@ -49,6 +49,7 @@ struct BwdArgs {
     int C, c0, nc;
     int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
     int part_major;  // workgroup -> (tile, part) order, see kernel
+    int no_wave_cull; // development: disable the wave-level footprint culling / compaction
     int ablate;      // development only (F3DGS_BWD_ABLATE): bit0 = skip the flush, bit1 = skip the pixel bodies
 };
 
@@ -204,21 +205,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     __builtin_amdgcn_wave_barrier();
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
-    // ---- chunks of 64 list positions, back to front: chunk covers [k0, k0 + 64) --------------------
-    for (int k0 = (int)((max_last + 63) / 64) * 64 - 64; k0 >= 0; k0 -= 64) {
-        // lane l holds list position k0 + 63 - l (lane 0 = farthest back)
-        SplatLane sl;
-        sl.pos = (uint32_t)(k0 + 63 - lane);
-        sl.have = sl.pos < max_last;
-        sl.mx = sl.my = sl.ca = sl.cb = sl.cc = sl.op = sl.cr = sl.cg = sl.cbl = sl.dep = 0.f;
-        uint32_t gid = 0;
-        if (sl.have) {
-            gid = a.point_list[r_lo + sl.pos];
-            const SplatRec* rp = a.rec + gid;
-            const float4 q0 = rp->q0, q1 = rp->q1, q2 = rp->q2;
-            sl.mx = q0.x; sl.my = q0.y; sl.ca = q0.z; sl.cb = q0.w; sl.cc = q1.x; sl.op = q1.y;
-            sl.cr = q1.z; sl.cg = q1.w; sl.cbl = q2.x; sl.dep = q2.y;
-        }
+    // ---- one (compacted) chunk of up to 64 splats against all live pixels of the wave ---------------------
+    auto process = [&](const SplatLane& sl, const uint32_t gid, const uint32_t pos_min) {
         float acc[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) acc[k] = 0.f;
@@ -238,7 +226,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         for (int it = 0; it < NV; it++) {
             // pixels still alive at this depth (lane = pixel for the ballot); two bodies per trip: ILP for the
             // scans, and the K = 2 of the MFMA
-            unsigned long long live = __ballot(v_last[it] > (uint32_t)k0);
+            unsigned long long live = __ballot(v_last[it] > pos_min);
             if (a.ablate & 2) { touched = sl.have; live = 0; }
             while (live) {
                 // take up to U live pixels; missing ones repeat the first with n_contrib = 0 (inert bodies)
@@ -343,7 +331,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         }
 
         // ---- flush this chunk: transpose through LDS in groups of 16 values, coalesced atomics -----------
-        if (!__any(touched) || (a.ablate & 1)) continue;
+        if (!__any(touched) || (a.ablate & 1)) return;
         L.ids[lane] = gid;
         L.touched[lane] = touched ? 1u : 0u;
         constexpr int CHF = MF ? 0 : CH;            // feature channels that travel through the LDS transpose
@@ -395,7 +383,56 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- walk the list back to front in windows of 64 positions; splats whose 1/255 footprint misses this
+    // wave's pixel block are dropped (rect_hit, exact-safe) and the survivors of consecutive windows are packed
+    // into full 64-lane chunks with ds_permute (lane 0 = farthest back stays true across windows) ----------------
+    const float wx0 = (float)px0, wx1 = (float)(px0 + PW - 1), wy0 = (float)py0, wy1 = (float)(py0 + NPIX / PW - 1);
+    SplatLane cur;
+    cur.mx = cur.my = cur.ca = cur.cb = cur.cc = cur.op = cur.cr = cur.cg = cur.cbl = cur.dep = 0.f;
+    cur.pos = 0; cur.have = false;
+    uint32_t cur_gid = 0;
+    int count = 0;
+    uint32_t cur_min = 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int k0 = (int)((max_last + 63) / 64) * 64 - 64; k0 >= 0; k0 -= 64) {
+        const uint32_t pos = (uint32_t)(k0 + 63 - lane);     // lane 0 = farthest back within the window
+        const bool have = pos < max_last;
+        float f[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        uint32_t gid = 0;
+        if (have) {
+            gid = a.point_list[r_lo + pos];
+            const SplatRec* rp = a.rec + gid;
+            const float4 q0 = rp->q0, q1 = rp->q1, q2 = rp->q2;
+            f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w; f[4] = q1.x; f[5] = q1.y;
+            f[6] = q1.z; f[7] = q1.w; f[8] = q2.x; f[9] = q2.y;
+        }
+        const bool hit = have && (a.no_wave_cull || rect_hit(f[0], f[1], f[2], f[3], f[4], f[5], wx0, wx1, wy0, wy1));
+        const unsigned long long hmask = __ballot(hit);
+        const int c2 = __popcll(hmask);
+        if (c2 == 0) continue;
+        if (count + c2 > 64) {
+            process(cur, cur_gid, cur_min);
+            count = 0;
+        }
+        // push the survivors to lanes count .. count + c2 - 1; the others aim at a lane whose result is unused
+        const int dest = hit ? count + __popcll(hmask & lt_mask) : (count > 0 ? 0 : c2 & 63);
+        const bool recv = lane >= count && lane < count + c2;
+        auto push = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(v))); };
+        const float m0 = push(f[0]), m1 = push(f[1]), m2 = push(f[2]), m3 = push(f[3]), m4 = push(f[4]);
+        const float m5 = push(f[5]), m6 = push(f[6]), m7 = push(f[7]), m8 = push(f[8]), m9 = push(f[9]);
+        const uint32_t mp = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)pos);
+        const uint32_t mg = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)gid);
+        if (recv) {
+            cur.mx = m0; cur.my = m1; cur.ca = m2; cur.cb = m3; cur.cc = m4; cur.op = m5;
+            cur.cr = m6; cur.cg = m7; cur.cbl = m8; cur.dep = m9; cur.pos = mp; cur_gid = mg;
+        }
+        count += c2;
+        cur.have = lane < count;
+        cur_min = (uint32_t)k0;      // every survivor of this window sits at a position >= k0
     }
+    if (count > 0) process(cur, cur_gid, cur_min);
 }
 
 int env_int(const char* name, int dflt) {
@@ -437,6 +474,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     const int npix = env_int("F3DGS_BWD_NPIX", 64);
     a.ablate = env_int("F3DGS_BWD_ABLATE", 0);
     a.part_major = env_int("F3DGS_BWD_PART_MAJOR", 0);
+    a.no_wave_cull = env_int("F3DGS_BWD_NO_WAVE_CULL", 0);
     const bool mf = env_int("F3DGS_FEATURE_MFMA", 1) != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
