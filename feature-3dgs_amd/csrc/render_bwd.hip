@@ -49,6 +49,7 @@ struct BwdArgs {
     int C, c0, nc;
     int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
     int part_major;  // workgroup -> (tile, part) order, see kernel
+    int strip;        // NPIX = 64: 16x4 pixel strips instead of 8x8 quadrants
     int no_wave_cull; // development: disable the wave-level footprint culling / compaction
     int ablate;      // development only (F3DGS_BWD_ABLATE): bit0 = skip the flush, bit1 = skip the pixel bodies
 };
@@ -151,11 +152,13 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     const uint2 rg = a.ranges[tile];
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
     const size_t HW = (size_t)a.W * a.H;
-    // pixel block of this wave: NPIX >= 128 -> ROWS full rows; 64 -> one 8x8 quadrant; 32 -> half a quadrant (8x4)
+    // pixel block of this wave: NPIX >= 128 -> ROWS full rows; 64 -> one 8x8 quadrant (or a 16x4 strip when
+    // a.strip is set); 32 -> half a quadrant (8x4)
     const int qd = NPIX == 32 ? part >> 1 : part;
-    const int px0 = tx * TILE + (NPIX <= 64 ? (qd & 1) * 8 : 0);
-    const int py0 = ty * TILE + (NPIX <= 64 ? (qd >> 1) * 8 + (NPIX == 32 ? (part & 1) * 4 : 0) : part * ROWS);
-    constexpr int PW = NPIX <= 64 ? 8 : 16;    // pixels per row of this wave's block
+    const bool strip = NPIX == 64 && a.strip;
+    const int px0 = tx * TILE + ((NPIX <= 64 && !strip) ? (qd & 1) * 8 : 0);
+    const int py0 = ty * TILE + (strip ? part * 4 : (NPIX <= 64 ? (qd >> 1) * 8 + (NPIX == 32 ? (part & 1) * 4 : 0) : part * ROWS));
+    const int PW = (NPIX <= 64 && !strip) ? 8 : 16;    // pixels per row of this wave's block
 
     // ---- stage the per-pixel data into LDS (lane = pixel here) -----------------------------------------
     uint32_t v_last[NV];
@@ -475,6 +478,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     a.ablate = env_int("F3DGS_BWD_ABLATE", 0);
     a.part_major = env_int("F3DGS_BWD_PART_MAJOR", 0);
     a.no_wave_cull = env_int("F3DGS_BWD_NO_WAVE_CULL", 0);
+    a.strip = env_int("F3DGS_BWD_STRIP", 0);
     const bool mf = env_int("F3DGS_FEATURE_MFMA", 1) != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
