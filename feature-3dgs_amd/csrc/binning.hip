@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t* __restrict
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-template <int BITS>
+template <int BITS, bool REORDER>
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
@@ -162,6 +162,12 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     constexpr int BPT = BINS / SORT_THREADS;   // bins per thread in the offset phase
     __shared__ uint32_t cnt[4][BINS];
     __shared__ uint32_t sh[8];
+    // REORDER: the chunk is first sorted inside LDS so that the global stores of a wave run over consecutive
+    // addresses per digit (16 items per digit on average) instead of 64 unrelated 4-byte scatters.
+    __shared__ uint32_t gbase[REORDER ? BINS : 1];     // global offset of this workgroup's run of digit d
+    __shared__ uint32_t lstart[REORDER ? BINS : 1];    // start of digit d inside the LDS-sorted chunk
+    __shared__ uint32_t skey[REORDER ? SORT_CHUNK : 1];
+    __shared__ uint32_t sval[REORDER ? SORT_CHUNK : 1];
     volatile uint32_t* vcnt = &cnt[0][0];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int d = threadIdx.x; d < 4 * BINS; d += SORT_THREADS) (&cnt[0][0])[d] = 0;
@@ -190,16 +196,25 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
         rank[k] = old + before;
     }
     __syncthreads();
-    // thread t owns digits [t*BPT, (t+1)*BPT): turn per-wave counts into absolute output offsets
+    // thread t owns digits [t*BPT, (t+1)*BPT): turn per-wave counts into offsets
     {
-        uint32_t tot[BPT], run = 0;
-#pragma unroll
-        for (int q = 0; q < BPT; q++) { tot[q] = totals[threadIdx.x * BPT + q]; run += tot[q]; }
-        uint32_t digit_base = block_excl_scan_256(run, sh, nullptr);
+        uint32_t tot[BPT], run = 0, blk[BPT], brun = 0;
 #pragma unroll
         for (int q = 0; q < BPT; q++) {
             const uint32_t d = threadIdx.x * BPT + q;
-            uint32_t r2 = digit_base + hist[(size_t)d * nb + blockIdx.x];
+            tot[q] = totals[d];
+            run += tot[q];
+            blk[q] = cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
+            brun += blk[q];
+        }
+        uint32_t digit_base = block_excl_scan_256(run, sh, nullptr);
+        uint32_t local_base = REORDER ? block_excl_scan_256(brun, sh, nullptr) : 0;
+#pragma unroll
+        for (int q = 0; q < BPT; q++) {
+            const uint32_t d = threadIdx.x * BPT + q;
+            const uint32_t g = digit_base + hist[(size_t)d * nb + blockIdx.x];
+            if (REORDER) { gbase[d] = g; lstart[d] = local_base; }
+            uint32_t r2 = REORDER ? local_base : g;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t c = cnt[k][d];
@@ -207,17 +222,45 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
                 r2 += c;
             }
             digit_base += tot[q];
+            local_base += blk[q];
         }
     }
     __syncthreads();
+    if (REORDER) {
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
-        const size_t i = wbase + (size_t)k * 64 + lane;
-        if (i < n) {
-            const uint32_t d = (key[k] >> shift) & (BINS - 1);
-            const uint32_t pos = cnt[w][d] + rank[k];
-            keys_out[pos] = key[k];
-            vals_out[pos] = vals_in ? vals_in[i] : (uint32_t)i;
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const size_t i = wbase + (size_t)k * 64 + lane;
+            if (i < n) {
+                const uint32_t d = (key[k] >> shift) & (BINS - 1);
+                const uint32_t lp = cnt[w][d] + rank[k];
+                skey[lp] = key[k];
+                sval[lp] = vals_in ? vals_in[i] : (uint32_t)i;
+            }
+        }
+        __syncthreads();
+        const size_t cbase = (size_t)blockIdx.x * SORT_CHUNK;
+        const uint32_t have = (uint32_t)min((size_t)SORT_CHUNK, n - cbase);
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const uint32_t j = (uint32_t)k * SORT_THREADS + threadIdx.x;
+            if (j < have) {
+                const uint32_t kk = skey[j];
+                const uint32_t d = (kk >> shift) & (BINS - 1);
+                const uint32_t pos = gbase[d] + (j - lstart[d]);
+                keys_out[pos] = kk;
+                vals_out[pos] = sval[j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const size_t i = wbase + (size_t)k * 64 + lane;
+            if (i < n) {
+                const uint32_t d = (key[k] >> shift) & (BINS - 1);
+                const uint32_t pos = cnt[w][d] + rank[k];
+                keys_out[pos] = key[k];
+                vals_out[pos] = vals_in ? vals_in[i] : (uint32_t)i;
+            }
         }
     }
 }
@@ -262,8 +305,8 @@ static void radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uin
     uint32_t* totals = hist + (size_t)BINS * nb;
     hipLaunchKernelGGL((radix_hist_kernel<BITS>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, n, shift, nb, hist);
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(BINS), dim3(256), 0, s, hist, nb, totals);
-    hipLaunchKernelGGL((radix_scatter_kernel<BITS>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko, vo, n, shift, nb,
-                       hist, totals);
+    hipLaunchKernelGGL((radix_scatter_kernel<BITS, (BITS <= 8)>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko, vo, n,
+                       shift, nb, hist, totals);
 }
 
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
