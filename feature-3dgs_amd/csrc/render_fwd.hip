@@ -340,30 +340,37 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
                 cdv[e] = ck.cd[je];
                 pos_e[e] = ck.pos[je];
             }
-            float araw[GI][PPL];
-            bool valid[GI][PPL];
+            // a quadrant whose 64 pixels are all saturated is skipped as a whole (wave-uniform branch)
+            bool slot_live[PPL];
 #pragma unroll
-            for (int e = 0; e < GI; e++)
-#pragma unroll
-                for (int p = 0; p < PPL; p++) {
-                    const float dx = g0[e].x - pxf[p], dy = g0[e].y - pyf[p];
-                    const float power = splat_power(dx, dy, g0[e].z, g0[e].w, g1[e].x);
-                    araw[e][p] = fminf(ALPHA_MAX, g1[e].y * __expf(power));
-                    valid[e][p] = live_e[e] && !(power > 0.0f) && !(araw[e][p] < ALPHA_MIN);
-                }
+            for (int p = 0; p < PPL; p++) slot_live[p] = !__all(done[p]);
             float w[GI][PPL];
             bool any_blend = false;
 #pragma unroll
-            for (int e = 0; e < GI; e++)
+            for (int p = 0; p < PPL; p++) {
+                if (!slot_live[p]) {
 #pragma unroll
-                for (int p = 0; p < PPL; p++) {
-                    bool ok = valid[e][p] && !done[p];
-                    const float test_T = T[p] * (1.0f - araw[e][p]);
+                    for (int e = 0; e < GI; e++) w[e][p] = 0.0f;
+                    continue;
+                }
+                float araw[GI];
+                bool valid[GI];
+#pragma unroll
+                for (int e = 0; e < GI; e++) {
+                    const float dx = g0[e].x - pxf[p], dy = g0[e].y - pyf[p];
+                    const float power = splat_power(dx, dy, g0[e].z, g0[e].w, g1[e].x);
+                    araw[e] = fminf(ALPHA_MAX, g1[e].y * __expf(power));
+                    valid[e] = live_e[e] && !(power > 0.0f) && !(araw[e] < ALPHA_MIN);
+                }
+#pragma unroll
+                for (int e = 0; e < GI; e++) {
+                    bool ok = valid[e] && !done[p];
+                    const float test_T = T[p] * (1.0f - araw[e]);
                     if (ok && test_T < T_MIN) {
                         done[p] = true;
                         ok = false;
                     }
-                    const float wv = ok ? araw[e][p] * T[p] : 0.0f;
+                    const float wv = ok ? araw[e] * T[p] : 0.0f;
                     w[e][p] = wv;
                     if (ok) {
                         T[p] = test_T;
@@ -375,6 +382,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
                     dep[p] = fmaf(cdv[e].w, wv, dep[p]);
                     any_blend = any_blend || ok;
                 }
+            }
             if (__any(any_blend) && !(a.ablate & 8)) {
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
