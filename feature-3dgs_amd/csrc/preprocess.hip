@@ -67,10 +67,8 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 //   q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 opacity)      (d = mean - pixel centre).
 // The reference emits one instance for EVERY tile of the 3-sigma bounding rectangle
 // (rasterizer_impl.cu:98-109); about half of those can never pass the test above for any pixel of the
-// tile.  tile_hit() minimises q over the tile's pixel-centre rectangle exactly (q is convex: the minimum
-// is 0 if the mean lies inside, otherwise it sits on one of the four edges at the clamped 1-D minimiser)
-// and keeps the tile unless the minimum exceeds the threshold by a safety margin that is orders of
-// magnitude above the round-off of the blend kernels' own power / expf evaluation.  Dropped instances
+// tile.  A tile is kept unless the ellipse {q <= threshold} misses its pixel-centre rectangle by a safety margin that is orders of
+// magnitude above the round-off of the blend kernels' own power / expf evaluation (row_span() below).  Dropped instances
 // would have been skipped for every pixel, so images, gradients and radii are unchanged; only the private
 // instance lists get shorter.  The count and the emission run the same code in this translation unit
 // (no contraction), so they always agree.
@@ -87,30 +85,34 @@ __device__ __forceinline__ CullParams make_cull(float mx, float my, float ca, fl
 __device__ __forceinline__ float quad_form(const CullParams& k, float dx, float dy) {
     return (k.a * dx) * dx + 2.0f * ((k.b * dx) * dy) + (k.c * dy) * dy;
 }
-__device__ __forceinline__ bool tile_hit(const CullParams& k, int tx, int ty) {
+// The test is evaluated per tile ROW: the tiles of tile-row `ty` that the ellipse {q <= thresh} can touch form ONE
+// contiguous span, because (ellipse ∩ horizontal band) is convex: a tile intersects the ellipse iff its x-range
+// intersects the x-projection of (ellipse ∩ band).  The projection's right end is the concave function
+// dx_r(dy) = (-b dy + sqrt(thresh a - det dy^2)) / a maximised over the band (at the ellipse's extreme point if
+// that lies in the band, else at the nearer band edge); the left end symmetrically.  One pair of square roots
+// per tile ROW instead of four quadratic-form evaluations per TILE.  The interval is widened by a small margin,
+// so the span is a superset of the exact tile set (never drops a blending tile); count and emission share it.
+__device__ __forceinline__ bool row_span(const CullParams& k, float det_inv, int ty, int x0, int x1, int& xa, int& xb) {
     if (k.thresh < 0.0f) return false;
-    const float xlo = k.mx - (float)(tx * TILE + TILE - 1), xhi = k.mx - (float)(tx * TILE);
-    const float ylo = k.my - (float)(ty * TILE + TILE - 1), yhi = k.my - (float)(ty * TILE);
-    if (xlo <= 0.0f && xhi >= 0.0f && ylo <= 0.0f && yhi >= 0.0f) return true;
-    const float ia = 1.0f / k.a, ic = 1.0f / k.c;
-    float best;
-    {
-        const float dy = fminf(yhi, fmaxf(ylo, -(k.b * xlo) * ic));
-        best = quad_form(k, xlo, dy);
-    }
-    {
-        const float dy = fminf(yhi, fmaxf(ylo, -(k.b * xhi) * ic));
-        best = fminf(best, quad_form(k, xhi, dy));
-    }
-    {
-        const float dx = fminf(xhi, fmaxf(xlo, -(k.b * ylo) * ia));
-        best = fminf(best, quad_form(k, dx, ylo));
-    }
-    {
-        const float dx = fminf(xhi, fmaxf(xlo, -(k.b * yhi) * ia));
-        best = fminf(best, quad_form(k, dx, yhi));
-    }
-    return !(best > k.thresh);   // NaN keeps the tile
+    const float ylo = k.my - (float)(ty * TILE + TILE - 1), yhi = k.my - (float)(ty * TILE);   // dy = mean - pixel
+    const float ymax = sqrtf(fmaxf(0.0f, k.thresh * k.a * det_inv));
+    const float lo = fmaxf(ylo, -ymax), hi = fminf(yhi, ymax);
+    if (lo > hi + 1e-3f) return false;
+    const float X = sqrtf(fmaxf(0.0f, k.thresh * k.c * det_inv));      // half-width of the whole ellipse
+    const float ic = 1.0f / k.c, ia = 1.0f / k.a;
+    const float det = 1.0f / det_inv;
+    auto root = [&](float dy) { return sqrtf(fmaxf(0.0f, k.thresh * k.a - det * dy * dy)); };
+    // right end: maximiser dy_r = -(b/c) X ; left end: minimiser dy_l = +(b/c) X
+    const float dyr = fminf(hi, fmaxf(lo, -(k.b * ic) * X));
+    const float dyl = fminf(hi, fmaxf(lo, (k.b * ic) * X));
+    const float dxr = (-(k.b * dyr) + root(dyr)) * ia;
+    const float dxl = (-(k.b * dyl) - root(dyl)) * ia;
+    // pixel x = mean_x - dx  in  [mx - dxr, mx - dxl]; widen by a margin (relative + absolute)
+    const float m = 2e-3f + 1e-4f * (fabsf(dxr) + fabsf(dxl));
+    const float pxl = k.mx - dxr - m, pxr = k.mx - dxl + m;
+    xa = max(x0, (int)ceilf((pxl - (float)(TILE - 1)) * (1.0f / TILE)));
+    xb = min(x1 - 1, (int)floorf(pxr * (1.0f / TILE)));
+    return xb >= xa;
 }
 
 __device__ __forceinline__ M3 quat_to_rot(float4 q) {
@@ -284,8 +286,11 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         bbox_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
         if (cull) {
             const CullParams ck = make_cull(px, py, ca, cb, cc, opacities[i]);
-            for (int ty = y0; ty < y1; ty++)
-                for (int tx = x0; tx < x1; tx++) out_tiles += tile_hit(ck, tx, ty) ? 1u : 0u;
+            const float cdet_inv = 1.0f / (ca * cc - cb * cb);
+            for (int ty = y0; ty < y1; ty++) {
+                int xa, xb;
+                if (row_span(ck, cdet_inv, ty, x0, x1, xa, xb)) out_tiles += (uint32_t)(xb - xa + 1);
+            }
         } else {
             out_tiles = bbox_tiles;
         }
@@ -324,13 +329,16 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
     int x0, y0, x1, y1;
     tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
     const CullParams ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            if (cull && !tile_hit(ck, x, y)) continue;
+    const float cdet_inv = 1.0f / (q0.z * q1.x - q0.w * q0.w);
+    for (int y = y0; y < y1; y++) {
+        int xa = x0, xb = x1 - 1;
+        if (cull && !row_span(ck, cdet_inv, y, x0, x1, xa, xb)) continue;
+        for (int x = xa; x <= xb; x++) {
             inst_tile[off] = (uint32_t)(y * gx + x);
             inst_id[off] = g;
             off++;
         }
+    }
 }
 
 // ---- backward: K8 (cov2D) + K9 (mean / SH / cov3D) fused, one thread per Gaussian ---------------------

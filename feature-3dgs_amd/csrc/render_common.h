@@ -48,10 +48,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// Exact-safe footprint test of one splat against a pixel-centre rectangle [x0, x1] x [y0, y1] (same
-// construction as tile_hit() in preprocess.hip, see there): the splat can reach alpha >= 1/255 at some
-// pixel of the rectangle only if the minimum of its quadratic form over the rectangle is below
-// 2 ln(255 opacity); a safety margin far above fp32 round-off keeps every borderline splat.
+// Exact-safe footprint test of one splat against a pixel-centre rectangle [x0, x1] x [y0, y1]: the splat can
+// reach alpha >= 1/255 at some pixel of the rectangle only if the minimum of its (convex) quadratic form over
+// the rectangle - 0 if the mean lies inside, otherwise attained on one of the four edges at the clamped 1-D
+// minimiser - is below 2 ln(255 opacity); a safety margin far above fp32 round-off keeps every borderline splat.
 __device__ __forceinline__ bool rect_hit(float mx, float my, float ca, float cb, float cc, float opacity, float x0,
                                          float x1, float y0, float y1) {
     const float s = 255.0f * opacity;
