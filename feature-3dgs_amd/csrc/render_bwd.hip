@@ -399,11 +399,14 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     int count = 0;
     uint32_t cur_min = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int k0 = (int)((max_last + 63) / 64) * 64 - 64; k0 >= 0; k0 -= 64) {
-        const uint32_t pos = (uint32_t)(k0 + 63 - lane);     // lane 0 = farthest back within the window
-        const bool have = pos < max_last;
-        float f[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        uint32_t gid = 0;
+    // software pipeline: the ids + records of window k0 - 64 are requested before window k0 is tested,
+    // compacted and (possibly) processed, so the two dependent gathers never sit on the critical path
+    auto load_window = [&](int k0w, float (&f)[10], uint32_t& gid, bool& have) {
+        const uint32_t pos = (uint32_t)(k0w + 63 - lane);
+        have = k0w >= 0 && pos < max_last;
+#pragma unroll
+        for (int k = 0; k < 10; k++) f[k] = 0.f;
+        gid = 0;
         if (have) {
             gid = a.point_list[r_lo + pos];
             const SplatRec* rp = a.rec + gid;
@@ -411,6 +414,20 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
             f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w; f[4] = q1.x; f[5] = q1.y;
             f[6] = q1.z; f[7] = q1.w; f[8] = q2.x; f[9] = q2.y;
         }
+    };
+    float nf[10];
+    uint32_t ngid;
+    bool nhave;
+    const int k_top = (int)((max_last + 63) / 64) * 64 - 64;
+    load_window(k_top, nf, ngid, nhave);
+    for (int k0 = k_top; k0 >= 0; k0 -= 64) {
+        const uint32_t pos = (uint32_t)(k0 + 63 - lane);     // lane 0 = farthest back within the window
+        float f[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) f[k] = nf[k];
+        const uint32_t gid = ngid;
+        const bool have = nhave;
+        load_window(k0 - 64, nf, ngid, nhave);
         const bool hit = have && (a.no_wave_cull || rect_hit(f[0], f[1], f[2], f[3], f[4], f[5], wx0, wx1, wy0, wy1));
         const unsigned long long hmask = __ballot(hit);
         const int c2 = __popcll(hmask);
