@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 for (int u = 0; u < U; u++) {
                     pa[u] = L.pa[qi[u]];
                     pb[u] = L.pb[qi[u]];
-                    lastq[u] = act[u] ? L.plast[qi[u]] : 0u;
+                    lastq[u] = L.plast[qi[u]];   // unconditional: keeps all broadcasts of the body in flight together
                 }
                 float dx[U], dy[U], G[U], al[U], f[U], q[U], D[U], P[U], Tb[U], w[U], Sinc[U];
                 bool ok[U];
@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     const float power = splat_power(dx[u], dy[u], sl.ca, sl.cb, sl.cc);
                     G[u] = __expf(power);
                     const float alpha = fminf(ALPHA_MAX, sl.op * G[u]);
-                    ok[u] = sl.have && sl.pos < lastq[u] && !(power > 0.0f) && !(alpha < ALPHA_MIN);
+                    // bitwise, not short-circuit: nothing here may turn into a branch that waits on one broadcast alone
+                    ok[u] = (int)sl.have & (int)act[u] & (int)(sl.pos < lastq[u]) & (int)!(power > 0.0f) & (int)!(alpha < ALPHA_MIN);
                     al[u] = ok[u] ? alpha : 0.f;
                     f[u] = __builtin_amdgcn_rcpf(1.f - al[u]);   // 1/(1-alpha); exactly 1 for skipped lanes
                     P[u] = f[u];

@@ -23,6 +23,16 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float s) {
             if (KIND == 8) asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[c]));   // fused dpp mul (with its own 2 wait states)
             if (KIND == 9) v[c] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[c]), i & 63));   // v_readlane (SGPR lane) + add
             if (KIND == 10) v[c] = (threadIdx.x & 63) == (i & 63) ? s : v[c];   // cmp_eq + cndmask (state write-back pattern)
+            if (KIND == 12 && (c & 1) == 0) {   // v_pk_fma_f32 on register pairs (counts as ONE instruction per pair)
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 x = {v[c], v[c + 1]}; const f2 ss = {s, s}; const f2 h = {0.5f, 0.25f};
+                x = __builtin_elementwise_fma(x, ss, h); v[c] = x.x; v[c + 1] = x.y;
+            }
+            if (KIND == 13 && (c & 1) == 0) {   // v_pk_mul_f32
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 x = {v[c], v[c + 1]}; const f2 ss = {s, s * 1.0001f};
+                x = x * ss; v[c] = x.x; v[c + 1] = x.y;
+            }
             if (KIND == 11) { auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v[c]), __float_as_int(v[(c + 1) % CHAINS]), false, false); v[c] = __int_as_float(r[0]) + 1.0f; }
         }
     }
@@ -58,5 +68,7 @@ int main() {
     run<1, 8>("mul", d, 4096); run<2, 8>("exp2", d, 4096); run<3, 8>("rcp", d, 4096);
     run<4, 8>("add_dpp", d, 4096); run<5, 8>("cmp+sel", d, 4096); run<6, 8>("add+min", d, 4096);
     run<7, 8>("movdpp+mul", d, 4096); run<8, 8>("asm mul_dpp", d, 4096); run<8, 2>("asm mul_dpp", d, 4096); run<9, 8>("readlane+add", d, 4096); run<10, 8>("cmpeq+cnd", d, 4096); run<11, 8>("permswap+add", d, 4096);
+    run<12, 8>("pk_fma (x2 work per inst; cycles per PAIR-inst = 2x shown)", d, 4096); run<13, 8>("pk_mul (same)", d, 4096);
+    run<12, 16>("pk_fma 16", d, 4096);
     return 0;
 }
