@@ -112,16 +112,18 @@ constexpr int FLUSH_STRIDE = FLUSH_GROUP + 1; // odd: conflict-free lane-major w
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int CH, int NPIX, bool MF>
 struct BwdLds {
-    static constexpr int GS = CH + 1;   // row stride (floats) of the MF image
+    // Row stride (floats) of the MF image: unpadded.  The operand reads of the matrix pipe take one aligned
+    // 32-float row per half-wave (conflict-free); only the one-off staging writes conflict.  Together with
+    // the ids riding in the padding column of the flush tile and `touched` as a ballot this makes the NPIX = 64, CH = 32 image 13312 B, i.e. 12
+    // waves (3 per SIMD) per CU instead of 11.
+    static constexpr int GS = CH;
     float4 pa[NPIX];
     float4 pb[NPIX];
     uint32_t plast[NPIX];
     float4 gf[MF ? 1 : (CH > 0 ? CH / 4 : 1)][MF ? 1 : NPIX];
-    float gfm[MF ? NPIX * GS : 1];
+    float gfm[MF ? NPIX * GS : 4];
     static constexpr int FS = MF ? 11 : FLUSH_STRIDE;   // MF: only the 10 geometric sums travel through LDS
     float flush[64 * FS];
-    uint32_t ids[64];
-    uint32_t touched[64];
 };
 
 struct SplatLane { // one chunk entry per lane
@@ -250,6 +252,17 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     pb[u] = L.pb[qi[u]];
                     lastq[u] = L.plast[qi[u]];   // unconditional: keeps all broadcasts of the body in flight together
                 }
+                float Bv[MF ? U / 2 : 1][NB > 0 ? NB : 1];
+                if constexpr (MF) {
+                    // B[k][j] = dO[pixel k][channel j] of the matrix-pipe contraction below; requested here so that the
+                    // LDS latency is covered by the alpha evaluation
+#pragma unroll
+                    for (int u = 0; u < U; u += 2) {
+                        const int prow = (lane < 32 ? qi[u] : qi[u + 1]) * Lds::GS + (lane & 31);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) Bv[u / 2][nb] = L.gfm[prow + 32 * nb];
+                    }
+                }
                 float dx[U], dy[U], G[U], al[U], f[U], q[U], D[U], P[U], Tb[U], w[U], Sinc[U];
                 bool ok[U];
 #pragma unroll
@@ -286,8 +299,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const float Sbehind = pa[u].w + (Sinc[u] - D[u]);
-                    float dL_dalpha = fmaf(Tb[u], q[u], -(Sbehind * f[u]));
-                    dL_dalpha = ok[u] ? dL_dalpha : 0.f;
+                    // finite on skipped lanes too (f = 1 there), and every use below is multiplied by Gs = 0 or w = 0
+                    const float dL_dalpha = fmaf(Tb[u], q[u], -(Sbehind * f[u]));
                     const float dL_dG = sl.op * dL_dalpha;
                     const float Gs = ok[u] ? G[u] : 0.f;      // exp(power) may be inf where power > 0
                     const float gdx = Gs * dx[u], gdy = Gs * dy[u];
@@ -322,12 +335,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     for (int u = 0; u < U; u += 2) {
                         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[u]), __float_as_int(w[u + 1]), false, false);
                         const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
-                        const int prow = (lane < 32 ? qi[u] : qi[u + 1]) * Lds::GS + (lane & 31);   // B[k][j] = dO[pixel k][channel j]
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) {
-                            const float Bv = L.gfm[prow + 32 * nb];
-                            macc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv, macc[nb][0], 0, 0, 0);
-                            macc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv, macc[nb][1], 0, 0, 0);
+                            macc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv[u / 2][nb], macc[nb][0], 0, 0, 0);
+                            macc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv[u / 2][nb], macc[nb][1], 0, 0, 0);
                         }
                     }
                 }
@@ -335,9 +346,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         }
 
         // ---- flush this chunk: transpose through LDS in groups of 16 values, coalesced atomics -----------
-        if (!__any(touched) || (a.ablate & 1)) return;
-        L.ids[lane] = gid;
-        L.touched[lane] = touched ? 1u : 0u;
+        const unsigned long long tmask = __ballot(touched);
+        if (tmask == 0 || (a.ablate & 1)) return;
+        L.flush[lane * Lds::FS + Lds::FS - 1] = __uint_as_float(gid);   // the stride's padding column carries the ids
         constexpr int CHF = MF ? 0 : CH;            // feature channels that travel through the LDS transpose
         constexpr int NG = (CHF + 10 + FLUSH_GROUP - 1) / FLUSH_GROUP;
         const int fsub = lane >> 4, fk = lane & 15;   // 4 instances per atomic instruction, 16 values each
@@ -358,8 +369,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
 #pragma unroll 4
             for (int i0 = 0; i0 < 64; i0 += 4) {
                 const int inst = i0 + fsub;
-                if (!L.touched[inst]) continue;
-                const uint32_t gg = L.ids[inst];
+                // scalar shift by the compile-time part, per-lane shift by the small remainder (a 64-bit per-lane
+                // mask per instance would be hoisted out of the chunk loop and cost two registers apiece)
+                if (!(((uint32_t)(tmask >> i0) >> fsub) & 1u)) continue;
+                const uint32_t gg = __float_as_uint(L.flush[inst * Lds::FS + Lds::FS - 1]);
                 const float v = fk < Lds::FS - 1 ? L.flush[inst * Lds::FS + fk] : 0.f;
                 if (idx < CHF) {
                     if (idx < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + idx, v);
@@ -377,8 +390,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int inst = 32 * hh + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (!L.touched[inst]) continue;
-                    const uint32_t gg = L.ids[inst];
+                    if (!(((uint32_t)(tmask >> (32 * hh + (r & 3) + 8 * (r >> 2))) >> (4 * (lane >> 5))) & 1u)) continue;
+                    const uint32_t gg = __float_as_uint(L.flush[inst * Lds::FS + Lds::FS - 1]);
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
                         const int ch = 32 * nb + (lane & 31);
