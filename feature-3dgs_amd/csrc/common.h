@@ -67,7 +67,7 @@ struct GeomState {
     uint32_t* offsets;        // P   exclusive scan of tiles_touched in depth order
     uint32_t* hist;           // RADIX_BINS * sort_blocks(P) + RADIX_BINS
     uint32_t* scan_tmp;       // scan_blocks(P) + 8
-    uint32_t* ref_partial;    // one bounding-rectangle tile count per preprocess workgroup ((P+255)/256)
+    uint32_t* ref_partial;    // per preprocess workgroup: bounding-rectangle tile counts, then list-entry counts
     uint32_t* counters;       // 16 words: [0] = instances in the (culled) lists, [1] = reference num_rendered
     static GeomState carve(char* base, size_t P, size_t* bytes) {
         Carver c(base);
@@ -83,7 +83,7 @@ struct GeomState {
         g.offsets = c.take<uint32_t>(P);
         g.hist = c.take<uint32_t>(DEPTH_RADIX_BINS * sort_blocks(P) + DEPTH_RADIX_BINS);
         g.scan_tmp = c.take<uint32_t>(scan_blocks(P) + 8);
-        g.ref_partial = c.take<uint32_t>((P + 255) / 256 + 1);
+        g.ref_partial = c.take<uint32_t>(2 * ((P + 255) / 256) + 2);
         g.counters = c.take<uint32_t>(16);
         if (bytes) *bytes = c.total();
         return g;

@@ -305,13 +305,40 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     // the reference's num_rendered = sum of bounding-rectangle tile counts (rasterizer_impl.cu:279-283)
     // Same-address atomics serialise at ~12 ns each on MI355X, so every workgroup writes ONE partial sum and
     // the scan's spine kernel adds the partials up.
-    __shared__ uint32_t wsum[4];
-    uint32_t v = bbox_tiles;
+    // The same goes for the length of our own (culled) instance lists: both totals are known right after this
+    // kernel, long before the host needs them (api.hip reads them back while the depth sort runs).
+    __shared__ uint32_t wsum[2][4];
+    uint32_t v = bbox_tiles, u = out_tiles;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    for (int d = 32; d >= 1; d >>= 1) {
+        v += (uint32_t)__shfl_xor((int)v, d, 64);
+        u += (uint32_t)__shfl_xor((int)u, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = v; wsum[1][threadIdx.x >> 6] = u; }
     __syncthreads();
-    if (threadIdx.x == 0) ref_partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        ref_partial[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+        ref_partial[gridDim.x + blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    }
+}
+
+// counters[0] = instances in our lists, counters[1] = the reference's bounding-rectangle count
+__global__ void __launch_bounds__(256) count_totals_kernel(const uint32_t* __restrict__ partial, int nb,
+                                                           uint32_t* __restrict__ counters) {
+    __shared__ uint32_t sh[2][4];
+    uint32_t v = 0, u = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) { v += partial[i]; u += partial[nb + i]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        v += (uint32_t)__shfl_xor((int)v, d, 64);
+        u += (uint32_t)__shfl_xor((int)u, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = v; sh[1][threadIdx.x >> 6] = u; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[1] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        counters[0] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
 }
 
 // Emit (tile, id) instances in depth order (same tile test as the count above).
@@ -608,6 +635,7 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
     hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales, rotations,
                        opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped, g.tiles_touched,
                        g.depth_key, cull, g.ref_partial);
+    hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(256), 0, s, g.ref_partial, (P + 255) / 256, g.counters);
 }
 
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
