@@ -207,13 +207,19 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
 // one v_permlane32_swap; B[k][n] = feature n of instance j+k, one ds_read_b32 per lane.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// One staged (compacted) list entry: a single LDS address per instance, three broadcast reads.
+struct FwdEntry {
+    float4 geo;        // mean_x, mean_y, conic_a, conic_b
+    float4 cd;         // r, g, b, depth
+    float co_c, co_o;  // conic_c, opacity
+    uint32_t pos;      // 1-based list position: n_contrib bookkeeping
+    uint32_t id;       // Gaussian index (feature row)
+};
+static_assert(sizeof(FwdEntry) == 48, "FwdEntry layout");
+
 template <int CH, int CHK>
 struct FwdChunkMF {
-    float4 geo[CHK];   // mean_x, mean_y, conic_a, conic_b
-    float2 co[CHK];    // conic_c, opacity
-    float4 cd[CHK];    // r, g, b, depth
-    uint32_t id[CHK + 8];
-    uint32_t pos[CHK];   // 1-based list position of every (compacted) entry: n_contrib bookkeeping
+    FwdEntry ent[CHK];
     static constexpr int FT = (CHK * CH > 32 * 65) ? CHK * CH : 32 * 65;
     float feat[FT];        // row-major [instance][channel]; reused as the epilogue transpose tile [channel][65]
 };
@@ -246,7 +252,10 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
     const int lx = lane & 7, ly = lane >> 3;
     float pxf[PPL], pyf[PPL];
     int pix_id[PPL];
-    bool inside[PPL], done[PPL];
+    // T carries the pixel's "finished" flag in its sign bit (T > 0 while the pixel is still blending; -T_final
+    // afterwards): a finished pixel then fails the test_T >= T_MIN check by itself and no per-lane boolean has
+    // to live in a register.
+    bool inside[PPL];
     float T[PPL], col[PPL][3], dep[PPL];
     uint32_t last[PPL];
     f32x16 acc[PPL][2][NB];
@@ -257,8 +266,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
         pxf[p] = (float)x; pyf[p] = (float)y;
         inside[p] = x < a.W && y < a.H;
         pix_id[p] = y * a.W + x;
-        done[p] = !inside[p];
-        T[p] = 1.0f; dep[p] = 0.f; last[p] = 0;
+        T[p] = inside[p] ? 1.0f : -1.0f; dep[p] = 0.f; last[p] = 0;
         col[p][0] = col[p][1] = col[p][2] = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; h++)
@@ -278,10 +286,10 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
     }
 
     for (uint32_t base = r_lo; base < r_hi; base += CHK) {
-        bool alld = true;
+        bool anylive = false;
 #pragma unroll
-        for (int p = 0; p < PPL; p++) alld = alld && done[p];
-        if (__all(alld)) break;
+        for (int p = 0; p < PPL; p++) anylive = anylive || T[p] > 0.0f;
+        if (!__any(anylive)) break;
         const int cnt_in = (int)min((uint32_t)CHK, r_hi - base);
         // wave-level culling: drop splats whose 1/255 footprint misses this wave's pixel block, compact the rest
         const bool hit = lane < cnt_in && rect_hit(n_q0.x, n_q0.y, n_q0.z, n_q0.w, n_q1.x, n_q1.y, wx0, wx1, wy0, wy1);
@@ -290,11 +298,13 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
         const int slot = __popcll(hmask & ((1ull << lane) - 1ull));
         __builtin_amdgcn_wave_barrier();
         if (hit) {
-            ck.geo[slot] = n_q0;
-            ck.co[slot] = make_float2(n_q1.x, n_q1.y);
-            ck.cd[slot] = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
-            ck.id[slot] = n_id;
-            ck.pos[slot] = base - r_lo + lane + 1;
+            FwdEntry en;
+            en.geo = n_q0;
+            en.cd = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
+            en.co_c = n_q1.x; en.co_o = n_q1.y;
+            en.pos = base - r_lo + lane + 1;
+            en.id = n_id;
+            ck.ent[slot] = en;
         }
         __builtin_amdgcn_wave_barrier();
         // prefetch the next chunk (registers) while this one is blended
@@ -310,7 +320,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
             const bool vec_ok = (a.C & 3) == 0 && (a.c0 & 3) == 0;
             for (int e = lane; e < cnt * CHV; e += 64) {
                 const int inst = e / CHV, v = e % CHV;
-                const uint32_t g = ck.id[inst];
+                const uint32_t g = ck.ent[inst].id;
                 const float* src = a.feat + (size_t)g * a.C + a.c0 + 4 * v;
                 float4 f;
                 if (vec_ok && 4 * v + 3 < a.nc) {
@@ -335,15 +345,16 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
             for (int e = 0; e < GI; e++) {
                 live_e[e] = j + e < cnt;
                 const int je = live_e[e] ? j + e : j;
-                g0[e] = ck.geo[je];
-                g1[e] = ck.co[je];
-                cdv[e] = ck.cd[je];
-                pos_e[e] = ck.pos[je];
+                g0[e] = ck.ent[je].geo;
+                cdv[e] = ck.ent[je].cd;
+                const float4 tail = *reinterpret_cast<const float4*>(&ck.ent[je].co_c);
+                g1[e] = make_float2(tail.x, tail.y);
+                pos_e[e] = __float_as_uint(tail.z);
             }
             // a quadrant whose 64 pixels are all saturated is skipped as a whole (wave-uniform branch)
             bool slot_live[PPL];
 #pragma unroll
-            for (int p = 0; p < PPL; p++) slot_live[p] = !__all(done[p]);
+            for (int p = 0; p < PPL; p++) slot_live[p] = __any(T[p] > 0.0f);
             float w[GI][PPL];
             bool any_blend = false;
 #pragma unroll
@@ -364,18 +375,14 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
                 }
 #pragma unroll
                 for (int e = 0; e < GI; e++) {
-                    bool ok = valid[e] && !done[p];
-                    const float test_T = T[p] * (1.0f - araw[e]);
-                    if (ok && test_T < T_MIN) {
-                        done[p] = true;
-                        ok = false;
-                    }
+                    const float test_T = T[p] * (1.0f - araw[e]);      // negative once the pixel is finished
+                    const bool below = test_T < T_MIN;
+                    const bool ok = valid[e] & !below;
+                    const bool term = valid[e] & below;                 // (re-)marks finished pixels
                     const float wv = ok ? araw[e] * T[p] : 0.0f;
                     w[e][p] = wv;
-                    if (ok) {
-                        T[p] = test_T;
-                        last[p] = pos_e[e];
-                    }
+                    T[p] = ok ? test_T : (term ? -fabsf(T[p]) : T[p]);
+                    last[p] = ok ? pos_e[e] : last[p];
                     col[p][0] = fmaf(cdv[e].x, wv, col[p][0]);
                     col[p][1] = fmaf(cdv[e].y, wv, col[p][1]);
                     col[p][2] = fmaf(cdv[e].z, wv, col[p][2]);
@@ -413,11 +420,12 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
     for (int p = 0; p < PPL; p++) {
         if (a.write_base && inside[p]) {
             const size_t pid = (size_t)pix_id[p];
-            a.final_T[pid] = T[p];
+            const float Tf = fabsf(T[p]);
+            a.final_T[pid] = Tf;
             a.n_contrib[pid] = last[p];
-            a.out_color[pid] = col[p][0] + T[p] * a.bg[0];
-            a.out_color[HW + pid] = col[p][1] + T[p] * a.bg[1];
-            a.out_color[2 * HW + pid] = col[p][2] + T[p] * a.bg[2];
+            a.out_color[pid] = col[p][0] + Tf * a.bg[0];
+            a.out_color[HW + pid] = col[p][1] + Tf * a.bg[1];
+            a.out_color[2 * HW + pid] = col[p][2] + Tf * a.bg[2];
             a.out_depth[pid] = dep[p];
         }
         // D[i][n]: lane holds column n = lane & 31 (channel), register r holds row i = (r&3) + 8(r>>2) + 4(lane>>5)
@@ -452,10 +460,10 @@ void launch_one_mf2(const FwdArgs& a, hipStream_t s) {
 template <int CH, int PPL>
 void launch_one_mf(const FwdArgs& a, hipStream_t s) {
     const int v = env_int("F3DGS_FWD_VARIANT", 0);   // tuning knob: chunk size / group size
-    if (v == 1) launch_one_mf2<CH, PPL, 64, 4>(a, s);
+    if (v == 1) launch_one_mf2<CH, PPL, 32, 4>(a, s);
     else if (v == 2) launch_one_mf2<CH, PPL, 32, 2>(a, s);
     else if (v == 3) launch_one_mf2<CH, PPL, 64, 2>(a, s);
-    else launch_one_mf2<CH, PPL, 32, 4>(a, s);   // default: 32-instance chunks, 4-instance groups (measured best at c3)
+    else launch_one_mf2<CH, PPL, 64, 4>(a, s);   // default: 64-instance chunks, 4-instance groups (measured best at c3)
 }
 
 template <int CH, int PPL>
