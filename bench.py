@@ -160,9 +160,9 @@ def main():
     stats = None
     if rank == 0:
         # N_r of SURVEY.md 8(d) is defined on the reference's (bounding-rectangle) instance lists
-        os.environ["F3DGS_TILE_CULL"] = "0"
+        _C.set_option("tile_cull", 0)
         stats = scene_stats(scene, dev)
-        os.environ.pop("F3DGS_TILE_CULL")
+        _C.set_option("tile_cull", 1)
     for _ in range(args.warmup):
         step()
     _C.profile_reset()

@@ -40,14 +40,7 @@ int fail(int code, const char* fmt, ...) {
 // ---- optional per-stage profiling (F3DGS_PROFILE=1) ----------------------------------------------------
 // HIP events are recorded on the caller's stream around every stage and resolved lazily when the
 // totals are read, so the timed region itself is never synchronised.
-bool profiling() {
-    static int on = -1;
-    if (on < 0) {
-        const char* v = getenv("F3DGS_PROFILE");
-        on = (v && atoi(v)) ? 1 : 0;
-    }
-    return on == 1;
-}
+bool profiling() { return options().profile != 0; }
 
 struct PendingSpan {
     const char* name;
@@ -57,6 +50,10 @@ std::mutex g_prof_mu;
 std::vector<PendingSpan> g_pending;
 std::vector<std::pair<const char*, std::pair<double, long>>> g_totals;  // name -> (ms, calls)
 
+void resolve_pending_locked();
+constexpr size_t MAX_PENDING_SPANS = 4096;   // unread spans are folded into the totals beyond this
+
+// RAII: the dangling start event is destroyed on every exit path of forward/backward.
 struct StageTimer {
     hipStream_t s;
     bool on;
@@ -67,6 +64,11 @@ struct StageTimer {
             (void)hipEventRecord(prev, s);
         }
     }
+    ~StageTimer() {
+        if (prev) (void)hipEventDestroy(prev);
+    }
+    StageTimer(const StageTimer&) = delete;
+    StageTimer& operator=(const StageTimer&) = delete;
     void mark(const char* name) {
         if (!on) return;
         hipEvent_t e;
@@ -77,18 +79,19 @@ struct StageTimer {
         (void)hipEventRecord(e2, s);
         {
             std::lock_guard<std::mutex> lk(g_prof_mu);
+            if (g_pending.size() >= MAX_PENDING_SPANS) resolve_pending_locked();   // nobody is reading: bound the queue
             g_pending.push_back({name, prev, e});
         }
         prev = e2;
-    }
-    void finish() {
-        if (on && prev) (void)hipEventDestroy(prev);
-        prev = nullptr;
     }
 };
 
 void resolve_pending() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    resolve_pending_locked();
+}
+
+void resolve_pending_locked() {
     for (auto& p : g_pending) {
         (void)hipEventSynchronize(p.b);
         float ms = 0;
@@ -121,12 +124,29 @@ void fill_view(ViewParams& vp, const float* view, const float* proj, const float
     vp.scale_modifier = mod;
 }
 
-// F3DGS_TILE_CULL=0 keeps the reference's bounding-rectangle instance lists (bit-identical intermediate
+// option "tile_cull" = 0 keeps the reference's bounding-rectangle instance lists (bit-identical intermediate
 // state, used by the parity tests); the default drops instances that cannot blend in a tile.
-int tile_cull_enabled() {
-    const char* v = getenv("F3DGS_TILE_CULL");
-    return (v && atoi(v) == 0) ? 0 : 1;
-}
+int tile_cull_enabled() { return options().tile_cull ? 1 : 0; }
+
+struct OptionDesc {
+    const char* name;
+    const char* env;
+    int Options::*field;
+    int dflt;
+};
+const OptionDesc kOptions[] = {
+    {"tile_cull", "F3DGS_TILE_CULL", &Options::tile_cull, 1},
+    {"feature_mfma", "F3DGS_FEATURE_MFMA", &Options::feature_mfma, 1},
+    {"profile", "F3DGS_PROFILE", &Options::profile, 0},
+    {"bwd_npix", "F3DGS_BWD_NPIX", &Options::bwd_npix, 0},
+    {"bwd_u", "F3DGS_BWD_U", &Options::bwd_u, 4},
+    {"bwd_part_major", "F3DGS_BWD_PART_MAJOR", &Options::bwd_part_major, 0},
+    {"bwd_strip", "F3DGS_BWD_STRIP", &Options::bwd_strip, 0},
+    {"bwd_wave_cull", "F3DGS_BWD_WAVE_CULL", &Options::bwd_wave_cull, 1},
+    {"fwd_ppl", "F3DGS_FWD_PPL", &Options::fwd_ppl, 0},
+    {"fwd_variant", "F3DGS_FWD_VARIANT", &Options::fwd_variant, 0},
+    {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 1},
+};
 
 int tile_bits(int tiles) {
     int b = 0;
@@ -135,6 +155,20 @@ int tile_bits(int tiles) {
 }
 
 }  // namespace
+
+namespace f3dgs {
+Options& options() {
+    static Options o = [] {
+        Options v{};
+        for (const OptionDesc& d : kOptions) {
+            const char* e = getenv(d.env);   // read once, at first use of the library
+            v.*(d.field) = e ? atoi(e) : d.dflt;
+        }
+        return v;
+    }();
+    return o;
+}
+}  // namespace f3dgs
 
 namespace {
 // Pinned landing zone + event for the instance-count read-back; one per host thread (the ABI is re-entrant
@@ -165,7 +199,27 @@ CountReadback& count_readback() {
 
 extern "C" {
 
-int f3dgs_version(void) { return 100; }
+int f3dgs_version(void) { return 200; }
+
+int f3dgs_set_option(const char* name, int value) {
+    if (!name) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null option name");
+    for (const OptionDesc& d : kOptions)
+        if (strcmp(d.name, name) == 0) {
+            options().*(d.field) = value;
+            return F3DGS_OK;
+        }
+    return fail(F3DGS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+}
+
+int f3dgs_get_option(const char* name, int* value) {
+    if (!name || !value) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null argument");
+    for (const OptionDesc& d : kOptions)
+        if (strcmp(d.name, name) == 0) {
+            *value = options().*(d.field);
+            return F3DGS_OK;
+        }
+    return fail(F3DGS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+}
 
 const char* f3dgs_last_error(void) { return g_err.c_str(); }
 
@@ -285,7 +339,6 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
                           img.n_contrib, out_color, out_feature_map, out_depth, s);
     if ((rc = check_debug(debug, s, "render"))) return rc;
     tm.mark("render_fwd");
-    tm.finish();
     HIP_TRY(hipGetLastError());
     return F3DGS_OK;
 }
@@ -325,8 +378,9 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     fill_view(vp, viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, width, height, scale_modifier);
     const size_t HW = (size_t)width * height, tiles = (size_t)vp.gx * vp.gy;
     GeomState geom = GeomState::carve(const_cast<char*>(geom_buffer), P, nullptr);
-    // R is the reference-style count; our (possibly culled) list sits at offset 0 of the binning buffer.
-    BinState bin = BinState::carve(const_cast<char*>(binning_buffer), R, nullptr);
+    // R is the reference-style count, NOT the length the forward carved the binning buffer with; the backward
+    // only reads the sorted instance list, which BinState keeps at offset 0 whatever the length.
+    const uint32_t* point_list = BinState::list_of(binning_buffer);
     ImageState img = ImageState::carve(const_cast<char*>(image_buffer), HW, tiles, nullptr);
     float* grec = static_cast<float*>(scratch);
 
@@ -335,7 +389,7 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     if (C > 0) HIP_TRY(hipMemsetAsync(dL_dsemantic_feature, 0, (size_t)P * C * sizeof(float), s));
     tm.mark("zero");
     if (R > 0)
-        launch_render_backward(vp, C, img.ranges, bin.point_list, geom.rec, img.final_T, img.n_contrib,
+        launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,
                                dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, s);
     if ((rc = check_debug(debug, s, "render backward"))) return rc;
     tm.mark("render_bwd");
@@ -345,7 +399,6 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
                                scales ? dL_drot : nullptr, dL_dz, s);
     if ((rc = check_debug(debug, s, "preprocess backward"))) return rc;
     tm.mark("preprocess_bwd");
-    tm.finish();
     HIP_TRY(hipGetLastError());
     return F3DGS_OK;
 }

@@ -46,6 +46,16 @@ torch::Tensor dev_f32(const torch::Tensor& t, const char* name) {
     return t.contiguous();
 }
 
+// The kernels index the feature tensor as (P, C): the reference's layout is (P, 1, C) (scene/gaussian_model.py:
+// `_semantic_feature`, rasterize_points.cu:160).  Anything else with more than C floats per Gaussian would be
+// read with the wrong stride, so it is rejected instead.
+int feature_channels(const torch::Tensor& semantic_feature, int64_t P) {
+    if (semantic_feature.numel() == 0) return semantic_feature.dim() >= 1 ? (int)semantic_feature.size(-1) : 0;
+    TORCH_CHECK(semantic_feature.dim() == 3 && semantic_feature.size(0) == P && semantic_feature.size(1) == 1,
+                "semantic_feature must have dimensions (num_points, 1, C); got ", semantic_feature.sizes());
+    return (int)semantic_feature.size(2);
+}
+
 void* current_stream(const torch::Tensor& ref) {
     return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(ref.device().index()).stream();
 }
@@ -63,7 +73,7 @@ RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D
     TORCH_CHECK(means3D.is_cuda(), "means3D must live on a HIP device: the MI355X rasterizer has no CPU path");
     const int P = means3D.size(0);
     const int H = image_height, W = image_width;
-    const int C = semantic_feature.dim() >= 1 ? (int)semantic_feature.size(-1) : 0;
+    const int C = feature_channels(semantic_feature, P);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
 
     auto f32 = means3D.options().dtype(torch::kFloat32);
@@ -109,8 +119,8 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     TORCH_CHECK(means3D.is_cuda(), "means3D must live on a HIP device: the MI355X rasterizer has no CPU path");
     const int P = means3D.size(0);
     const int H = dL_dout_color.size(1), W = dL_dout_color.size(2);  // rasterize_points.cu:154-155
-    const int C = semantic_feature.dim() >= 1 ? (int)semantic_feature.size(-1) : 0;
-    const int F1 = semantic_feature.dim() >= 2 ? (int)semantic_feature.size(1) : 1;
+    const int C = feature_channels(semantic_feature, P);
+    const int F1 = 1;
     c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
 
     auto shs = dev_f32(sh, "sh");
@@ -179,6 +189,12 @@ PYBIND11_MODULE(_C, m) {
     m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
     m.def("mark_visible", &markVisible);
     m.def("version", []() { return f3dgs_version(); });
+    m.def("set_option", [](const std::string& name, int value) { check_status(f3dgs_set_option(name.c_str(), value), "set_option"); });
+    m.def("get_option", [](const std::string& name) {
+        int v = 0;
+        check_status(f3dgs_get_option(name.c_str(), &v), "get_option");
+        return v;
+    });
     m.def("profile_reset", []() { f3dgs_profile_reset(); });
     m.def("profile_read", []() {
         const char* names[64];

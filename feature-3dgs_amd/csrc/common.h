@@ -96,10 +96,13 @@ struct BinState {
     uint32_t* id_tmp;       // N  ping-pong partners
     uint32_t* tile_tmp;     // N
     uint32_t* hist;         // RADIX_BINS * sort_blocks(N) + RADIX_BINS
+    // The sorted list is the FIRST sub-buffer: its address does not depend on N, so a reader that only knows the
+    // buffer (the backward pass) finds it without the length the forward carved with.
+    static const uint32_t* list_of(const char* base) { return reinterpret_cast<const uint32_t*>(base); }
     static BinState carve(char* base, size_t N, size_t* bytes) {
         Carver c(base);
         BinState b;
-        b.point_list = c.take<uint32_t>(N);
+        b.point_list = c.take<uint32_t>(N);   // offset 0 (see list_of)
         b.tile_sorted = c.take<uint32_t>(N);
         b.id_tmp = c.take<uint32_t>(N);
         b.tile_tmp = c.take<uint32_t>(N);
@@ -123,6 +126,25 @@ struct ImageState {
         return s;
     }
 };
+
+// ---- process-wide options ------------------------------------------------------------------------
+// Seeded ONCE from the environment (F3DGS_<NAME>) when the library is first used and changed afterwards only
+// through f3dgs_set_option(); no launch path ever calls getenv().  They select between complete, tested code
+// paths (never skip work): see include/f3dgs.h for the list.
+struct Options {
+    int tile_cull;       // 1: drop instances whose 1/255 ellipse misses the tile (default); 0: reference-identical lists
+    int feature_mfma;    // 1: feature contraction on the matrix pipe where a kernel variant exists (default)
+    int profile;         // 1: record per-stage HIP events (f3dgs_profile_read)
+    int bwd_npix;        // pixels per wave of the blend backward: 0 = automatic, 32/64/128/256
+    int bwd_u;           // pixel bodies interleaved per loop trip of the blend backward: 2 or 4
+    int bwd_part_major;  // blend backward workgroup order
+    int bwd_strip;       // blend backward: 16x4 strips instead of 8x8 quadrants
+    int bwd_wave_cull;   // blend backward: wave-level footprint culling (default 1)
+    int fwd_ppl;         // quadrants per wave of the blend forward: 0 = automatic, 1/2/4
+    int fwd_variant;     // blend forward chunk/group shape: 0 = default
+    int sort_onesweep;   // 1: single-pass histogram + decoupled look-back scatter (default)
+};
+Options& options();
 
 // ---- host-side launchers (one per translation unit) ----------------------------------------------
 // Camera matrices / position / background stay in DEVICE memory (that is where the reference's tensors

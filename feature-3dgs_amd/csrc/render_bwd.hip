@@ -50,8 +50,7 @@ struct BwdArgs {
     int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
     int part_major;  // workgroup -> (tile, part) order, see kernel
     int strip;        // NPIX = 64: 16x4 pixel strips instead of 8x8 quadrants
-    int no_wave_cull; // development: disable the wave-level footprint culling / compaction
-    int ablate;      // development only (F3DGS_BWD_ABLATE): bit0 = skip the flush, bit1 = skip the pixel bodies
+    int no_wave_cull; // option bwd_wave_cull = 0: no wave-level footprint culling / compaction
 };
 
 // ---- paired DPP prefix scans --------------------------------------------------------------------------
@@ -232,7 +231,6 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
             // pixels still alive at this depth (lane = pixel for the ballot); two bodies per trip: ILP for the
             // scans, and the K = 2 of the MFMA
             unsigned long long live = __ballot(v_last[it] > pos_min);
-            if (a.ablate & 2) { touched = sl.have; live = 0; }
             while (live) {
                 // take up to U live pixels; missing ones repeat the first with n_contrib = 0 (inert bodies)
                 int qi[U];
@@ -347,7 +345,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
 
         // ---- flush this chunk: transpose through LDS in groups of 16 values, coalesced atomics -----------
         const unsigned long long tmask = __ballot(touched);
-        if (tmask == 0 || (a.ablate & 1)) return;
+        if (tmask == 0) return;
         L.flush[lane * Lds::FS + Lds::FS - 1] = __uint_as_float(gid);   // the stride's padding column carries the ids
         constexpr int CHF = MF ? 0 : CH;            // feature channels that travel through the LDS transpose
         constexpr int NG = (CHF + 10 + FLUSH_GROUP - 1) / FLUSH_GROUP;
@@ -469,16 +467,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     if (count > 0) process(cur, cur_gid, cur_min);
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 template <int CH, int NPIX, bool MF>
 void launch_one(const BwdArgs& a, hipStream_t s) {
-    const size_t lds = sizeof(BwdLds<CH, NPIX, MF>) + (size_t)env_int("F3DGS_BWD_EXTRA_LDS", 0);   // extra: occupancy experiments
+    const size_t lds = sizeof(BwdLds<CH, NPIX, MF>);
     const dim3 grid(a.gx * a.gy * (256 / NPIX));
-    if (env_int("F3DGS_BWD_U", 4) == 2)
+    if (options().bwd_u == 2)
         hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 2>), grid, dim3(64), lds, s, a);
     else
         hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4>), grid, dim3(64), lds, s, a);
@@ -505,12 +498,12 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     a.final_T = final_T; a.n_contrib = n_contrib; a.dL_dpix = dL_dpix; a.dL_dfeat = dL_dfeat;
     a.dL_ddepth = dL_ddepth; a.grec = grec; a.dL_dfeature = dL_dfeature;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
-    const int npix = env_int("F3DGS_BWD_NPIX", 64);
-    a.ablate = env_int("F3DGS_BWD_ABLATE", 0);
-    a.part_major = env_int("F3DGS_BWD_PART_MAJOR", 0);
-    a.no_wave_cull = env_int("F3DGS_BWD_NO_WAVE_CULL", 0);
-    a.strip = env_int("F3DGS_BWD_STRIP", 0);
-    const bool mf = env_int("F3DGS_FEATURE_MFMA", 1) != 0;
+    const Options& opt = options();
+    const int npix = opt.bwd_npix ? opt.bwd_npix : 64;
+    a.part_major = opt.bwd_part_major;
+    a.no_wave_cull = !opt.bwd_wave_cull;
+    a.strip = opt.bwd_strip;
+    const bool mf = opt.feature_mfma != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
         launch_npix<0, false>(a, npix, s);

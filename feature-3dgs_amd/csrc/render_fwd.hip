@@ -21,11 +21,6 @@ namespace f3dgs {
 
 namespace {
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 template <int CH>
 struct FwdChunk {
     float4 geo[64];  // mean_x, mean_y, conic_a, conic_b
@@ -50,7 +45,6 @@ struct FwdArgs {
     int C;        // total feature channels (row stride of feat)
     int c0, nc;   // channel window handled by this launch
     int write_base;  // 1: also write colour / depth / final_T / n_contrib
-    int ablate;      // development only (F3DGS_FWD_ABLATE): bit0 skip blend loop, bit1 skip feature staging, bit2 skip epilogue stores
 };
 
 template <int CH, int PPL>
@@ -315,7 +309,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
         }
 
         // feature rows of the chunk -> LDS (coalesced: CH/4 lanes x 16 B per instance)
-        if (!(a.ablate & 2)) {
+        {
             constexpr int CHV = CH / 4;
             const bool vec_ok = (a.C & 3) == 0 && (a.c0 & 3) == 0;
             for (int e = lane; e < cnt * CHV; e += 64) {
@@ -336,7 +330,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
         }
         __builtin_amdgcn_wave_barrier();
 
-        for (int j = 0; j < ((a.ablate & 1) ? 0 : cnt); j += GI) {
+        for (int j = 0; j < cnt; j += GI) {
             float4 g0[GI], cdv[GI];
             float2 g1[GI];
             uint32_t pos_e[GI];
@@ -390,7 +384,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
                     any_blend = any_blend || ok;
                 }
             }
-            if (__any(any_blend) && !(a.ablate & 8)) {
+            if (__any(any_blend)) {
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
                     // B rows: instance j+2k for lanes 0-31, j+2k+1 for lanes 32-63 (a missing instance has w = 0 and
@@ -441,7 +435,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
                     ck.feat[(lane & 31) * 65 + i] = acc[p][h][nb][r];
                 }
             __builtin_amdgcn_wave_barrier();
-            if (inside[p] && !(a.ablate & 4)) {
+            if (inside[p]) {
 #pragma unroll 8
                 for (int n = 0; n < 32; n++)
                     if (32 * nb + n < a.nc)
@@ -459,7 +453,7 @@ void launch_one_mf2(const FwdArgs& a, hipStream_t s) {
 }
 template <int CH, int PPL>
 void launch_one_mf(const FwdArgs& a, hipStream_t s) {
-    const int v = env_int("F3DGS_FWD_VARIANT", 0);   // tuning knob: chunk size / group size
+    const int v = options().fwd_variant;   // tuning knob: chunk size / group size
     if (v == 1) launch_one_mf2<CH, PPL, 32, 4>(a, s);
     else if (v == 2) launch_one_mf2<CH, PPL, 32, 2>(a, s);
     else if (v == 3) launch_one_mf2<CH, PPL, 64, 2>(a, s);
@@ -485,9 +479,8 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges, con
     a.final_T = final_T; a.n_contrib = n_contrib; a.out_color = out_color; a.out_feat = out_feat;
     a.out_depth = out_depth;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
-    a.ablate = env_int("F3DGS_FWD_ABLATE", 0);
-    const int ppl = env_int("F3DGS_FWD_PPL", 0);
-    const bool mf = env_int("F3DGS_FEATURE_MFMA", 1) != 0;
+    const int ppl = options().fwd_ppl;
+    const bool mf = options().feature_mfma != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
         if (ppl == 1) launch_one<0, 1>(a, s);

@@ -61,6 +61,24 @@ int f3dgs_version(void);
 const char* f3dgs_last_error(void);
 
 /*
+ * Process-wide options (no counterpart in the reference).  Each option selects between complete, tested code
+ * paths; none removes work.  Defaults are seeded ONCE, at first use of the library, from the environment
+ * variable F3DGS_<NAME IN CAPITALS>; afterwards only these calls change them (no launch path reads the
+ * environment).
+ *   "tile_cull"      1 (default): instances whose 1/255-alpha ellipse misses a tile are never emitted (they
+ *                    could not blend at any of its pixels, so outputs are unchanged); 0: the reference's
+ *                    bounding-rectangle lists, bit-identical private state (used by the parity tests)
+ *   "feature_mfma"   1 (default): feature contraction of the blend kernels on the matrix pipe (exact fp32)
+ *   "profile"        1: per-stage HIP events, see f3dgs_profile_read
+ *   "sort_onesweep"  1 (default): single-pass radix scatter with decoupled look-back; 0: three-kernel passes
+ *   "bwd_npix", "bwd_u", "bwd_part_major", "bwd_strip", "bwd_wave_cull", "fwd_ppl", "fwd_variant":
+ *                    kernel-shape tuning knobs (0 = automatic where applicable)
+ * Unknown names return F3DGS_ERR_INVALID_ARGUMENT.
+ */
+int f3dgs_set_option(const char* name, int value);
+int f3dgs_get_option(const char* name, int* value /* host pointer, out */);
+
+/*
  * Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:24-29,
  * rasterizer_impl.cu:141-153): present[i] = (view * p_i).z > 0.2.
  * `present` is a device array of P bytes (0/1).
@@ -90,9 +108,9 @@ int f3dgs_mark_visible(
  * this library.  *num_rendered receives the reference's return value: the
  * number of (tile, Gaussian) instances of the 3-sigma bounding rectangles
  * (rasterizer_impl.cu:279-283).  The private instance lists may be shorter:
- * unless the environment variable F3DGS_TILE_CULL=0 is set, instances whose
- * 1/255-alpha ellipse misses the tile are never emitted (they could not blend
- * at any pixel, so outputs are unchanged).  Reading the counts costs one
+ * unless option "tile_cull" is 0, instances whose 1/255-alpha ellipse misses
+ * the tile are never emitted (they could not blend at any pixel, so outputs
+ * are unchanged).  Reading the counts costs one
  * 8-byte device-to-host copy + stream sync, like rasterizer_impl.cu:283.
  */
 int f3dgs_forward(
@@ -203,8 +221,7 @@ int f3dgs_debug_read(
     void* host_dst, size_t dst_bytes,
     void* stream);
 
-/* Per-stage device-time accounting, active when the environment variable F3DGS_PROFILE=1 is set
- * at first use.  HIP events are recorded on the call's stream around every stage (no
+/* Per-stage device-time accounting, active while option "profile" is 1 (seeded from F3DGS_PROFILE).  HIP events are recorded on the call's stream around every stage (no
  * synchronisation inside forward/backward); f3dgs_profile_read waits for the recorded events and
  * returns, per stage name, the accumulated milliseconds and the number of spans since the last
  * f3dgs_profile_reset.  Returns the number of stages written; names[i] are static strings. */

@@ -58,6 +58,26 @@ def main():
     finally:
         torch.zeros = real_zeros
     out["cov_scales"], out["cov_rot"] = scales.numpy(), rot_n.numpy()
+    # ---- camera matrices: utils/graphics_utils.py:38-71 + scene/cameras.py:55-58 ---------------------------
+    # (synth.make_camera must hand the op exactly what the reference's Camera class would)
+    import math
+    from utils.graphics_utils import getProjectionMatrix, getWorld2View2  # noqa: E402  (reference code)
+    cams = [(256, 256, 60.0, 0.0), (1920, 1080, 60.0, 0.0), (1920, 1080, 60.0, 10.0), (3840, 2160, 60.0, 35.0),
+            (97, 61, 45.0, -20.0)]
+    out["cam_params"] = np.array(cams, np.float64)
+    for i, (W, H, fovx_deg, yaw_deg) in enumerate(cams):
+        fovx = math.radians(fovx_deg)
+        fovy = 2 * math.atan(math.tan(fovx / 2) * H / W)
+        a = math.radians(yaw_deg)
+        w2c_rot = np.array([[math.cos(a), 0.0, -math.sin(a)], [0.0, 1.0, 0.0], [math.sin(a), 0.0, math.cos(a)]])
+        R = w2c_rot.T                      # the reference stores the camera-to-world rotation (cameras.py:21-22)
+        T = np.zeros(3)
+        view = torch.tensor(getWorld2View2(R, T)).transpose(0, 1)
+        proj = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+        full = (view.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+        out[f"cam{i}_view"], out[f"cam{i}_full"] = view.numpy(), full.numpy()
+        out[f"cam{i}_center"] = view.inverse()[3, :3].numpy()
+        out[f"cam{i}_tan"] = np.array([math.tan(fovx * 0.5), math.tan(fovy * 0.5)])   # gaussian_renderer/__init__.py:189-190
     np.savez_compressed(os.path.join(HERE, "reference_fallbacks.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_fallbacks.npz"), {k: v.shape for k, v in out.items()})
 

@@ -19,10 +19,10 @@ def c3():
     return make_scene(seed=1, **CONFIGS["c3"])
 
 
-def test_c3_lists_are_sorted_and_consistent(c3, monkeypatch):
+def test_c3_lists_are_sorted_and_consistent(c3, option):
     lib = _lib()
     for cull in ("0", "1"):
-        monkeypatch.setenv("F3DGS_TILE_CULL", cull)
+        option("tile_cull", int(cull))
         res = _raw_forward(c3)
         cnt = _read(lib, "counters", c3, res, np.uint32, 16)
         n_list, n_ref = int(cnt[0]), int(cnt[1])
@@ -53,15 +53,15 @@ def test_c3_lists_are_sorted_and_consistent(c3, monkeypatch):
         assert np.all(radii[np.unique(pl)] > 0)
 
 
-def test_c3_culling_and_reruns_are_bit_identical(c3, monkeypatch):
-    monkeypatch.setenv("F3DGS_TILE_CULL", "0")
+def test_c3_culling_and_reruns_are_bit_identical(c3, option):
+    option("tile_cull", 0)
     a = _raw_forward(c3)
-    monkeypatch.setenv("F3DGS_TILE_CULL", "1")
+    option("tile_cull", 1)
     b = _raw_forward(c3)
     c = _raw_forward(c3)
     for i in (1, 2, 3, 4):
         assert torch.equal(a[i], b[i]) and torch.equal(b[i], c[i])
-    monkeypatch.setenv("F3DGS_FEATURE_MFMA", "0")                     # VALU feature path: same fp32 fma chain order?
+    option("feature_mfma", 0)                     # VALU feature path: same fp32 fma chain order?
     d = _raw_forward(c3)
     assert torch.equal(b[1], d[1]) and torch.equal(b[3], d[3])        # colour / depth never touch the matrix pipe
     assert float((b[2] - d[2]).abs().max()) < 1e-5                    # features: same sums, different association

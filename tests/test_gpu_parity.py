@@ -57,8 +57,8 @@ def _read(lib, what, scene, res, dtype, count):
 
 
 @pytest.mark.parametrize("seed,P,W,H,C", [(1, 5000, 256, 256, 3), (2, 20000, 320, 200, 16), (3, 3000, 97, 61, 32)])
-def test_binning_is_bit_exact(seed, P, W, H, C, monkeypatch):
-    monkeypatch.setenv("F3DGS_TILE_CULL", "0")   # reference-identical instance lists
+def test_binning_is_bit_exact(seed, P, W, H, C, option):
+    option("tile_cull", 0)   # reference-identical instance lists
     scene = _scene(P=P, C=C, width=W, height=H, seed=seed, scale_lo=0.005, scale_hi=0.08)
     o, want, _ = run_oracle(scene, backward=False)
     res = _raw_forward(scene)
@@ -108,6 +108,53 @@ CASES = [
 ]
 
 
+def _strict_compare(scene, pc=False, pv=False):
+    """HIP path vs the C++ oracle with the north-star bars: outputs <= 1e-4 abs, gradients <= 1e-3 rel
+    (`|err| <= 1e-3 |g| + 1e-5 max|g|` for EVERY element and max err <= 1e-3 max|g|), after the pixels PROVEN to be
+    threshold flips (refutil.flip_pixels: n_contrib / final-T evidence from both implementations) have been
+    counted, bounded and removed exactly by zeroing their upstream gradients on both sides."""
+    import refutil as ru
+    from util import set_option
+    W, H = scene["image_width"], scene["image_height"]
+    npix = W * H
+    o, want, _ = run_oracle(scene, pc, pv, backward=False)
+    old = set_option("tile_cull", 0)      # n_contrib is a list position: comparable only on the reference's lists
+    try:
+        d = ru.device_inputs(scene, scene["C"], "cuda:0", pc, pv)
+        f0 = ru.raw_forward(ru.product_module(), scene, d)
+        img_prod = ru.product_image_state(scene, f0)
+    finally:
+        set_option("tile_cull", old)
+    flips = ru.flip_pixels(dict(n_contrib=o.read("n_contrib"), final_T=o.read("final_T")), img_prod)
+    nflip = int(flips.sum())
+    assert nflip <= max(2, npix // 10000), f"{nflip} threshold-flip pixels"
+    ok = ~flips
+    masked = dict(scene)
+    keep = torch.from_numpy(ok.reshape(1, H, W))
+    for k in ("dL_dcolor", "dL_dfeature", "dL_ddepth"):
+        masked[k] = scene[k] * keep
+    got, got_g = run_hip(masked, pc, pv)
+    want_g = o.backward(masked["dL_dcolor"], masked["dL_dfeature"], masked["dL_ddepth"])
+    assert np.array_equal(got["radii"], want["radii"])
+    for k in ("color", "feature_map", "depth"):
+        if want[k].size == 0:
+            assert got[k].shape == want[k].shape
+            continue
+        err = np.abs(got[k] - want[k]).reshape(want[k].shape[0], -1).max(0)
+        assert err[ok].max() <= 1e-4, f"{k}: max abs err {err[ok].max():.3e} outside the {nflip} flip pixels"
+    names = {"dL_dmeans3D", "dL_dmeans2D", "dL_dsemantic_feature", "dL_dopacity"}
+    names |= {"dL_dcolors"} if pc else {"dL_dsh"}
+    names |= {"dL_dcov3D"} if pv else {"dL_dscales", "dL_drotations"}
+    for k in sorted(names):
+        w = want_g[k]
+        if w.size == 0:
+            continue
+        mx, worst = ru.grad_errors(got_g[k], w)
+        assert mx <= 1e-3, f"{k}: max err / max|g| = {mx:.2e}"
+        assert worst <= 1.0, f"{k}: worst element {worst:.2f}x outside 1e-3*|g| + 1e-5*max|g|"
+    return nflip
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k != "bg"))
 def test_forward_backward_parity(case):
     big = case.get("big", False)
@@ -117,28 +164,7 @@ def test_forward_backward_parity(case):
     if "bg" in case:
         scene["bg"] = torch.tensor(case["bg"])
     scene = precompute_optionals(scene)
-    pc, pv = case.get("precomp_color", False), case.get("precomp_cov", False)
-    _, want, want_g = run_oracle(scene, pc, pv)
-    got, got_g = run_hip(scene, pc, pv)
-    assert np.array_equal(got["radii"], want["radii"])
-    npix = case["W"] * case["H"]
-    for k in ("color", "feature_map", "depth"):
-        if want[k].size == 0:
-            assert got[k].shape == want[k].shape
-            continue
-        err = np.abs(got[k] - want[k])
-        bad_pix = int((err.reshape(err.shape[0], -1).max(0) > 1e-4).sum())
-        assert bad_pix <= max(2, npix // 10000), f"{k}: {bad_pix} pixels above 1e-4 (max {err.max():.3e})"
-    names = {"dL_dmeans3D", "dL_dmeans2D", "dL_dsemantic_feature", "dL_dopacity"}
-    names |= {"dL_dcolors"} if pc else {"dL_dsh"}
-    names |= {"dL_dcov3D"} if pv else {"dL_dscales", "dL_drotations"}
-    for k in sorted(names):
-        w = want_g[k]
-        if w.size == 0:
-            continue
-        mx, bad = grad_report(k, got_g[k], w)
-        assert bad < 2e-3, f"{k}: fraction {bad:.2e} beyond 1e-3 rel (max err / max |g| = {mx:.2e})"
-        assert mx < 5e-3, f"{k}: max err / max |g| = {mx:.2e}"
+    _strict_compare(scene, case.get("precomp_color", False), case.get("precomp_cov", False))
 
 
 def test_empty_and_degenerate_inputs():
@@ -197,25 +223,19 @@ def test_mark_visible_matches_oracle():
 def test_rotated_view_and_scale_modifier():
     scene = _scene(P=6000, C=8, width=192, height=108, seed=21, yaw_deg=10.0, scale_lo=0.005, scale_hi=0.08)
     scene["scale_modifier"] = 0.7
-    _, want, want_g = run_oracle(scene)
-    got, got_g = run_hip(scene)
-    assert np.array_equal(got["radii"], want["radii"])
-    assert np.abs(got["color"] - want["color"]).max() < 1e-4
-    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
-        mx, bad = grad_report(k, got_g[k], want_g[k])
-        assert bad < 2e-3 and mx < 5e-3, (k, mx, bad)
+    _strict_compare(scene)
 
 
 @pytest.mark.parametrize("seed,P,W,H,C", [(31, 30000, 320, 192, 8), (32, 4000, 64, 64, 4)])
-def test_tile_culling_changes_lists_not_results(seed, P, W, H, C, monkeypatch):
+def test_tile_culling_changes_lists_not_results(seed, P, W, H, C, option):
     """Default mode drops instances whose 1/255 ellipse misses the tile: shorter private lists, the
     reference's num_rendered, and BIT-identical images (same blends in the same order)."""
     scene = _scene(P=P, C=C, width=W, height=H, seed=seed, scale_lo=0.005, scale_hi=0.15)
     lib = _lib()
-    monkeypatch.setenv("F3DGS_TILE_CULL", "0")
+    option("tile_cull", 0)
     ref = _raw_forward(scene)
     ref_n = int(_read(lib, "counters", scene, ref, np.uint32, 16)[0])
-    monkeypatch.setenv("F3DGS_TILE_CULL", "1")
+    option("tile_cull", 1)
     cul = _raw_forward(scene)
     cnt = _read(lib, "counters", scene, cul, np.uint32, 16)
     _, want, _ = run_oracle(scene, backward=False)

@@ -29,6 +29,19 @@ def test_cov3d_matches_reference_build_covariance(oracle_lib):
         assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), mod
 
 
+def test_synthetic_cameras_match_the_reference_camera_class():
+    """synth.make_camera hands the op the matrices the reference's Camera would build (utils/graphics_utils.py:38-71,
+    scene/cameras.py:55-58), frozen from the imported reference code."""
+    from synth import make_camera
+    g = np.load(os.path.join(GOLD, "reference_fallbacks.npz"))
+    for i, (W, H, fovx_deg, yaw_deg) in enumerate(g["cam_params"]):
+        cam = make_camera(int(W), int(H), fovx_deg=float(fovx_deg), yaw_deg=float(yaw_deg))
+        assert np.allclose(cam["viewmatrix"].numpy(), g[f"cam{i}_view"], rtol=0, atol=1e-7), i
+        assert np.allclose(cam["projmatrix"].numpy(), g[f"cam{i}_full"], rtol=1e-6, atol=1e-7), i
+        assert np.allclose(cam["campos"].numpy(), g[f"cam{i}_center"], rtol=0, atol=1e-7), i
+        assert np.allclose([cam["tanfovx"], cam["tanfovy"]], g[f"cam{i}_tan"], rtol=1e-12), i
+
+
 def test_oracle_regression_vectors(oracle_lib):
     import importlib.util
     spec = importlib.util.spec_from_file_location("mk", os.path.join(GOLD, "make_oracle_regression.py"))

@@ -13,6 +13,14 @@ for p in (ROOT, os.path.join(ROOT, "feature-3dgs_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+def set_option(name: str, value: int) -> int:
+    """Change a process-wide option of the product library (include/f3dgs.h); returns the previous value."""
+    from diff_gaussian_rasterization import _C
+    old = _C.get_option(name)
+    _C.set_option(name, int(value))
+    return old
+
+
 GRAD_NAMES = ["dL_dmeans3D", "dL_dmeans2D", "dL_dsh", "dL_dcolors", "dL_dsemantic_feature", "dL_dopacity",
               "dL_dscales", "dL_drotations", "dL_dcov3D"]
 

@@ -6,8 +6,8 @@ import bench
 from synth import make_scene, CONFIGS
 sc = make_scene(seed=0, **CONFIGS["c3"])
 for cull in ("0", "1"):
-    os.environ["F3DGS_TILE_CULL"] = cull
     from diff_gaussian_rasterization import _C
+    _C.set_option("tile_cull", int(cull))
     t = lambda x: x.to("cuda:0"); e = torch.Tensor([])
     res = _C.rasterize_gaussians(t(sc["bg"]), t(sc["means3D"]), e, t(sc["semantic_feature"]), t(sc["opacities"]), t(sc["scales"]), t(sc["rotations"]), 1.0, e, t(sc["viewmatrix"]), t(sc["projmatrix"]), sc["tanfovx"], sc["tanfovy"], 1080, 1920, t(sc["shs"]), 3, t(sc["campos"]), False, False)
     torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 """Per-stage timing of one config on the GPU under a list of environment settings (development aid;
 bench.py is the contract).
 
-    python tools/quick_bench.py c3 10 "" "F3DGS_FWD_PPL=1" "F3DGS_FWD_PPL=1 F3DGS_FWD_VARIANT=2"
+    python tools/quick_bench.py c3 10 "" "fwd_ppl=1" "fwd_ppl=1 fwd_variant=2"
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,8 +40,8 @@ for setting in settings:
     added = []
     for kv in setting.split():
         k, v = kv.split("=")
-        os.environ[k] = v
-        added.append(k)
+        added.append((k, _C.get_option(k)))
+        _C.set_option(k, int(v))
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -53,5 +53,5 @@ for setting in settings:
     ms = 1e3 * (time.perf_counter() - t0) / iters
     prof = {n: m / max(1, c) for n, m, c in _C.profile_read()}
     print(f"[{setting or 'default'}] {ms:.3f} ms/step | " + " ".join(f"{n}={m:.3f}" for n, m in prof.items()), flush=True)
-    for k in added:
-        del os.environ[k]
+    for k, old in added:
+        _C.set_option(k, old)
