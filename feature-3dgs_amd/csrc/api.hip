@@ -139,13 +139,15 @@ const OptionDesc kOptions[] = {
     {"feature_mfma", "F3DGS_FEATURE_MFMA", &Options::feature_mfma, 1},
     {"profile", "F3DGS_PROFILE", &Options::profile, 0},
     {"bwd_npix", "F3DGS_BWD_NPIX", &Options::bwd_npix, 0},
-    {"bwd_u", "F3DGS_BWD_U", &Options::bwd_u, 4},
     {"bwd_part_major", "F3DGS_BWD_PART_MAJOR", &Options::bwd_part_major, 0},
     {"bwd_strip", "F3DGS_BWD_STRIP", &Options::bwd_strip, 0},
     {"bwd_wave_cull", "F3DGS_BWD_WAVE_CULL", &Options::bwd_wave_cull, 1},
     {"fwd_ppl", "F3DGS_FWD_PPL", &Options::fwd_ppl, 0},
     {"fwd_variant", "F3DGS_FWD_VARIANT", &Options::fwd_variant, 0},
-    {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 1},
+    {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},
+#ifdef F3DGS_DEV
+    {"dev", "F3DGS_DEV_BITS", &Options::dev, 0},
+#endif
 };
 
 int tile_bits(int tiles) {
@@ -280,62 +282,79 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     char* img_ptr = image_resize(image_ctx, img_bytes);
     if (!img_ptr) return fail(F3DGS_ERR_ALLOC, "image buffer allocation of %zu bytes failed", img_bytes);
     ImageState img = ImageState::carve(img_ptr, HW, tiles, nullptr);
+    // the single-pass sorts handle tile ids of up to two 8-bit digits (65536 tiles = 4096 x 4096 pixels and beyond
+    // 4K); larger grids take the three-kernel passes
+    const bool onesweep = options().sort_onesweep != 0 && tiles <= 65536;
 
     StageTimer tm(s);
     // K1: projection, culling, SH colour, tile counts
     const int cull = tile_cull_enabled();
     launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, vp, radii,
-                      geom, cull, s);
+                      geom, cull, !onesweep, s);
     if ((rc = check_debug(debug, s, "preprocess"))) return rc;
+    tm.mark("preprocess");
+    if (onesweep) launch_sort_prologue(geom, (size_t)P, s);   // digit histograms of the depth keys + both instance totals
     // Both instance totals are final here.  Their read-back (the counterpart of rasterizer_impl.cu:283) is
-    // requested now and awaited only after the depth sort and the scan have been enqueued, so the host round
-    // trip hides behind ~0.15 ms of GPU work instead of idling the device.
+    // requested now and awaited only after the depth sort has been enqueued, so the host round
+    // trip hides behind ~0.1 ms of GPU work instead of idling the device.
     CountReadback& rb = count_readback();
     if (!rb.host || !rb.done) return fail(F3DGS_ERR_ALLOC, "pinned read-back buffer / event creation failed");
     HIP_TRY(hipMemcpyAsync(rb.host, geom.counters, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(rb.done, s));
-    tm.mark("preprocess");
 
     // depth sort of the Gaussians (ids start in index order -> ties keep ascending id)
-    launch_depth_sort(geom.depth_key, geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, geom.hist, s);
+    if (onesweep) launch_depth_sort_onesweep(geom, (size_t)P, s);
+    else launch_depth_sort(geom.depth_key, geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, geom.hist, s);
     if ((rc = check_debug(debug, s, "depth sort"))) return rc;
     tm.mark("depth_sort");
     const uint32_t* order = geom.val_a;
 
-    // instance offsets in depth order + total
-    launch_exclusive_scan(geom.tiles_touched, order, geom.offsets, nullptr, (size_t)P, geom.scan_tmp, nullptr, 0,
-                          nullptr, s);
+    // instance offsets in depth order (three-kernel flavour only; the single-pass emit scans on the fly)
+    if (!onesweep)
+        launch_exclusive_scan(geom.tiles_touched, order, geom.offsets, nullptr, (size_t)P, geom.scan_tmp, nullptr, 0,
+                              nullptr, s);
     HIP_TRY(hipEventSynchronize(rb.done));
     // [0] instances in our lists, [1] the reference's bounding-rectangle count
     const uint32_t counts[2] = {rb.host[0], rb.host[1]};
     const uint32_t N = counts[0];
-    if ((int)N < 0 || (int)counts[1] < 0) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^31 instances");
+    if (N >= (1u << 30) || counts[1] >= (1u << 31)) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^30 instances");
     if (num_rendered) *num_rendered = (int)counts[1];
     tm.mark("scan+sync");
 
-    BinState::carve(nullptr, N, &bin_bytes);
+    BinState::carve(nullptr, N, &bin_bytes, tiles);
     char* bin_ptr = binning_resize(binning_ctx, bin_bytes);
     if (!bin_ptr) return fail(F3DGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
-    BinState bin = BinState::carve(bin_ptr, N, nullptr);
+    BinState bin = BinState::carve(bin_ptr, N, nullptr, tiles);
 
-    if (N > 0) {
-        const int bits = tile_bits((int)tiles);
-        const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
-        // result must land in (tile_sorted, point_list) == the "A" side
-        uint32_t* in_tile = (passes % 2 == 0) ? bin.tile_sorted : bin.tile_tmp;
-        uint32_t* in_id = (passes % 2 == 0) ? bin.point_list : bin.id_tmp;
-        launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, s);
+    const int bits = tile_bits((int)tiles);
+    const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
+    // result must land in (tile_sorted, point_list) == the "A" side
+    uint32_t* in_tile = (passes % 2 == 0) ? bin.tile_sorted : bin.tile_tmp;
+    uint32_t* in_id = (passes % 2 == 0) ? bin.point_list : bin.id_tmp;
+    if (onesweep) {
+        // emits, builds the tile digit histograms, presets the ranges
+        launch_emit_scan(P, geom, bin, order, vp.gx, vp.gy, cull, in_tile, in_id, N, bin.ranges_enc, s);
         if ((rc = check_debug(debug, s, "emit"))) return rc;
         tm.mark("emit");
-        launch_radix_sort_pairs(bin.tile_sorted, bin.point_list, bin.tile_tmp, bin.id_tmp, N, bits, bin.hist, true, s);
+        launch_tile_sort_onesweep(geom, bin, N, passes, bin.ranges_enc, s);   // the final pass also records the tile ranges
         if ((rc = check_debug(debug, s, "tile sort"))) return rc;
         tm.mark("tile_sort");
+    } else {
+        // all-ones = "no entry yet" for both halves of the encoded ranges (see BinState::ranges_enc)
+        HIP_TRY(hipMemsetAsync(bin.ranges_enc, 0xFF, tiles * sizeof(uint2), s));
+        if (N > 0) {
+            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, s);
+            if ((rc = check_debug(debug, s, "emit"))) return rc;
+            tm.mark("emit");
+            // the final pass also records the tile ranges
+            launch_radix_sort_pairs(bin.tile_sorted, bin.point_list, bin.tile_tmp, bin.id_tmp, N, bits, bin.hist, true,
+                                    bin.ranges_enc, s);
+            if ((rc = check_debug(debug, s, "tile sort"))) return rc;
+            tm.mark("tile_sort");
+        }
     }
-    launch_tile_ranges(N, bin.tile_sorted, img.ranges, tiles, s);
-    if ((rc = check_debug(debug, s, "ranges"))) return rc;
-    tm.mark("ranges");
 
-    launch_render_forward(vp, C, img.ranges, bin.point_list, geom.rec, semantic_feature, img.final_T,
+    launch_render_forward(vp, C, bin.ranges_enc, img.ranges, bin.point_list, geom.rec, semantic_feature, img.final_T,
                           img.n_contrib, out_color, out_feature_map, out_depth, s);
     if ((rc = check_debug(debug, s, "render"))) return rc;
     tm.mark("render_fwd");

@@ -17,36 +17,11 @@
 // stable scatter (wave-level match with ballots, wave-ordered LDS counters).
 
 #include "common.h"
+#include "lookback.h"
 
 namespace f3dgs {
 
 namespace {
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-// Exclusive scan of one value per thread across a 256-thread workgroup. `sh` holds >= 8 words.
-__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* sh, uint32_t* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t inc = wave_incl_scan(v, lane);
-    if (lane == 63) sh[w] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t s = sh[k];
-        if (k < w) base += s;
-    }
-    if (total) *total = sh[0] + sh[1] + sh[2] + sh[3];
-    __syncthreads();
-    return base + inc - v;
-}
 
 // ---------------- generic exclusive scan (reduce / spine / apply) ------------------------------------
 __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* __restrict__ in,
@@ -153,11 +128,22 @@ __global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t* __restrict
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-template <int BITS, bool REORDER>
+// RANGES (final tile pass only, needs REORDER): the keys are whole tile ids and the output is fully sorted, so the
+// range of a tile is [min, max + 1) of the output positions of its entries.  Inside the LDS-sorted chunk the entries
+// of one tile are adjacent and so are their output positions: two atomicMin per (workgroup, tile) segment on the
+// all-ones preset of BinState::ranges_enc - a few dozen per workgroup, spread over all tiles.  This replaces a
+// separate pass over the sorted keys.
+__device__ __forceinline__ void record_range(uint2* ranges_enc, uint32_t tile, bool first, bool last, uint32_t pos) {
+    if (first) atomicMin(&ranges_enc[tile].x, pos);
+    if (last) atomicMin(&ranges_enc[tile].y, 0xFFFFFFFFu - (pos + 1u));
+}
+
+template <int BITS, bool REORDER, bool RANGES>
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
-                     uint32_t nb, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
+                     uint32_t nb, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+                     uint2* __restrict__ ranges_enc) {
     constexpr int BINS = 1 << BITS;
     constexpr int BPT = BINS / SORT_THREADS;   // bins per thread in the offset phase
     __shared__ uint32_t cnt[4][BINS];
@@ -249,6 +235,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
                 const uint32_t pos = gbase[d] + (j - lstart[d]);
                 keys_out[pos] = kk;
                 vals_out[pos] = sval[j];
+                if (RANGES) record_range(ranges_enc, kk, j == 0 || skey[j - 1] != kk, j + 1 == have || skey[j + 1] != kk, pos);
             }
         }
     } else {
@@ -265,26 +252,162 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     }
 }
 
+
+// =====================================================================================================
+// Single-pass ("onesweep") radix passes with decoupled look-back.
+//
+// One launch per 8-bit digit.  The global digit histograms of ALL passes of a sort are produced up front in
+// a single read of the keys (depth keys: sort_prologue_kernel; tile ids: derived from the per-tile counts by
+// the last workgroup of emit_scan_kernel), so a pass is: take a ticket (virtual workgroup id = arrival order,
+// which makes "every predecessor is resident or done" true whatever the hardware's dispatch order is), rank the
+// chunk's items per digit, publish the chunk's 256 digit counts, look back over the predecessors' published
+// counts (one thread per digit) until an inclusive prefix is found, scatter through an LDS-sorted image of
+// the chunk (helpers: lookback.h).
+template <int ITEMS, bool WRITE_KEYS, bool RANGES>
+__global__ void __launch_bounds__(SORT_THREADS)
+onesweep_pass_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
+                     const uint32_t* __restrict__ digit_totals, uint32_t* __restrict__ status,
+                     uint32_t* __restrict__ ticket, uint2* __restrict__ ranges) {
+    constexpr int BINS = 256;
+    constexpr int CHUNK = SORT_THREADS * ITEMS;
+    __shared__ uint32_t cnt[4][BINS];
+    __shared__ uint32_t sh[8];
+    __shared__ uint32_t gbase[BINS];     // global offset of this workgroup's run of digit d
+    __shared__ uint32_t lstart[BINS];    // start of digit d inside the LDS-sorted chunk
+    __shared__ uint32_t skey[CHUNK];
+    __shared__ uint32_t sval[CHUNK];
+    __shared__ uint32_t s_vb;
+    volatile uint32_t* vcnt = &cnt[0][0];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_vb = atomicAdd(ticket, 1u);
+    for (int d = threadIdx.x; d < 4 * BINS; d += SORT_THREADS) (&cnt[0][0])[d] = 0;
+    __syncthreads();
+    const uint32_t vb = s_vb;
+
+    const size_t cbase = (size_t)vb * CHUNK;
+    const size_t wbase = cbase + (size_t)w * (ITEMS * 64);
+    uint32_t key[ITEMS];
+    uint32_t rank[ITEMS];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const size_t i = wbase + (size_t)k * 64 + lane;
+        const bool valid = i < n;
+        key[k] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        const uint32_t d = (key[k] >> shift) & (BINS - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t before = __popcll(peers & lt_mask);
+        const uint32_t old = vcnt[w * BINS + d];
+        if (valid && before == 0) vcnt[w * BINS + d] = old + (uint32_t)__popcll(peers);
+        rank[k] = old + before;
+    }
+    __syncthreads();
+    {   // thread d owns digit d
+        const uint32_t d = threadIdx.x;
+        const uint32_t blk = cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
+        const uint32_t total = digit_totals[d];
+        const uint32_t digit_base = block_excl_scan_256(total, sh, nullptr);
+        const uint32_t local_base = block_excl_scan_256(blk, sh, nullptr);
+        const uint32_t before_me = lookback(status + d, BINS, vb, blk);
+        gbase[d] = digit_base + before_me;
+        lstart[d] = local_base;
+        uint32_t r2 = local_base;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t c = cnt[k][d];
+            cnt[k][d] = r2;
+            r2 += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const size_t i = wbase + (size_t)k * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (key[k] >> shift) & (BINS - 1);
+            const uint32_t lp = cnt[w][d] + rank[k];
+            skey[lp] = key[k];
+            sval[lp] = vals_in ? vals_in[i] : (uint32_t)i;
+        }
+    }
+    __syncthreads();
+    const uint32_t have = (uint32_t)min((size_t)CHUNK, n - cbase);
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t j = (uint32_t)k * SORT_THREADS + threadIdx.x;
+        if (j < have) {
+            const uint32_t kk = skey[j];
+            const uint32_t d = (kk >> shift) & (BINS - 1);
+            const uint32_t pos = gbase[d] + (j - lstart[d]);
+            if (WRITE_KEYS) keys_out[pos] = kk;
+            vals_out[pos] = sval[j];
+            if (RANGES) record_range(ranges, kk, j == 0 || skey[j - 1] != kk, j + 1 == have || skey[j + 1] != kk, pos);
+        }
+    }
+}
+
+// Before the depth sort: the four digit histograms of the depth keys in one read, the two instance totals
+// (sum of the per-workgroup partials of preprocess_kernel; the host reads them back while the sort runs) and
+// the zero-fill of every look-back status word the forward pass will use from the geometry buffer.
+__global__ void __launch_bounds__(256)
+sort_prologue_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __restrict__ depth_hist,
+                     const uint32_t* __restrict__ partial, int n_partial, uint32_t* __restrict__ counters,
+                     uint32_t* __restrict__ zero_words, size_t n_zero) {
+    __shared__ uint32_t h[4][256];
+    __shared__ uint32_t shc[2][4];
+    for (int d = threadIdx.x; d < 1024; d += 256) (&h[0][0])[d] = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_zero; i += (size_t)gridDim.x * 256) zero_words[i] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
+    uint32_t culled = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const size_t i = base + (size_t)k * 256 + threadIdx.x;
+        if (i < n) {
+            const uint32_t kk = keys[i];
+            if (kk == 0xFFFFFFFFu) { culled++; continue; }      // culled Gaussians: one shared bin per digit
+            atomicAdd(&h[0][kk & 255], 1u);
+            atomicAdd(&h[1][(kk >> 8) & 255], 1u);
+            atomicAdd(&h[2][(kk >> 16) & 255], 1u);
+            atomicAdd(&h[3][kk >> 24], 1u);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) culled += (uint32_t)__shfl_xor((int)culled, d, 64);
+    if ((threadIdx.x & 63) == 0 && culled)
+        for (int p = 0; p < 4; p++) atomicAdd(&h[p][255], culled);
+    __syncthreads();
+    for (int p = 0; p < 4; p++) {
+        const uint32_t c = h[p][threadIdx.x];
+        if (c) atomicAdd(&depth_hist[p * 256 + threadIdx.x], c);
+    }
+    if (blockIdx.x == 0) {   // counters[0] = instances in our lists, counters[1] = the reference's count
+        uint32_t v = 0, u = 0;
+        for (int i = threadIdx.x; i < n_partial; i += 256) { v += partial[i]; u += partial[n_partial + i]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            v += (uint32_t)__shfl_xor((int)v, d, 64);
+            u += (uint32_t)__shfl_xor((int)u, d, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { shc[0][threadIdx.x >> 6] = v; shc[1][threadIdx.x >> 6] = u; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            counters[1] = shc[0][0] + shc[0][1] + shc[0][2] + shc[0][3];
+            counters[0] = shc[1][0] + shc[1][1] + shc[1][2] + shc[1][3];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = (uint32_t)i;
-}
-
-__global__ void __launch_bounds__(256) tile_ranges_kernel(size_t N, const uint32_t* __restrict__ tile_sorted,
-                                                          uint2* __restrict__ ranges) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const uint32_t cur = tile_sorted[i];
-    if (i == 0) {
-        ranges[cur].x = 0;
-    } else {
-        const uint32_t prev = tile_sorted[i - 1];
-        if (cur != prev) {
-            ranges[prev].y = (uint32_t)i;
-            ranges[cur].x = (uint32_t)i;
-        }
-    }
-    if (i == N - 1) ranges[cur].y = (uint32_t)N;
 }
 
 }  // namespace
@@ -300,17 +423,21 @@ void launch_exclusive_scan(const uint32_t* in, const uint32_t* gather, uint32_t*
 
 template <int BITS>
 static void radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n, int shift,
-                       uint32_t nb, uint32_t* hist, hipStream_t s) {
+                       uint32_t nb, uint32_t* hist, hipStream_t s, uint2* ranges_enc = nullptr) {
     constexpr int BINS = 1 << BITS;
     uint32_t* totals = hist + (size_t)BINS * nb;
     hipLaunchKernelGGL((radix_hist_kernel<BITS>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, n, shift, nb, hist);
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(BINS), dim3(256), 0, s, hist, nb, totals);
-    hipLaunchKernelGGL((radix_scatter_kernel<BITS, (BITS <= 8)>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko, vo, n,
-                       shift, nb, hist, totals);
+    if (ranges_enc && BITS <= 8)
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, true, true>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko, vo, n,
+                           shift, nb, hist, totals, ranges_enc);
+    else
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, (BITS <= 8), false>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko,
+                           vo, n, shift, nb, hist, totals, (uint2*)nullptr);
 }
 
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
-                             uint32_t* hist, bool result_in_a, hipStream_t s) {
+                             uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s) {
     // Input is expected in A when (#passes even) == result_in_a, else in B; the caller arranges that.
     const int passes = (nbits + RADIX_BITS - 1) / RADIX_BITS;
     if (n == 0 || passes == 0) return;
@@ -321,7 +448,7 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
         uint32_t* vi = in_a ? val_a : val_b;
         uint32_t* ko = in_a ? key_b : key_a;
         uint32_t* vo = in_a ? val_b : val_a;
-        radix_pass<RADIX_BITS>(ki, vi, ko, vo, n, p * RADIX_BITS, nb, hist, s);
+        radix_pass<RADIX_BITS>(ki, vi, ko, vo, n, p * RADIX_BITS, nb, hist, s, p == passes - 1 ? ranges_enc : nullptr);
         in_a = !in_a;
     }
 }
@@ -347,14 +474,53 @@ void launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, u
     radix_pass<DEPTH_RADIX_BITS>(key_b, val_b, key_a, val_a, n, 2 * DEPTH_RADIX_BITS, nb, hist, s);
 }
 
-void launch_iota(uint32_t* dst, size_t n, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, n);
+
+void launch_sort_prologue(const GeomState& g, size_t P, hipStream_t s) {
+    const size_t nb = scan_blocks(P);
+    if (nb == 0) return;
+    hipLaunchKernelGGL(sort_prologue_kernel, dim3(nb), dim3(256), 0, s, g.depth_key, P, g.depth_hist, g.ref_partial,
+                       (int)((P + 255) / 256), g.counters, g.lb_words, g.n_lb_words);
 }
 
-void launch_tile_ranges(size_t N, const uint32_t* tile_sorted, uint2* ranges, size_t tiles, hipStream_t s) {
-    (void)hipMemsetAsync(ranges, 0, tiles * sizeof(uint2), s);
-    if (N == 0) return;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, tile_sorted, ranges);
+// Depth sort, onesweep flavour: four 8-bit passes, one launch each; ids end in val_a (keys are not written by the
+// last pass: nothing reads them).
+void launch_depth_sort_onesweep(const GeomState& g, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    const uint32_t nb = (uint32_t)depth_sort_blocks(n);
+    uint32_t* st = g.depth_status;
+    const size_t st_stride = (size_t)nb * 256;
+    uint2* const no_ranges = nullptr;
+    hipLaunchKernelGGL((onesweep_pass_kernel<DEPTH_SORT_ITEMS, true, false>), dim3(nb), dim3(SORT_THREADS), 0, s, g.depth_key,
+                       (const uint32_t*)nullptr, g.key_b, g.val_b, n, 0, g.depth_hist, st, g.tickets + 0, no_ranges);
+    hipLaunchKernelGGL((onesweep_pass_kernel<DEPTH_SORT_ITEMS, true, false>), dim3(nb), dim3(SORT_THREADS), 0, s, g.key_b,
+                       g.val_b, g.key_a, g.val_a, n, 8, g.depth_hist + 256, st + st_stride, g.tickets + 1, no_ranges);
+    hipLaunchKernelGGL((onesweep_pass_kernel<DEPTH_SORT_ITEMS, true, false>), dim3(nb), dim3(SORT_THREADS), 0, s, g.key_a,
+                       g.val_a, g.key_b, g.val_b, n, 16, g.depth_hist + 512, st + 2 * st_stride, g.tickets + 2, no_ranges);
+    hipLaunchKernelGGL((onesweep_pass_kernel<DEPTH_SORT_ITEMS, false, false>), dim3(nb), dim3(SORT_THREADS), 0, s, g.key_b,
+                       g.val_b, g.key_a, g.val_a, n, 24, g.depth_hist + 768, st + 3 * st_stride, g.tickets + 3, no_ranges);
+}
+
+// Tile sort, onesweep flavour (ids only travel with their tile ids; `passes` = 1 or 2 digits of 8 bits).
+// Input in (tile_tmp, id_tmp) for an odd number of passes, in (tile_sorted, point_list) for an even one; the
+// result lands in (tile_sorted, point_list).
+void launch_tile_sort_onesweep(const GeomState& g, const BinState& b, size_t n, int passes, uint2* ranges, hipStream_t s) {
+    if (n == 0) return;
+    const uint32_t nb = (uint32_t)sort_blocks(n);
+    const size_t st_stride = (size_t)nb * 256;
+    if (passes == 1) {
+        hipLaunchKernelGGL((onesweep_pass_kernel<SORT_ITEMS, true, true>), dim3(nb), dim3(SORT_THREADS), 0, s, b.tile_tmp,
+                           b.id_tmp, b.tile_sorted, b.point_list, n, 0, g.tile_hist, b.tile_status, g.tickets + 5, ranges);
+        return;
+    }
+    hipLaunchKernelGGL((onesweep_pass_kernel<SORT_ITEMS, true, false>), dim3(nb), dim3(SORT_THREADS), 0, s, b.tile_sorted,
+                       b.point_list, b.tile_tmp, b.id_tmp, n, 0, g.tile_hist, b.tile_status, g.tickets + 5, (uint2*)nullptr);
+    hipLaunchKernelGGL((onesweep_pass_kernel<SORT_ITEMS, true, true>), dim3(nb), dim3(SORT_THREADS), 0, s, b.tile_tmp,
+                       b.id_tmp, b.tile_sorted, b.point_list, n, 8, g.tile_hist + 256, b.tile_status + st_stride,
+                       g.tickets + 6, ranges);
+}
+
+void launch_iota(uint32_t* dst, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, n);
 }
 
 }  // namespace f3dgs

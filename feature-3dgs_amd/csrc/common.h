@@ -51,9 +51,12 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 16;                                  // items per thread
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;           // items per workgroup
 constexpr int SCAN_CHUNK = 256 * 16;
+constexpr int DEPTH_SORT_ITEMS = 8;                             // onesweep depth passes: 2048 keys per workgroup
 
 inline size_t sort_blocks(size_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
 inline size_t scan_blocks(size_t n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK; }
+inline size_t depth_sort_blocks(size_t n) { return (n + SORT_THREADS * DEPTH_SORT_ITEMS - 1) / (SORT_THREADS * DEPTH_SORT_ITEMS); }
+inline size_t emit_blocks(size_t n) { return (n + 255) / 256; }
 
 struct GeomState {
     SplatRec* rec;            // P
@@ -69,6 +72,16 @@ struct GeomState {
     uint32_t* scan_tmp;       // scan_blocks(P) + 8
     uint32_t* ref_partial;    // per preprocess workgroup: bounding-rectangle tile counts, then list-entry counts
     uint32_t* counters;       // 16 words: [0] = instances in the (culled) lists, [1] = reference num_rendered
+    // -- control words of the single-pass sorts (lookback.h).  depth_hist is zeroed by preprocess_kernel (it is
+    //    accumulated by the kernel after it); everything from lb_words on is zeroed by sort_prologue_kernel.
+    uint32_t* depth_hist;     // 4 x 256 digit totals of the depth keys
+    uint32_t* lb_words;       // start of the zero-filled region, n_lb_words long:
+    size_t n_lb_words;
+    uint32_t* tickets;        //   8  arrival counters: [0..3] depth passes, [4] emit, [5..6] tile passes, [7] emit "done"
+    uint32_t* tile_hist;      //   2 x 256 digit totals of the tile ids (written by the last emit workgroup)
+    uint32_t* depth_status;   //   4 x depth_sort_blocks(P) x 256
+    uint32_t* emit_status;    //   emit_blocks(P)
+    uint32_t* hist_copies;    //   64 x 512 private copies of the tile digit histograms (emit kernel)
     static GeomState carve(char* base, size_t P, size_t* bytes) {
         Carver c(base);
         GeomState g;
@@ -85,6 +98,14 @@ struct GeomState {
         g.scan_tmp = c.take<uint32_t>(scan_blocks(P) + 8);
         g.ref_partial = c.take<uint32_t>(2 * ((P + 255) / 256) + 2);
         g.counters = c.take<uint32_t>(16);
+        g.depth_hist = c.take<uint32_t>(4 * 256);
+        g.n_lb_words = 8 + 2 * 256 + 4 * depth_sort_blocks(P) * 256 + emit_blocks(P) + 64 * 512;
+        g.lb_words = c.take<uint32_t>(g.n_lb_words);
+        g.tickets = g.lb_words;
+        g.tile_hist = g.tickets + 8;
+        g.depth_status = g.tile_hist + 2 * 256;
+        g.emit_status = g.depth_status + 4 * depth_sort_blocks(P) * 256;
+        g.hist_copies = g.emit_status + emit_blocks(P);
         if (bytes) *bytes = c.total();
         return g;
     }
@@ -96,10 +117,14 @@ struct BinState {
     uint32_t* id_tmp;       // N  ping-pong partners
     uint32_t* tile_tmp;     // N
     uint32_t* hist;         // RADIX_BINS * sort_blocks(N) + RADIX_BINS
+    uint32_t* tile_status;  // 2 x sort_blocks(N) x 256 look-back words (zeroed by the emit kernel)
+    uint2* ranges_enc;      // tiles: {min position, UINT_MAX - (max position + 1)} per tile, preset to all-ones and
+                            // updated with atomicMin by the final tile-sort pass; decoded into ImageState::ranges
+                            // by the blend forward kernel (an untouched entry = empty tile)
     // The sorted list is the FIRST sub-buffer: its address does not depend on N, so a reader that only knows the
     // buffer (the backward pass) finds it without the length the forward carved with.
     static const uint32_t* list_of(const char* base) { return reinterpret_cast<const uint32_t*>(base); }
-    static BinState carve(char* base, size_t N, size_t* bytes) {
+    static BinState carve(char* base, size_t N, size_t* bytes, size_t tiles = 0) {
         Carver c(base);
         BinState b;
         b.point_list = c.take<uint32_t>(N);   // offset 0 (see list_of)
@@ -107,6 +132,8 @@ struct BinState {
         b.id_tmp = c.take<uint32_t>(N);
         b.tile_tmp = c.take<uint32_t>(N);
         b.hist = c.take<uint32_t>(RADIX_BINS * sort_blocks(N) + RADIX_BINS);
+        b.tile_status = c.take<uint32_t>(2 * sort_blocks(N) * 256);
+        b.ranges_enc = c.take<uint2>(tiles);
         if (bytes) *bytes = c.total();
         return b;
     }
@@ -136,13 +163,15 @@ struct Options {
     int feature_mfma;    // 1: feature contraction on the matrix pipe where a kernel variant exists (default)
     int profile;         // 1: record per-stage HIP events (f3dgs_profile_read)
     int bwd_npix;        // pixels per wave of the blend backward: 0 = automatic, 32/64/128/256
-    int bwd_u;           // pixel bodies interleaved per loop trip of the blend backward: 2 or 4
     int bwd_part_major;  // blend backward workgroup order
     int bwd_strip;       // blend backward: 16x4 strips instead of 8x8 quadrants
     int bwd_wave_cull;   // blend backward: wave-level footprint culling (default 1)
     int fwd_ppl;         // quadrants per wave of the blend forward: 0 = automatic, 1/2/4
     int fwd_variant;     // blend forward chunk/group shape: 0 = default
-    int sort_onesweep;   // 1: single-pass histogram + decoupled look-back scatter (default)
+    int sort_onesweep;   // 1: single-pass radix passes with decoupled look-back (measured slower on MI355X; default 0)
+#ifdef F3DGS_DEV
+    int dev;             // development builds only (make DEV=1): work-skipping experiments, never in a release library
+#endif
 };
 Options& options();
 
@@ -164,7 +193,7 @@ void launch_mark_visible(int P, const float* means3D, const float* view_dev, uin
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull,
-                       hipStream_t s);
+                       bool totals_kernel, hipStream_t s);
 void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D, const int* radii, const float* shs,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
                                 const ViewParams& vp, const GeomState& g, const float* grec, float* dL_dmean2D,
@@ -180,17 +209,24 @@ void launch_exclusive_scan(const uint32_t* in, const uint32_t* gather, uint32_t*
 // Stable LSD radix sort of (key,val) u32 pairs on key bits [0, nbits).  Result lands in (key_out,val_out);
 // (key_in,val_in) and the *_tmp buffers are clobbered.  key_out/val_out may alias the tmp or in buffers
 // only as arranged by the caller through the pass parity (see binning.hip).
+// `ranges_enc` (optional): the final pass records every tile's [min, max + 1) output positions (BinState::ranges_enc)
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
-                             uint32_t* hist, bool result_in_a, hipStream_t s);
+                             uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s);
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
                            uint32_t* inst_tile, uint32_t* inst_id, hipStream_t s);
+// single-pass flavour (option sort_onesweep): offsets by decoupled look-back inside the emit kernel, which also
+// produces the tile digit histograms, presets `ranges` for the final sort pass and zero-fills b.tile_status
+void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,
+                      uint32_t* inst_tile, uint32_t* inst_id, uint32_t N, uint2* ranges, hipStream_t s);
+void launch_sort_prologue(const GeomState& g, size_t P, hipStream_t s);
+void launch_depth_sort_onesweep(const GeomState& g, size_t n, hipStream_t s);
+void launch_tile_sort_onesweep(const GeomState& g, const BinState& b, size_t n, int passes, uint2* ranges, hipStream_t s);
 void launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
                        uint32_t* hist, hipStream_t s);
 void launch_iota(uint32_t* dst, size_t n, hipStream_t s);
-void launch_tile_ranges(size_t N, const uint32_t* tile_sorted, uint2* ranges, size_t tiles, hipStream_t s);
 
 // render_fwd.hip / render_bwd.hip
-void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
+void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc, uint2* ranges, const uint32_t* point_list,
                            const SplatRec* rec, const float* feat, float* final_T,
                            uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, hipStream_t s);
 void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,

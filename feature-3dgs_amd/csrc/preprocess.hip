@@ -12,6 +12,7 @@
 // reference's GLM expressions; operation order inside each 3x3 product is ((p0+p1)+p2).
 
 #include "common.h"
+#include "lookback.h"
 
 namespace f3dgs {
 
@@ -231,8 +232,11 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
                   const float* __restrict__ colors_precomp, ViewParams vp, int* __restrict__ radii,
                   SplatRec* __restrict__ rec, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
-                  uint32_t* __restrict__ depth_key, int cull, uint32_t* __restrict__ ref_partial) {
+                  uint32_t* __restrict__ depth_key, int cull, uint32_t* __restrict__ ref_partial,
+                  uint32_t* __restrict__ depth_hist) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // the digit histograms of the depth sort are accumulated by the NEXT kernel: zero them here (1024 words)
+    if (blockIdx.x < 4) depth_hist[blockIdx.x * 256 + threadIdx.x] = 0;
     int out_radius = 0;
     uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu, bbox_tiles = 0;
     if (i < P) do {
@@ -317,8 +321,11 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = v; wsum[1][threadIdx.x >> 6] = u; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        ref_partial[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-        ref_partial[gridDim.x + blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+        const int nbp = (P + 255) / 256;      // padding workgroups (tiny P) have nothing to report
+        if ((int)blockIdx.x < nbp) {
+            ref_partial[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+            ref_partial[nbp + blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+        }
     }
 }
 
@@ -366,6 +373,91 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
             off++;
         }
     }
+}
+
+
+// Single-pass flavour of scan + emit (option sort_onesweep).  Workgroup vb (ticket order) owns Gaussians
+// [256 vb, 256 vb + 256) of the depth order: it sums their tile counts, obtains its list offset by decoupled
+// look-back (lookback.h) and emits.  On the way it builds the two digit histograms of the tile sort in LDS and
+// adds them to one of HIST_COPIES private global copies (same-line global atomics serialise at 25-100 ns apiece
+// on MI355X, so thousands of workgroups must not meet on 32 cache lines), clears the look-back words of the tile
+// sort and presets the encoded tile ranges (BinState::ranges_enc) for the final sort pass; the workgroup
+// that finishes LAST folds the histogram copies into the totals the sort passes read.
+constexpr int HIST_COPIES = 64;
+
+__global__ void __launch_bounds__(256)
+emit_scan_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
+                 const SplatRec* __restrict__ rec, int gx, int gy, int cull, uint32_t* __restrict__ inst_tile,
+                 uint32_t* __restrict__ inst_id, uint32_t* __restrict__ tickets, uint32_t* __restrict__ status,
+                 uint32_t* __restrict__ hist_copies, uint32_t* __restrict__ zero_words, size_t n_zero,
+                 uint32_t* __restrict__ tile_hist, uint2* __restrict__ ranges) {
+    __shared__ uint32_t sh[8];
+    __shared__ uint32_t s_vb, s_base, s_last;
+    __shared__ uint32_t h[2][256];
+    if (threadIdx.x == 0) s_vb = atomicAdd(&tickets[4], 1u);
+    h[0][threadIdx.x] = 0;
+    h[1][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t vb = s_vb;
+    for (size_t k = (size_t)vb * 256 + threadIdx.x; k < n_zero; k += (size_t)gridDim.x * 256) zero_words[k] = 0;
+    const uint32_t tiles = (uint32_t)(gx * gy);
+    for (uint32_t t = vb * 256 + threadIdx.x; t < tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    const int i = (int)(vb * 256 + threadIdx.x);
+    uint32_t g = 0, cnt = 0;
+    if (i < P) {
+        g = order[i];
+        cnt = tiles_touched[g];
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_256(cnt, sh, &tot);
+    if (threadIdx.x < 64) {
+        const uint32_t base = lookback_wave(status, vb, tot, (int)threadIdx.x);
+        if (threadIdx.x == 0) s_base = base;
+    }
+    __syncthreads();
+    if (cnt) {
+        uint32_t off = s_base + ex;
+        const float4 q0 = rec[g].q0, q1 = rec[g].q1;
+        const int radius = __float_as_int(rec[g].q2.z);  // integer bits stored by preprocess_kernel
+        int x0, y0, x1, y1;
+        tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
+        const CullParams ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+        const float cdet_inv = 1.0f / (q0.z * q1.x - q0.w * q0.w);
+        for (int y = y0; y < y1; y++) {
+            int xa = x0, xb = x1 - 1;
+            if (cull && !row_span(ck, cdet_inv, y, x0, x1, xa, xb)) continue;
+            for (int x = xa; x <= xb; x++) {
+                const uint32_t t = (uint32_t)(y * gx + x);
+                inst_tile[off] = t;
+                inst_id[off] = g;
+                atomicAdd(&h[0][t & 255], 1u);
+                atomicAdd(&h[1][(t >> 8) & 255], 1u);
+                off++;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t* mine = hist_copies + (size_t)(vb % HIST_COPIES) * 512;
+        const uint32_t c0 = h[0][threadIdx.x], c1 = h[1][threadIdx.x];
+        if (c0) atomicAdd(&mine[threadIdx.x], c0);
+        if (c1) atomicAdd(&mine[256 + threadIdx.x], c1);
+    }
+    // ---- last workgroup out: fold the copies ----------------------------------------------------------------
+    // (workgroup-scope release = "my atomics above have been acknowledged"; they are performed at the memory side,
+    // so no L2 write-back is needed - an agent-scope fence here would flush the 40 MB this kernel just wrote)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[7], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    uint32_t a0 = 0, a1 = 0;
+    for (int c = 0; c < HIST_COPIES; c++) {
+        a0 += lb_load(&hist_copies[(size_t)c * 512 + threadIdx.x]);
+        a1 += lb_load(&hist_copies[(size_t)c * 512 + 256 + threadIdx.x]);
+    }
+    tile_hist[threadIdx.x] = a0;
+    tile_hist[256 + threadIdx.x] = a1;
 }
 
 // ---- backward: K8 (cov2D) + K9 (mean / SH / cov3D) fused, one thread per Gaussian ---------------------
@@ -631,17 +723,29 @@ void launch_mark_visible(int P, const float* means3D, const float* view_dev, uin
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales, rotations,
+                       bool totals_kernel, hipStream_t s) {
+    // at least 4 workgroups so that the depth_hist zero-fill above is complete even for tiny P
+    const int grid = max(4, (P + 255) / 256);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, P, D, M, means3D, scales, rotations,
                        opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped, g.tiles_touched,
-                       g.depth_key, cull, g.ref_partial);
-    hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(256), 0, s, g.ref_partial, (P + 255) / 256, g.counters);
+                       g.depth_key, cull, g.ref_partial, g.depth_hist);
+    // (the single-pass sort computes the totals in its prologue kernel instead)
+    if (totals_kernel)
+        hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(256), 0, s, g.ref_partial, (P + 255) / 256, g.counters);
 }
 
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
                            uint32_t* inst_tile, uint32_t* inst_id, hipStream_t s) {
     hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.offsets,
                        g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id);
+}
+
+void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,
+                      uint32_t* inst_tile, uint32_t* inst_id, uint32_t N, uint2* ranges, hipStream_t s) {
+    const size_t n_zero = 2 * sort_blocks(N) * 256;
+    hipLaunchKernelGGL(emit_scan_kernel, dim3(emit_blocks(P)), dim3(256), 0, s, P, order, g.tiles_touched, g.rec, gx, gy,
+                       cull, inst_tile, inst_id, g.tickets, g.emit_status, g.hist_copies, b.tile_status, n_zero,
+                       g.tile_hist, ranges);
 }
 
 void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D, const int* radii, const float* shs,

@@ -51,6 +51,9 @@ struct BwdArgs {
     int part_major;  // workgroup -> (tile, part) order, see kernel
     int strip;        // NPIX = 64: 16x4 pixel strips instead of 8x8 quadrants
     int no_wave_cull; // option bwd_wave_cull = 0: no wave-level footprint culling / compaction
+#ifdef F3DGS_DEV
+    int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs
+#endif
 };
 
 // ---- paired DPP prefix scans --------------------------------------------------------------------------
@@ -124,6 +127,12 @@ struct BwdLds {
     static constexpr int FS = MF ? 11 : FLUSH_STRIDE;   // MF: only the 10 geometric sums travel through LDS
     float flush[64 * FS];
 };
+
+#ifdef F3DGS_DEV
+#define F3DGS_DEV_SKIP(bit) (a.dev & (bit))
+#else
+#define F3DGS_DEV_SKIP(bit) false      // release builds: compiled out
+#endif
 
 struct SplatLane { // one chunk entry per lane
     float mx, my, ca, cb, cc, op, cr, cg, cbl, dep;
@@ -231,6 +240,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
             // pixels still alive at this depth (lane = pixel for the ballot); two bodies per trip: ILP for the
             // scans, and the K = 2 of the MFMA
             unsigned long long live = __ballot(v_last[it] > pos_min);
+            if (F3DGS_DEV_SKIP(2)) { touched = sl.have; live = 0; }
             while (live) {
                 // take up to U live pixels; missing ones repeat the first with n_contrib = 0 (inert bodies)
                 int qi[U];
@@ -326,7 +336,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                         }
                     }
                 }
-                if constexpr (MF) {
+                if constexpr (MF) if (!F3DGS_DEV_SKIP(4)) {
                     // A = W^T block: rows = instances, k = two pixels.  One half-wave swap builds both 32-instance
                     // operands:  X = [w_a lanes 0-31 | w_b lanes 0-31],  Y = [w_a lanes 32-63 | w_b lanes 32-63].
 #pragma unroll
@@ -345,7 +355,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
 
         // ---- flush this chunk: transpose through LDS in groups of 16 values, coalesced atomics -----------
         const unsigned long long tmask = __ballot(touched);
-        if (tmask == 0) return;
+        if (tmask == 0 || F3DGS_DEV_SKIP(1)) return;
         L.flush[lane * Lds::FS + Lds::FS - 1] = __uint_as_float(gid);   // the stride's padding column carries the ids
         constexpr int CHF = MF ? 0 : CH;            // feature channels that travel through the LDS transpose
         constexpr int NG = (CHF + 10 + FLUSH_GROUP - 1) / FLUSH_GROUP;
@@ -471,10 +481,7 @@ template <int CH, int NPIX, bool MF>
 void launch_one(const BwdArgs& a, hipStream_t s) {
     const size_t lds = sizeof(BwdLds<CH, NPIX, MF>);
     const dim3 grid(a.gx * a.gy * (256 / NPIX));
-    if (options().bwd_u == 2)
-        hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 2>), grid, dim3(64), lds, s, a);
-    else
-        hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4>), grid, dim3(64), lds, s, a);
+    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4>), grid, dim3(64), lds, s, a);
 }
 
 template <int CH, bool MF>
@@ -499,6 +506,9 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     a.dL_ddepth = dL_ddepth; a.grec = grec; a.dL_dfeature = dL_dfeature;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
     const Options& opt = options();
+#ifdef F3DGS_DEV
+    a.dev = opt.dev;
+#endif
     const int npix = opt.bwd_npix ? opt.bwd_npix : 64;
     a.part_major = opt.bwd_part_major;
     a.no_wave_cull = !opt.bwd_wave_cull;

@@ -31,7 +31,8 @@ struct FwdChunk {
 };
 
 struct FwdArgs {
-    const uint2* ranges;
+    const uint2* ranges_enc;   // BinState::ranges_enc, decoded into `ranges` by the launch that has write_base set
+    uint2* ranges;
     const uint32_t* point_list;
     const SplatRec* rec;
     const float* feat;
@@ -58,7 +59,14 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
 
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const uint2 rg = a.ranges[tile];
+    uint2 rg;
+    if (a.write_base) {   // first channel window: decode {min, UINT_MAX - (max + 1)}; untouched = empty tile
+        const uint2 e = a.ranges_enc[tile];
+        rg = e.x == 0xFFFFFFFFu ? make_uint2(0u, 0u) : make_uint2(e.x, 0xFFFFFFFFu - e.y);
+        if (threadIdx.x == 0) a.ranges[tile] = rg;
+    } else {
+        rg = a.ranges[tile];
+    }
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x), r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
 
     const int lx = lane & 7, ly = lane >> 3;
@@ -233,7 +241,14 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
 
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const uint2 rg = a.ranges[tile];
+    uint2 rg;
+    if (a.write_base) {   // first channel window: decode {min, UINT_MAX - (max + 1)}; untouched = empty tile
+        const uint2 e = a.ranges_enc[tile];
+        rg = e.x == 0xFFFFFFFFu ? make_uint2(0u, 0u) : make_uint2(e.x, 0xFFFFFFFFu - e.y);
+        if (threadIdx.x == 0) a.ranges[tile] = rg;
+    } else {
+        rg = a.ranges[tile];
+    }
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x), r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
 
     // pixel-centre rectangle covered by this wave (PPL quadrants): used by the wave-level footprint test
@@ -470,11 +485,11 @@ void launch_one(const FwdArgs& a, hipStream_t s) {
 
 }  // namespace
 
-void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
+void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc, uint2* ranges, const uint32_t* point_list,
                            const SplatRec* rec, const float* feat, float* final_T,
                            uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, hipStream_t s) {
     FwdArgs a;
-    a.ranges = ranges; a.point_list = point_list; a.rec = rec; a.feat = feat;
+    a.ranges_enc = ranges_enc; a.ranges = ranges; a.point_list = point_list; a.rec = rec; a.feat = feat;
     a.bg = vp.bg;
     a.final_T = final_T; a.n_contrib = n_contrib; a.out_color = out_color; a.out_feat = out_feat;
     a.out_depth = out_depth;

@@ -19,7 +19,9 @@ def c3():
     return make_scene(seed=1, **CONFIGS["c3"])
 
 
-def test_c3_lists_are_sorted_and_consistent(c3, option):
+@pytest.mark.parametrize("onesweep", [0, 1], ids=["three-kernel-passes", "single-pass-lookback"])
+def test_c3_lists_are_sorted_and_consistent(c3, onesweep, option):
+    option("sort_onesweep", onesweep)
     lib = _lib()
     for cull in ("0", "1"):
         option("tile_cull", int(cull))

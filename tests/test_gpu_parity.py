@@ -56,9 +56,11 @@ def _read(lib, what, scene, res, dtype, count):
     return out
 
 
+@pytest.mark.parametrize("onesweep", [0, 1], ids=["three-kernel-passes", "single-pass-lookback"])
 @pytest.mark.parametrize("seed,P,W,H,C", [(1, 5000, 256, 256, 3), (2, 20000, 320, 200, 16), (3, 3000, 97, 61, 32)])
-def test_binning_is_bit_exact(seed, P, W, H, C, option):
+def test_binning_is_bit_exact(seed, P, W, H, C, onesweep, option):
     option("tile_cull", 0)   # reference-identical instance lists
+    option("sort_onesweep", onesweep)
     scene = _scene(P=P, C=C, width=W, height=H, seed=seed, scale_lo=0.005, scale_hi=0.08)
     o, want, _ = run_oracle(scene, backward=False)
     res = _raw_forward(scene)
