@@ -73,6 +73,10 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 // would have been skipped for every pixel, so images, gradients and radii are unchanged; only the private
 // instance lists get shorter.  The count and the emission run the same code in this translation unit
 // (no contraction), so they always agree.
+// conditioning of the conic, clamped to [1, 1e6] (a NaN from a degenerate conic falls back to 1)
+__device__ __forceinline__ float cull_kappa(float ca, float cb, float cc) {
+    return fminf(fmaxf((ca * cc) / (ca * cc - cb * cb), 1.0f), 1e6f);
+}
 struct CullParams {
     float mx, my, a, b, c, thresh;   // thresh = 2 * (ln(255 o) + margin); negative => never visible
 };
@@ -80,7 +84,11 @@ __device__ __forceinline__ CullParams make_cull(float mx, float my, float ca, fl
     CullParams k;
     k.mx = mx; k.my = my; k.a = ca; k.b = cb; k.c = cc;
     const float s = 255.0f * opacity;
-    k.thresh = s > 1.0f ? 2.0f * (logf(s) * 1.0001f + 1e-3f) : -1.0f;
+    // The blend kernels evaluate the quadratic form in fp32; at a pixel ON the threshold ellipse its three terms are as
+    // large as kappa * thresh with kappa = a c / det >= 1 (thin splats at an angle: the terms cancel), so their round-off
+    // is ~ eps * kappa * thresh.  The threshold is inflated by 32 eps kappa on top of the fixed margin: a needle-shaped
+    // splat keeps every tile it could blend in.
+    k.thresh = s > 1.0f ? 2.0f * (logf(s) * 1.0001f + 1e-3f) * (1.0f + 2e-6f * cull_kappa(ca, cb, cc)) : -1.0f;
     return k;
 }
 __device__ __forceinline__ float quad_form(const CullParams& k, float dx, float dy) {
@@ -585,97 +593,102 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
             q = reinterpret_cast<const float4*>(rotations)[si];
             cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov6);
         }
-        // ---- conic -> cov2D -> (cov3D, t) --------------------------------------------------------
+        // ---- conic -> cov2D -> (cov3D, t), in matrix form ------------------------------------------------
+        // Notation: A = J W (2x3, rows = screen axes), S = cov3D (symmetric 3x3), C = A S A^T + 0.3 I, conic = C^-1.
+        // ewa_setup keeps A transposed: A[i][k] = e.T.v[k][i]; W[m][l] = e.Wm.v[l][m].
+        //   dL/dC   = -C^-1 Gk C^-1          Gk = [[dca, dcb], [dcb, dcc]]  (the blend backward accumulates the
+        //                                    off-diagonal conic parameter once, so it enters both entries whole)
+        //   dL/dS   = A^T (dL/dC) A          (off-diagonal pairs of the six-parameter form add up)
+        //   dL/dA   = 2 (dL/dC) A S
+        //   dL/dJ   = (dL/dA) W^T            of which only J00, J02, J11, J12 depend on t
         const Ewa e = ewa_setup(mean, vp, cov6);
-        float a, b, c;
-        ewa_cov(e, a, b, c);
-        const float dca = gr[2], dcb = gr[3], dcc = gr[4];
-        const float denom = a * c - b * b;
-        float dL_da = 0, dL_db = 0, dL_dc = 0;
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        // column i / row j of the reference's GLM matrices = (row j, col i) here
-#define TT(i, j) e.T.v[j][i]
-#define VV(i, j) e.Vrk.v[j][i]
-#define WW(i, j) e.Wm.v[j][i]
-        if (denom2inv != 0) {
-            dL_da = denom2inv * (-c * c * dca + 2 * b * c * dcb + (denom - a * c) * dcc);
-            dL_dc = denom2inv * (-a * a * dcc + 2 * a * b * dcb + (denom - a * c) * dca);
-            dL_db = denom2inv * 2 * (b * c * dca - (denom + 2 * b * b) * dcb + a * b * dcc);
-            dcov6[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
-            dcov6[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
-            dcov6[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
-            dcov6[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
-            dcov6[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
-            dcov6[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+        float ca, cb, cc;
+        ewa_cov(e, ca, cb, cc);
+        const float det = ca * cc - cb * cb;
+        const float det2inv = 1.0f / ((det * det) + 0.0000001f);   // the reference's regularised 1 / det^2
+        // adj(C) = det * conic; dL/dC = -adj Gk adj / det^2 (symmetric: three entries)
+        const float k00 = cc, k01 = -cb, k11 = ca;
+        const float m00 = k00 * gr[2] + k01 * gr[3], m01 = k00 * gr[3] + k01 * gr[4];
+        const float m10 = k01 * gr[2] + k11 * gr[3], m11 = k01 * gr[3] + k11 * gr[4];
+        const float gC[2][2] = {{-(m00 * k00 + m01 * k01) * det2inv, -(m00 * k01 + m01 * k11) * det2inv},
+                                {-(m10 * k00 + m11 * k01) * det2inv, -(m10 * k01 + m11 * k11) * det2inv}};
+        float A[2][3], B[2][3];        // B = (dL/dC) A
+#pragma unroll
+        for (int k = 0; k < 3; k++) { A[0][k] = e.T.v[k][0]; A[1][k] = e.T.v[k][1]; }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) B[i][k] = gC[i][0] * A[0][k] + gC[i][1] * A[1][k];
+        float dS[3][3];                // A^T B
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int l = 0; l < 3; l++) dS[k][l] = A[0][k] * B[0][l] + A[1][k] * B[1][l];
+        dcov6[0] = dS[0][0]; dcov6[1] = dS[0][1] + dS[1][0]; dcov6[2] = dS[0][2] + dS[2][0];
+        dcov6[3] = dS[1][1]; dcov6[4] = dS[1][2] + dS[2][1]; dcov6[5] = dS[2][2];
+        float dJ[2][3];                // 2 B S W^T
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float dA[3];
+#pragma unroll
+            for (int l = 0; l < 3; l++)
+                dA[l] = 2.0f * (B[i][0] * e.Vrk.v[0][l] + B[i][1] * e.Vrk.v[1][l] + B[i][2] * e.Vrk.v[2][l]);
+#pragma unroll
+            for (int m = 0; m < 3; m++) dJ[i][m] = dA[0] * e.Wm.v[0][m] + dA[1] * e.Wm.v[1][m] + dA[2] * e.Wm.v[2][m];
         }
-        const float dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
-                           (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
-        const float dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
-                           (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
-        const float dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
-                           (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
-        const float dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
-                           (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
-        const float dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
-                           (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
-        const float dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
-                           (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
-        const float dJ00 = WW(0, 0) * dT00 + WW(0, 1) * dT01 + WW(0, 2) * dT02;
-        const float dJ02 = WW(2, 0) * dT00 + WW(2, 1) * dT01 + WW(2, 2) * dT02;
-        const float dJ11 = WW(1, 0) * dT10 + WW(1, 1) * dT11 + WW(1, 2) * dT12;
-        const float dJ12 = WW(2, 0) * dT10 + WW(2, 1) * dT11 + WW(2, 2) * dT12;
-#undef TT
-#undef VV
-#undef WW
-        const float tz = 1.f / e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
-        const float xm = e.clamp_x ? 0.f : 1.f, ym = e.clamp_y ? 0.f : 1.f;
-        const float dtx = xm * -vp.fx * tz2 * dJ02;
-        const float dty = ym * -vp.fy * tz2 * dJ12;
-        const float dtz = -vp.fx * tz2 * dJ00 - vp.fy * tz2 * dJ11 + (2 * vp.fx * e.t[0]) * tz3 * dJ02 +
-                          (2 * vp.fy * e.t[1]) * tz3 * dJ12;
-        const float* m = vp.view;
-        dmean.x = m[0] * dtx + m[1] * dty + m[2] * dtz;
-        dmean.y = m[4] * dtx + m[5] * dty + m[6] * dtz;
-        dmean.z = m[8] * dtx + m[9] * dty + m[10] * dtz;
-        // ---- screen-space mean + depth -> 3D mean -----------------------------------------------
-        const float* pr = vp.proj;
-        const float mhw = pr[3] * mean.x + pr[7] * mean.y + pr[11] * mean.z + pr[15];
-        const float mw = 1.0f / (mhw + 0.0000001f);
-        const float mul1 = (pr[0] * mean.x + pr[4] * mean.y + pr[8] * mean.z + pr[12]) * mw * mw;
-        const float mul2 = (pr[1] * mean.x + pr[5] * mean.y + pr[9] * mean.z + pr[13]) * mw * mw;
-        const float gx2 = gr[0], gy2 = gr[1];
-        V3 dm;
-        dm.x = (pr[0] * mw - pr[3] * mul1) * gx2 + (pr[1] * mw - pr[3] * mul2) * gy2;
-        dm.y = (pr[4] * mw - pr[7] * mul1) * gx2 + (pr[5] * mw - pr[7] * mul2) * gy2;
-        dm.z = (pr[8] * mw - pr[11] * mul1) * gx2 + (pr[9] * mw - pr[11] * mul2) * gy2;
-        const float dz = gr[9];
-        dm.x += dz * vp.view[2]; dm.y += dz * vp.view[6]; dm.z += dz * vp.view[10];
-        dmean.x += dm.x; dmean.y += dm.y; dmean.z += dm.z;
-        // ---- cov3D -> scale / rotation ------------------------------------------------------------
+        // J = [[fx/tz, 0, -fx tx/tz^2], [0, fy/tz, -fy ty/tz^2]]; the frustum clamp of tx, ty is a constant (Q7)
+        const float itz = 1.f / e.t[2], itz2 = itz * itz, itz3 = itz2 * itz;
+        V3 dt;
+        dt.x = e.clamp_x ? 0.f : -vp.fx * itz2 * dJ[0][2];
+        dt.y = e.clamp_y ? 0.f : -vp.fy * itz2 * dJ[1][2];
+        dt.z = -itz2 * (vp.fx * dJ[0][0] + vp.fy * dJ[1][1]) + 2.0f * itz3 * (vp.fx * e.t[0] * dJ[0][2] + vp.fy * e.t[1] * dJ[1][2]);
+        // t = W p + const  ->  dL/dp = W^T dL/dt
+        dmean.x = e.Wm.v[0][0] * dt.x + e.Wm.v[0][1] * dt.y + e.Wm.v[0][2] * dt.z;
+        dmean.y = e.Wm.v[1][0] * dt.x + e.Wm.v[1][1] * dt.y + e.Wm.v[1][2] * dt.z;
+        dmean.z = e.Wm.v[2][0] * dt.x + e.Wm.v[2][1] * dt.y + e.Wm.v[2][2] * dt.z;
+        // ---- screen-space mean + depth -> 3D mean ------------------------------------------------------------
+        // ndc = h.xy / (h.w + eps) with h = P p: quotient rule, dL/dp = (P_x^T g_x + P_y^T g_y) / w - (g . h.xy) P_w^T / w^2
+        const float* pr = vp.proj;      // element (row r, col c) at [4c + r]
+        const float hx = pr[0] * mean.x + pr[4] * mean.y + pr[8] * mean.z + pr[12];
+        const float hy = pr[1] * mean.x + pr[5] * mean.y + pr[9] * mean.z + pr[13];
+        const float hw = pr[3] * mean.x + pr[7] * mean.y + pr[11] * mean.z + pr[15];
+        const float iw = 1.0f / (hw + 0.0000001f);
+        const float gh = (gr[0] * hx + gr[1] * hy) * iw * iw;
+        const float gxw = gr[0] * iw, gyw = gr[1] * iw, dz = gr[9];
+        dmean.x += pr[0] * gxw + pr[1] * gyw - pr[3] * gh + dz * vp.view[2];
+        dmean.y += pr[4] * gxw + pr[5] * gyw - pr[7] * gh + dz * vp.view[6];
+        dmean.z += pr[8] * gxw + pr[9] * gyw - pr[11] * gh + dz * vp.view[10];
+        // ---- cov3D -> scale / rotation -------------------------------------------------------------------------
+        // S = L L^T with L = R diag(s), s = modifier * scale:  dL/dL = 2 G L  (G = symmetric per-entry gradient),
+        // dL/ds_k = column k of dL/dL . column k of R  (returned w.r.t. s, as the reference does),  dL/dR = dL/dL diag(s).
         if (scales) {
-            const float r = q.x, x = q.y, y = q.z, z = q.w;
             const M3 R = quat_to_rot(q);
-            const float s[3] = {vp.scale_modifier * sc.x, vp.scale_modifier * sc.y, vp.scale_modifier * sc.z};
-            M3 M2, dS;
+            const float sv[3] = {vp.scale_modifier * sc.x, vp.scale_modifier * sc.y, vp.scale_modifier * sc.z};
+            const float G[3][3] = {{dcov6[0], 0.5f * dcov6[1], 0.5f * dcov6[2]},
+                                   {0.5f * dcov6[1], dcov6[3], 0.5f * dcov6[4]},
+                                   {0.5f * dcov6[2], 0.5f * dcov6[4], dcov6[5]}};
+            float dR[3][3];
 #pragma unroll
-            for (int k = 0; k < 3; k++)
+            for (int k = 0; k < 3; k++) {
+                float dLk[3];          // column k of 2 G L
+                dscale[k] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 3; j++) M2.v[k][j] = 2.0f * (s[k] * R.v[j][k]);
-            dS.v[0][0] = dcov6[0]; dS.v[0][1] = 0.5f * dcov6[1]; dS.v[0][2] = 0.5f * dcov6[2];
-            dS.v[1][0] = 0.5f * dcov6[1]; dS.v[1][1] = dcov6[3]; dS.v[1][2] = 0.5f * dcov6[4];
-            dS.v[2][0] = 0.5f * dcov6[2]; dS.v[2][1] = 0.5f * dcov6[4]; dS.v[2][2] = dcov6[5];
-            M3 dM = mul3(M2, dS);
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                dscale[k] = R.v[0][k] * dM.v[k][0] + R.v[1][k] * dM.v[k][1] + R.v[2][k] * dM.v[k][2];
-#pragma unroll
-            for (int j = 0; j < 3; j++) { dM.v[0][j] *= s[0]; dM.v[1][j] *= s[1]; dM.v[2][j] *= s[2]; }
-#define DM(a, b) dM.v[a][b]
-            drot[0] = 2 * z * (DM(0, 1) - DM(1, 0)) + 2 * y * (DM(2, 0) - DM(0, 2)) + 2 * x * (DM(1, 2) - DM(2, 1));
-            drot[1] = 2 * y * (DM(1, 0) + DM(0, 1)) + 2 * z * (DM(2, 0) + DM(0, 2)) + 2 * r * (DM(1, 2) - DM(2, 1)) - 4 * x * (DM(2, 2) + DM(1, 1));
-            drot[2] = 2 * x * (DM(1, 0) + DM(0, 1)) + 2 * r * (DM(2, 0) - DM(0, 2)) + 2 * z * (DM(1, 2) + DM(2, 1)) - 4 * y * (DM(2, 2) + DM(0, 0));
-            drot[3] = 2 * r * (DM(0, 1) - DM(1, 0)) + 2 * x * (DM(2, 0) + DM(0, 2)) + 2 * y * (DM(1, 2) + DM(2, 1)) - 4 * z * (DM(1, 1) + DM(0, 0));
-#undef DM
+                for (int i = 0; i < 3; i++) {
+                    dLk[i] = 2.0f * sv[k] * (G[i][0] * R.v[0][k] + G[i][1] * R.v[1][k] + G[i][2] * R.v[2][k]);
+                    dscale[k] += dLk[i] * R.v[i][k];
+                    dR[i][k] = dLk[i] * sv[k];
+                }
+            }
+            // R(q) for the un-normalised q = (r, v): with Y = dR + dR^T (off-diagonal) and the axial vector
+            // w = (dR21 - dR12, dR02 - dR20, dR10 - dR01):
+            //   dL/dr = 2 v . w,   dL/dv = 2 (Y v + r w) - 4 v * (trace(dR) - diag(dR))
+            const float r = q.x, vx = q.y, vy = q.z, vz = q.w;
+            const float wx = dR[2][1] - dR[1][2], wy = dR[0][2] - dR[2][0], wz = dR[1][0] - dR[0][1];
+            const float y01 = dR[0][1] + dR[1][0], y02 = dR[0][2] + dR[2][0], y12 = dR[1][2] + dR[2][1];
+            drot[0] = 2.0f * (vx * wx + vy * wy + vz * wz);
+            drot[1] = 2.0f * (y01 * vy + y02 * vz + r * wx) - 4.0f * vx * (dR[1][1] + dR[2][2]);
+            drot[2] = 2.0f * (y01 * vx + y12 * vz + r * wy) - 4.0f * vy * (dR[0][0] + dR[2][2]);
+            drot[3] = 2.0f * (y02 * vx + y12 * vy + r * wz) - 4.0f * vz * (dR[0][0] + dR[1][1]);
         }
     }
     // ---- SH gradients (writes all M coefficients; zero where unused / culled) ---------------------

@@ -56,7 +56,9 @@ __device__ __forceinline__ bool rect_hit(float mx, float my, float ca, float cb,
                                          float x1, float y0, float y1) {
     const float s = 255.0f * opacity;
     if (!(s > 1.0f)) return false;
-    const float thresh = 2.0f * (__logf(s) * 1.0001f + 2e-3f);
+    // + 32 eps * kappa: fp32 round-off of the quadratic form of needle-shaped splats (see make_cull, preprocess.hip)
+    const float kappa = fminf(fmaxf((ca * cc) * __builtin_amdgcn_rcpf(ca * cc - cb * cb), 1.0f), 1e6f);
+    const float thresh = 2.0f * (__logf(s) * 1.0001f + 2e-3f) * (1.0f + 2e-6f * kappa);
     const float xlo = mx - x1, xhi = mx - x0, ylo = my - y1, yhi = my - y0;
     if (xlo <= 0.0f && xhi >= 0.0f && ylo <= 0.0f && yhi >= 0.0f) return true;
     const float ia = __builtin_amdgcn_rcpf(ca), ic = __builtin_amdgcn_rcpf(cc);

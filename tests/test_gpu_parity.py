@@ -228,11 +228,20 @@ def test_rotated_view_and_scale_modifier():
     _strict_compare(scene)
 
 
-@pytest.mark.parametrize("seed,P,W,H,C", [(31, 30000, 320, 192, 8), (32, 4000, 64, 64, 4)])
-def test_tile_culling_changes_lists_not_results(seed, P, W, H, C, option):
+@pytest.mark.parametrize("seed,P,W,H,C,needles", [(31, 30000, 320, 192, 8, False), (32, 4000, 64, 64, 4, False),
+                                                  (33, 20000, 640, 360, 8, True)])
+def test_tile_culling_changes_lists_not_results(seed, P, W, H, C, needles, option):
     """Default mode drops instances whose 1/255 ellipse misses the tile: shorter private lists, the
-    reference's num_rendered, and BIT-identical images (same blends in the same order)."""
+    reference's num_rendered, and BIT-identical images (same blends in the same order).  `needles`: splats hundreds of
+    pixels long and a fraction of a pixel wide at random angles - the fp32 round-off of the blend's quadratic form is
+    largest there, the culling margins must still keep every tile that blends."""
     scene = _scene(P=P, C=C, width=W, height=H, seed=seed, scale_lo=0.005, scale_hi=0.15)
+    if needles:
+        g = torch.Generator().manual_seed(seed)
+        long_axis = torch.randint(0, 3, (P,), generator=g)
+        sc = torch.full((P, 3), 0.0015)
+        sc[torch.arange(P), long_axis] = torch.exp(torch.rand(P, generator=g) * 2.0 - 1.5)      # 0.22 .. 1.6 world units
+        scene["scales"] = sc.contiguous()
     lib = _lib()
     option("tile_cull", 0)
     ref = _raw_forward(scene)
