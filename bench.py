@@ -1,20 +1,31 @@
 #!/usr/bin/env python
-"""bench.py — headline benchmark of the MI355X-native Feature-3DGS rasterizer.
+"""bench.py - headline benchmark of the MI355X-native Feature-3DGS rasterizer.
 
 Metric (BASELINE.json): train-step ms + rendered Mpix/s of one rasterizer forward+backward per view,
 1M synthetic Gaussians @1920x1080, SH degree 3, feat_dim=32 (config "c3"), inputs resident in HBM.
 A "step" is one forward + one backward of the op over one view per GPU (everything inside the op:
-buffer sizing, the 4-byte num_rendered read-back, output/gradient allocation; no loss, no optimiser).
+buffer sizing, the 8-byte instance-count read-back, output/gradient allocation; no loss, no optimiser),
+with a FRESH set of upstream gradients every step (a rotating pool generated before the timed region).
 With N > 1 GPUs every rank renders its own view of the same Gaussians (view r is rotated r*5 degrees)
-and the per-Gaussian gradients ((59+C) floats each) are summed with a RCCL all-reduce inside the step.
+and the per-Gaussian gradients ((59+C) floats each) are summed over RCCL inside the step; the feature
+gradient's all-reduce starts inside the backward pass (dp.FeatureGradOverlap).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1..c5] [--no-cpu-baseline] [--comm-only]
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel: algorithmic bytes per launch
-(restated in DESIGN.md) over its mean duration measured with HIP events on the
-op's stream inside the timed region.  `cpu_baseline` is the scalar CPU oracle (a port, 1 core) timed
-on a bounded sample of the same workload.
+`--gpus N` with N > 1 needs one process per GPU: started under torch.distributed.run it uses the ranks it is
+given; started plainly it re-launches itself under torch.distributed.run (same arguments) and relays that
+run's JSON line - it never reports a number measured on fewer GPUs than asked for.
+
+Rank 0 prints ONE JSON line.  What is measured where:
+  * `value` / `ms_per_step`: wall clock of exactly K steps between barrier + synchronize pairs, max over ranks
+    (the contract); `step_ms` adds the per-step distribution (median, p10, p90) from HIP events on the op's stream.
+  * `roofline`: the dominant kernel's ALGORITHMIC bytes per launch (restated in DESIGN.md)
+    over its mean duration, measured live with HIP events recorded by the library around every stage on the
+    stream the kernels run on, inside the timed region.  `traffic` is null: HBM counters cannot be read from
+    inside this process; the separately profiled figure is quoted under `profiled` with its source file.
+  * `cpu_baseline`: the scalar C++ oracle (a port, 1 core) on a bounded sample of the same workload;
+    `cpu_reference_path_c1`: BASELINE.json config 1 - the PyTorch-CPU autograd restatement on all host cores
+    next to the product on the GPU, both at c1 (SURVEY.md 8(d) "CPU reference timing").
 """
 from __future__ import annotations
 
@@ -22,6 +33,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,13 +42,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "feature-3dgs_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
-os.environ.setdefault("F3DGS_PROFILE", "1")          # event spans around every stage (no syncs inside the op)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz, un-packed fp32 (157.3 with v_pk_fma)
 
 
 def algorithmic_bytes(P, Pv, N, N_r, HW, tiles, C, M=16):
@@ -56,6 +66,8 @@ def algorithmic_bytes(P, Pv, N, N_r, HW, tiles, C, M=16):
 def scene_stats(scene, dev):
     """One untimed forward through _C to obtain Pv, N and N_r (= sum over tiles of the deepest list
     position any pixel of the tile blends, from the n_contrib plane)."""
+    import numpy as np
+    import torch
     from diff_gaussian_rasterization import _C
     t = lambda x: x.to(dev)
     e = torch.Tensor([])
@@ -102,39 +114,72 @@ def cpu_baseline(cfg_kw):
                       f"feat_dim={kw['C']} (the workload with 1/5 of the Gaussians), {dt:.1f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c3")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--feat-dim", type=int, default=None, help="override the config's feature dim (development)")
-    args = ap.parse_args()
+def cpu_reference_path_c1(dev):
+    """BASELINE.json config 1 (10k Gaussians, 256x256, RGB only): the PyTorch-CPU autograd restatement on the host
+    cores and the product on the GPU at the same config.  SURVEY.md 8(d) asks for torch.set_num_threads(all cores);
+    on the 256-core GPU host that setting makes the restatement 700x SLOWER than 8 threads (259 s vs 0.34 s per step,
+    measured: thread wake-ups on thousands of tiny per-tile tensors), so the thread count is swept over 1 / 8 / 32
+    under a time budget and the best is reported next to the all-cores observation."""
+    import statistics
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    import torch
+    from oracle import torch_oracle
+    from synth import CONFIGS, make_scene
+    sc = make_scene(seed=0, **CONFIGS["c1"])
+    cores = os.cpu_count() or 1
+    old = torch.get_num_threads()
+    sweep = {}
+    budget_end = time.perf_counter() + 25.0
+    try:
+        for n in sorted({1, min(8, cores), min(32, cores)}):
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            torch_oracle.forward_backward(sc, dtype=torch.float32)          # warm-up
+            warm = time.perf_counter() - t0
+            times = []
+            while len(times) < 5 and time.perf_counter() + warm < budget_end:
+                t0 = time.perf_counter()
+                torch_oracle.forward_backward(sc, dtype=torch.float32)
+                times.append(time.perf_counter() - t0)
+            sweep[n] = 1e3 * (statistics.median(times) if times else warm)
+    finally:
+        torch.set_num_threads(old)
+    best_n = min(sweep, key=sweep.get)
+    cpu_ms = sweep[best_n]
+    step, _ = make_step(sc, dev, pool=2)
+    for _ in range(5):
+        step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(50):
+        step(i)
+    torch.cuda.synchronize()
+    gpu_ms = 1e3 * (time.perf_counter() - t0) / 50
+    mpix = sc["image_width"] * sc["image_height"] / 1e6
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"config": "c1: 10000 Gaussians, 256x256, SH degree 3, feat_dim=0",
+            "torch_cpu_autograd_ms": cpu_ms, "torch_cpu_autograd_mpix_s": mpix / (cpu_ms * 1e-3), "threads": best_n,
+            "ms_by_threads": sweep, "host_cores": cores, "cpu_model": model,
+            "gpu_ms": gpu_ms, "gpu_mpix_s": mpix / (gpu_ms * 1e-3),
+            "note": "CPU: oracle/torch_oracle.py (restatement of the reference's algorithm; the reference has no CPU "
+                    "rasterizer), median of up to 5 runs after 1 warm-up per thread count, best count reported; with "
+                    "torch.set_num_threads(256) one step took 259 s on this host class (profiles/r02_notes.md). "
+                    "GPU: this library, mean of 50 steps"}
+
+
+def make_step(scene, dev, pool=4, dist=None, overlap=True):
+    """Returns (step(i), leaves): one forward+backward (+ gradient exchange) with the i-th upstream gradient set."""
+    import torch
 
     import diff_gaussian_rasterization as dgr
     import dp
-    from diff_gaussian_rasterization import _C
-    from synth import CONFIGS, make_scene
-
-    cfg_kw = dict(CONFIGS[args.config])
-    if args.feat_dim is not None:
-        cfg_kw["C"] = args.feat_dim
-    scene = make_scene(seed=0, yaw_deg=5.0 * rank, **cfg_kw)
     P, C = scene["P"], scene["C"]
     W, H = scene["image_width"], scene["image_height"]
     t = lambda x: x.to(dev)
@@ -146,16 +191,137 @@ def main():
                   opacities=t(scene["opacities"]).requires_grad_(), shs=t(scene["shs"]).requires_grad_(),
                   semantic_feature=t(scene["semantic_feature"]).requires_grad_(),
                   scales=t(scene["scales"]).requires_grad_(), rotations=t(scene["rotations"]).requires_grad_())
-    up = [t(scene["dL_dcolor"]), t(scene["dL_dfeature"]), t(scene["dL_ddepth"])]
-    reduce_keys = ["means3D", "shs", "semantic_feature", "opacities", "scales", "rotations"]   # 59 + C floats
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    hw = float(W * H)
+    ups = []
+    for _ in range(pool):   # fresh upstream gradients: same distribution as the recipe, new values every step
+        dd = scene["dL_ddepth"] if float(scene["dL_ddepth"].abs().max()) == 0.0 else torch.randn(1, H, W, generator=g) / hw
+        ups.append([t(torch.randn(3, H, W, generator=g) / hw), t(torch.randn(C, H, W, generator=g) / hw), t(dd)])
+    reduce_keys = ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")   # 59 + C floats
 
-    def step():
+    def fwd_bwd(i):
+        color, feat, _radii, depth = rasterizer(**leaves)
+        torch.autograd.backward([color, feat, depth], ups[i % pool])
+
+    def step(i):
         for v in leaves.values():
             v.grad = None
-        color, feat, _radii, depth = rasterizer(**leaves)
-        torch.autograd.backward([color, feat, depth], up)
+        if dist is None:
+            fwd_bwd(i)
+            return
+        sub = {k: leaves[k] for k in reduce_keys}
+        dp.dp_step(lambda _vid: fwd_bwd(i), sub, [0], overlap=overlap)
+    return step, leaves
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run and relay its output."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm-only", action="store_true", help="time only the gradient exchange of the config (N > 1)")
+    ap.add_argument("--no-overlap", action="store_true", help="exchange all gradients after the backward pass")
+    ap.add_argument("--feat-dim", type=int, default=None, help="override the config's feature dim (development)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0 and args.gpus > 1:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to report fewer")
+        raise SystemExit(respawn_under_torchrun(args))
+    world = max(world, 1)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}; "
+                         f"launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from diff_gaussian_rasterization import _C
+    from synth import CONFIGS, make_scene
+
+    cfg_kw = dict(CONFIGS[args.config])
+    if args.feat_dim is not None:
+        cfg_kw["C"] = args.feat_dim
+    scene = make_scene(seed=0, yaw_deg=5.0 * rank, **cfg_kw)
+    P, C = scene["P"], scene["C"]
+    W, H = scene["image_width"], scene["image_height"]
+    step, leaves = make_step(scene, dev, dist=dist, overlap=not args.no_overlap)
+
+    def timed(n_steps, per_step_events):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)] if per_step_events else None
+        torch.cuda.synchronize()
         if dist is not None:
-            dp.all_reduce_gaussian_grads({k: leaves[k].grad for k in reduce_keys})
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            if evs:
+                evs[i].record()
+            step(i)
+        if evs:
+            evs[n_steps].record()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps)] if evs else None
+        return el, per
+
+    if args.comm_only:
+        import dp
+        if dist is None:
+            raise SystemExit("--comm-only needs --gpus N > 1")
+        for v in leaves.values():
+            v.grad = torch.zeros_like(v)
+        grads = {k: leaves[k].grad for k in ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")}
+        for _ in range(args.warmup):
+            dp.all_reduce_gaussian_grads(grads)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dp.all_reduce_gaussian_grads(grads)
+        torch.cuda.synchronize()
+        dist.barrier()
+        el = time.perf_counter() - t0
+        nbytes = sum(g.numel() * 4 for g in grads.values())
+        if rank == 0:
+            print(json.dumps({"metric": "gradient all-reduce only (no rendering)", "value": 1e3 * el / args.steps, "unit": "ms",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": False,
+                              "bytes_per_rank": nbytes, "algbw_GBps": nbytes / (el / args.steps) / 1e9,
+                              "config": {"workload": f"{args.config}: (59+{C}) floats x {P} Gaussians"}}), flush=True)
+        dist.destroy_process_group()
+        return
 
     stats = None
     if rank == 0:
@@ -163,55 +329,61 @@ def main():
         _C.set_option("tile_cull", 0)
         stats = scene_stats(scene, dev)
         _C.set_option("tile_cull", 1)
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    # events-off reference run (same K steps): shows what the stage events of the timed region cost
+    _C.set_option("profile", 0)
+    el_plain, _ = timed(args.steps, per_step_events=False)
+    # THE timed region: stage events on (roofline contract) + one event pair per step
+    _C.set_option("profile", 1)
     _C.profile_reset()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, per_step = timed(args.steps, per_step_events=True)
     prof = {name: (ms, calls) for name, ms, calls in _C.profile_read()}
+    _C.set_option("profile", 0)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         mpix = world * W * H / 1e6 / (elapsed / args.steps)
-        stage_ms = {k: v[0] / max(1, args.steps) for k, v in prof.items()}
+        stage_ms = {k: v[0] / max(1, v[1]) for k, v in prof.items()}
         alg = algorithmic_bytes(P, stats["Pv"], stats["N"], stats["N_r"], W * H, stats["tiles"], C)
         kernel_stage = {"preprocess": "preprocess", "render_fwd": "render_fwd", "render_bwd": "render_bwd",
                         "preprocess_bwd": "preprocess_bwd"}
         dom = max(kernel_stage, key=lambda k: stage_ms.get(kernel_stage[k], 0.0))
         dom_ms = stage_ms.get(kernel_stage[dom], float("nan"))
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_file):
-            try:
-                traffic = json.load(open(pmc_file)).get(dom)
-            except Exception:
-                traffic = None
+        profiled = None
+        for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+            f = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(f):
+                try:
+                    d = json.load(open(f))
+                    profiled = {"source": f"profiles/{name} (rocprofv3 --pmc, separate runs of this config; NOT measured by "
+                                          f"this process)", **({dom: d[dom]} if dom in d else {})}
+                    break
+                except Exception:
+                    pass
+        per = sorted(per_step)
+        pct = lambda q: per[min(len(per) - 1, int(q * len(per)))]
         out = {
             "metric": "rendered Mpix/s of rasterizer fwd+bwd (train-step ms in ms_per_step), 1M Gaussians @1080p, feat_dim=32",
             "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {scene['sh_degree']}, feat_dim={C}, "
-                                   f"one view per GPU (SURVEY.md 8d recipe, seed 0)",
+                                   f"one view per GPU (SURVEY.md 8d recipe, seed 0), fresh upstream gradients per step",
                        "P": P, "Pv": stats["Pv"], "N": stats["N"], "N_r": stats["N_r"],
                        "parallelism": "single GPU" if world == 1 else
-                       f"view-sharded dp{world} + RCCL all-reduce of (59+C) floats per Gaussian"},
+                       f"view-sharded dp{world} + RCCL all-reduce of (59+C) floats per Gaussian"
+                       + ("" if args.no_overlap else ", feature all-reduce started inside the backward pass")},
+            "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "n": len(per),
+                        "source": "HIP events on the op's stream, rank 0",
+                        "ms_per_step_without_stage_events": 1e3 * el_plain / args.steps},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": dom_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": dom_ms,
+                         "note": "HBM is the roofline the contract names for this path; the kernel itself is bound by "
+                                 "VALU issue and by the fp32 global-atomic rate (DESIGN.md 3.5, profiles/): see `profiled`"},
+            "profiled": profiled,
             "roofline_whole_step": {"algorithmic_bytes": alg["total"],
                                     "achieved": alg["total"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                                     "frac": alg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -219,6 +391,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_kw)
+            out["cpu_reference_path_c1"] = cpu_reference_path_c1(dev)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -20,6 +20,8 @@ using namespace f3dgs;
 namespace {
 
 thread_local std::string g_err;
+thread_local f3dgs_stage_fn g_feature_ready_fn = nullptr;
+thread_local void* g_feature_ready_ctx = nullptr;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -42,47 +44,68 @@ int fail(int code, const char* fmt, ...) {
 // totals are read, so the timed region itself is never synchronised.
 bool profiling() { return options().profile != 0; }
 
+// One event per stage boundary: the event that ends span i starts span i+1 (every recorded event costs a marker
+// packet between two kernels, ~4 us of device time each).  Events are pooled; a span with a null name only hands
+// its start event back to the pool (end of a chain).
 struct PendingSpan {
     const char* name;
     hipEvent_t a, b;
 };
 std::mutex g_prof_mu;
 std::vector<PendingSpan> g_pending;
+std::vector<hipEvent_t> g_event_pool;
 std::vector<std::pair<const char*, std::pair<double, long>>> g_totals;  // name -> (ms, calls)
 
 void resolve_pending_locked();
 constexpr size_t MAX_PENDING_SPANS = 4096;   // unread spans are folded into the totals beyond this
 
-// RAII: the dangling start event is destroyed on every exit path of forward/backward.
+hipEvent_t take_event_locked() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// RAII: the chain is closed (its last event handed back) on every exit path of forward/backward.
 struct StageTimer {
     hipStream_t s;
     bool on;
     hipEvent_t prev;
     explicit StageTimer(hipStream_t st) : s(st), on(profiling()), prev(nullptr) {
         if (on) {
-            (void)hipEventCreate(&prev);
+            {
+                std::lock_guard<std::mutex> lk(g_prof_mu);
+                prev = take_event_locked();
+            }
             (void)hipEventRecord(prev, s);
         }
     }
     ~StageTimer() {
-        if (prev) (void)hipEventDestroy(prev);
+        if (prev) {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_pending.push_back({nullptr, prev, nullptr});
+        }
     }
     StageTimer(const StageTimer&) = delete;
     StageTimer& operator=(const StageTimer&) = delete;
     void mark(const char* name) {
         if (!on) return;
         hipEvent_t e;
-        (void)hipEventCreate(&e);
-        (void)hipEventRecord(e, s);
-        hipEvent_t e2;  // the end event doubles as the next span's start: keep a second handle alive
-        (void)hipEventCreate(&e2);
-        (void)hipEventRecord(e2, s);
         {
             std::lock_guard<std::mutex> lk(g_prof_mu);
             if (g_pending.size() >= MAX_PENDING_SPANS) resolve_pending_locked();   // nobody is reading: bound the queue
+            e = take_event_locked();
+        }
+        (void)hipEventRecord(e, s);
+        {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
             g_pending.push_back({name, prev, e});
         }
-        prev = e2;
+        prev = e;
     }
 };
 
@@ -93,15 +116,18 @@ void resolve_pending() {
 
 void resolve_pending_locked() {
     for (auto& p : g_pending) {
-        (void)hipEventSynchronize(p.b);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, p.a, p.b);
-        (void)hipEventDestroy(p.a);
-        (void)hipEventDestroy(p.b);
-        bool found = false;
-        for (auto& t : g_totals)
-            if (strcmp(t.first, p.name) == 0) { t.second.first += ms; t.second.second++; found = true; break; }
-        if (!found) g_totals.push_back({p.name, {ms, 1}});
+        if (p.name) {
+            (void)hipEventSynchronize(p.b);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, p.a, p.b);
+            bool found = false;
+            for (auto& t : g_totals)
+                if (strcmp(t.first, p.name) == 0) { t.second.first += ms; t.second.second++; found = true; break; }
+            if (!found) g_totals.push_back({p.name, {ms, 1}});
+        } else {
+            (void)hipEventSynchronize(p.a);
+        }
+        g_event_pool.push_back(p.a);     // every event is the start of exactly one span (the chain's last: of the sentinel)
     }
     g_pending.clear();
 }
@@ -224,6 +250,11 @@ int f3dgs_get_option(const char* name, int* value) {
 }
 
 const char* f3dgs_last_error(void) { return g_err.c_str(); }
+
+void f3dgs_set_feature_grad_ready_callback(f3dgs_stage_fn fn, void* ctx) {
+    g_feature_ready_fn = fn;
+    g_feature_ready_ctx = ctx;
+}
 
 int f3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                        uint8_t* present, void* stream) {
@@ -412,6 +443,7 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
                                dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, s);
     if ((rc = check_debug(debug, s, "render backward"))) return rc;
     tm.mark("render_bwd");
+    if (g_feature_ready_fn) g_feature_ready_fn(g_feature_ready_ctx, stream);   // dL_dsemantic_feature is final on `s` here
     launch_preprocess_backward(P, D, M, C, means3D, radii, shs, scales, rotations, cov3D_precomp, vp, geom, grec,
                                dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
                                (M > 0 && shs) ? dL_dsh : nullptr, scales ? dL_dscale : nullptr,

@@ -25,6 +25,8 @@
 
 #include "../../include/f3dgs.h"
 
+namespace py = pybind11;
+
 namespace {
 
 const float* fptr(const torch::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
@@ -54,6 +56,17 @@ int feature_channels(const torch::Tensor& semantic_feature, int64_t P) {
     TORCH_CHECK(semantic_feature.dim() == 3 && semantic_feature.size(0) == P && semantic_feature.size(1) == 1,
                 "semantic_feature must have dimensions (num_points, 1, C); got ", semantic_feature.sizes());
     return (int)semantic_feature.size(2);
+}
+
+// Python callable invoked with dL_dsemantic_feature as soon as the blend backward has been enqueued
+// (include/f3dgs.h: f3dgs_set_feature_grad_ready_callback).  The GIL is held throughout the binding call.
+py::object& feature_grad_hook() {
+    static py::object* hook = new py::object(py::none());   // leaked on purpose: no destructor after interpreter exit
+    return *hook;
+}
+void feature_ready_trampoline(void* ctx, void* /*stream*/) {
+    py::object& hook = feature_grad_hook();
+    if (!hook.is_none()) hook(*static_cast<torch::Tensor*>(ctx));
 }
 
 void* current_stream(const torch::Tensor& ref) {
@@ -152,6 +165,8 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     TORCH_CHECK(radii.is_cuda() || P == 0, "radii must live on a HIP device");
     auto rad = radii.contiguous();
 
+    const bool notify = !feature_grad_hook().is_none() && P > 0 && C > 0;
+    if (notify) f3dgs_set_feature_grad_ready_callback(feature_ready_trampoline, &dL_dsemantic_feature);
     const int rc = f3dgs_backward(
         P, degree, M, C, R, fptr(bg), W, H, fptr(m3), fptr(shs), fptr(col), fptr(sf), fptr(sc), scale_modifier, fptr(rot),
         fptr(cov), fptr(vm), fptr(pm), fptr(cp), tan_fovx, tan_fovy, P ? rad.data_ptr<int>() : nullptr,
@@ -163,6 +178,7 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
         (P && M) ? dL_dsh.data_ptr<float>() : nullptr, P ? dL_dscales.data_ptr<float>() : nullptr,
         P ? dL_drotations.data_ptr<float>() : nullptr, nullptr, P ? scratch.data_ptr() : nullptr, debug ? 1 : 0,
         current_stream(means3D));
+    if (notify) f3dgs_set_feature_grad_ready_callback(nullptr, nullptr);
     check_status(rc, "rasterize_gaussians_backward");
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dsemantic_feature, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
                            dL_dscales, dL_drotations);
@@ -189,6 +205,8 @@ PYBIND11_MODULE(_C, m) {
     m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
     m.def("mark_visible", &markVisible);
     m.def("version", []() { return f3dgs_version(); });
+    m.def("set_feature_grad_hook", [](py::object fn) { feature_grad_hook() = std::move(fn); },
+          "callable(dL_dsemantic_feature) run inside rasterize_gaussians_backward once that tensor is final on the stream; None removes it");
     m.def("set_option", [](const std::string& name, int value) { check_status(f3dgs_set_option(name.c_str(), value), "set_option"); });
     m.def("get_option", [](const std::string& name) {
         int v = 0;

@@ -29,6 +29,19 @@ except ImportError as exc:  # fail loudly — a silent fallback would void every
     ) from exc
 
 
+_backward_done_hook = None
+
+
+def set_feature_grad_hook(on_ready, on_done=None) -> None:
+    """Data-parallel overlap (not in the reference): `on_ready(dL_dsemantic_feature)` runs inside the backward
+    pass as soon as that tensor is final on the current stream (the per-Gaussian stage still follows);
+    `on_done()` runs when the extension call has returned, before autograd sees the gradients.  `None` removes
+    both.  See feature-3dgs_amd/dp.py: FeatureGradOverlap."""
+    global _backward_done_hook
+    _C.set_feature_grad_hook(on_ready)
+    _backward_done_hook = on_done if on_ready is not None else None
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -91,6 +104,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         (grad_means2D, grad_colors_precomp, grad_semantic_feature, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
          grad_sh, grad_scales, grad_rotations) = _call_with_snapshot(
             _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        if _backward_done_hook is not None:
+            _backward_done_hook()
         # one gradient per forward input, in input order; raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_semantic_feature, grad_opacities,
                 grad_scales, grad_rotations, grad_cov3Ds_precomp, None)
@@ -134,4 +149,5 @@ class GaussianRasterizer(nn.Module):
                                    rotations, cov3D_precomp, self.raster_settings)
 
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "cpu_deep_copy_tuple"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "cpu_deep_copy_tuple",
+           "set_feature_grad_hook"]

@@ -1,33 +1,49 @@
 """View-sharded data parallelism for the rasterizer: one process per GPU, one view per rank and step,
-RCCL all-reduce of the per-Gaussian gradients over xGMI.
+RCCL reduction of the per-Gaussian gradients over xGMI.
 
 The reference trains on ONE view per iteration on one GPU and contains no torch.distributed call on
 this path (reference train.py:73-149), so this is new functionality layered ABOVE
 the drop-in op: every rank holds all P Gaussians (2M x (59+256) floats = 2.5 GB at config c4, trivial in
-288 GB), renders its own view, and the gradients of the leaf inputs of the op — means3D 3, SH 48,
-semantic feature C, opacity 1, scales 3, rotations 4 = (59 + C) floats per Gaussian — are summed.
+288 GB), renders its own view, and the gradients of the leaf inputs of the op - means3D 3, SH 48,
+semantic feature C, opacity 1, scales 3, rotations 4 = (59 + C) floats per Gaussian - are summed.
 
 xGMI on MI355X is a point-to-point mesh (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by ONE
-link, so the gradients are packed into a few large flat buckets (default 256 MiB) and handed to RCCL as
-single collectives, which lets it use its direct/one-shot algorithms across all links; buckets are issued
-asynchronously in reverse production order so the first ones overlap the tail of the backward pass.
+link, so the gradients travel as a few LARGE collectives (SH and feature gradients in place, the four
+small tensors in one flat bucket), which lets RCCL use its direct algorithms across all links.
+
+Three ways to exchange, all IN PLACE on the tensors handed in (so `leaf.grad` is what the optimiser reads):
+
+  * `all_reduce_gaussian_grads(grads)`            after the backward pass, everything at once;
+  * `FeatureGradOverlap`                          starts the all-reduce of the (largest) feature gradient as
+                                                  soon as the blend backward has produced it, on a side
+                                                  stream, while the op's last kernel (preprocess backward)
+                                                  still runs;
+  * `reduce_scatter_gaussian_grads(grads, ...)`   for a sharded optimiser: every rank receives only the sum
+                                                  of ITS slice of Gaussians - half the bytes of an all-reduce;
+                                                  `all_gather_params` redistributes the updated parameters.
+
 Densification statistics need two more tiny reductions: SUM of the screen-space gradient norms / visibility
 counts and MAX of the radii (reference train.py:132-133, scene/gaussian_model.py:436-438).
 
-Backends: "nccl" (= RCCL on ROCm) on GPUs; "gloo" works for the CPU tests.
+Backends: "nccl" (= RCCL on ROCm) on GPUs; "gloo" for the CPU tests.
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List, Optional, Sequence
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
+# the leaf inputs of the op under the names of `GaussianRasterizer.forward` (reference __init__.py:204)
 GRAD_KEYS = ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")
 
 
+def _active(group) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
 def views_for_rank(num_views: int, rank: int, world: int, iteration: int = 0) -> List[int]:
-    """Deterministic sharding: rank r renders views world*iteration + r (mod num_views) — every rank a
+    """Deterministic sharding: rank r renders views world*iteration + r (mod num_views) - every rank a
     different view of the same step, every view visited equally often."""
     if num_views <= 0:
         return []
@@ -41,7 +57,7 @@ class GradBuckets:
         self.layout = []  # (key, bucket, offset, numel, shape)
         self.buckets: List[torch.Tensor] = []
         cap = max(1, bucket_bytes // 4)
-        cur, fill = [], 0
+        fill = 0
         sizes = []
         for k, shp in shapes.items():
             n = 1
@@ -56,7 +72,7 @@ class GradBuckets:
         self.buckets = [torch.empty(s, dtype=torch.float32, device=device) for s in sizes]
 
     def views(self) -> Dict[str, torch.Tensor]:
-        """Per-key views INTO the buckets (write gradients here to skip the pack copy)."""
+        """Per-key views INTO the buckets."""
         return {k: self.buckets[b][o:o + n].view(shp) for k, b, o, n, shp in self.layout}
 
     def pack(self, grads: Dict[str, torch.Tensor]) -> None:
@@ -71,25 +87,44 @@ class GradBuckets:
             w.wait()
         return None
 
-    def unpack(self) -> Dict[str, torch.Tensor]:
-        return self.views()
+    def unpack_into(self, grads: Dict[str, torch.Tensor]) -> None:
+        """Copy the reduced values back into the caller's tensors (in place)."""
+        for k, b, o, n, shp in self.layout:
+            grads[k].copy_(self.buckets[b][o:o + n].view(shp))
+
+
+def _check(grads: Dict[str, torch.Tensor]) -> List[str]:
+    keys = []
+    for k, v in grads.items():
+        if v is None:
+            continue
+        if not isinstance(v, torch.Tensor):
+            raise TypeError(f"gradient '{k}' is a {type(v).__name__}, expected a tensor")
+        if v.dtype != torch.float32:
+            raise TypeError(f"gradient '{k}' is {v.dtype}; the op produces float32 gradients")
+        keys.append(k)
+    return keys
 
 
 def all_reduce_gaussian_grads(grads: Dict[str, torch.Tensor], group=None, bucket_bytes: int = 256 << 20,
-                              buckets: Optional[GradBuckets] = None,
-                              direct_bytes: int = 32 << 20) -> Dict[str, torch.Tensor]:
-    """Sum the per-Gaussian gradients over all ranks; returns tensors with the input shapes.
+                              buckets: Optional[GradBuckets] = None, direct_bytes: int = 32 << 20,
+                              skip: Iterable[str] = ()) -> Dict[str, torch.Tensor]:
+    """SUM every tensor of `grads` over all ranks, IN PLACE, and return the same dict.
 
-    Tensors of at least `direct_bytes` (SH and feature gradients: 192 MB / 4C MB per million Gaussians) are
-    already collective-sized and are reduced IN PLACE without a pack copy; the small ones (means, opacity,
-    scales, rotations) share one flat bucket so that they cost one collective instead of four."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    Any key is accepted (the reference's leaves are called `_xyz`, `_features_dc`, ...: pass
+    `{name: p.grad for name, p in model.named_parameters()}` or the op's own input names alike); `None`
+    values are ignored.  Tensors of at least `direct_bytes` (SH and feature gradients: 192 MB / 4C MB per
+    million Gaussians) are already collective-sized and are reduced directly; the small ones (means, opacity,
+    scales, rotations) share one flat bucket so that they cost one collective instead of four, and the reduced
+    values are copied back into the caller's tensors.  `skip`: keys that were already reduced elsewhere
+    (FeatureGradOverlap)."""
+    if not _active(group):
         return grads
-    keys = [k for k in GRAD_KEYS if k in grads and grads[k] is not None]
+    skip = set(skip)
+    keys = [k for k in _check(grads) if k not in skip]
     big = [k for k in keys if grads[k].numel() * 4 >= direct_bytes and grads[k].is_contiguous()]
     small = [k for k in keys if k not in big]
     works = [dist.all_reduce(grads[k], op=dist.ReduceOp.SUM, group=group, async_op=True) for k in big]
-    out = dict(grads)
     if small:
         if buckets is None:
             buckets = GradBuckets({k: grads[k].shape for k in small}, grads[small[0]].device, bucket_bytes)
@@ -98,14 +133,135 @@ def all_reduce_gaussian_grads(grads: Dict[str, torch.Tensor], group=None, bucket
     for w in works:
         w.wait()
     if small:
-        out.update(buckets.unpack())
-    return out
+        buckets.unpack_into(grads)
+    return grads
+
+
+class FeatureGradOverlap:
+    """Overlaps the all-reduce of dL/dsemantic_feature with the tail of the op's backward pass.
+
+    The feature gradient (C of the 59 + C floats per Gaussian: 2 GB of the 2.5 GB at config c4) is complete
+    when the blend backward kernel has run; the op then still executes its preprocess backward.  The op calls
+    the hook installed here at that point (`diff_gaussian_rasterization.set_feature_grad_hook`): it records an
+    event on the op's stream, lets a side stream wait for it and starts the RCCL all-reduce there.
+    The current stream is made to wait for the collective before the extension call returns to autograd, so
+    whatever autograd does with the tensor afterwards (keep it as `leaf.grad` or copy it) sees the SUM.  Then reduce
+    the remaining gradients, skipping the feature leaf:
+
+        with FeatureGradOverlap(group) as ov:
+            loss.backward()
+            all_reduce_gaussian_grads(grads, skip=ov.reduced(("semantic_feature",)))
+    """
+
+    def __init__(self, group=None):
+        self.group = group
+        self._work = None
+        self._tensor: Optional[torch.Tensor] = None
+        self._stream = None
+        self._installed = False
+        self._count = 0
+
+    def _hook(self, feature_grad: torch.Tensor) -> None:
+        if not _active(self.group) or feature_grad.numel() == 0:
+            return
+        self._tensor = feature_grad
+        if feature_grad.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=feature_grad.device)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(feature_grad.device))
+            self._stream.wait_event(ready)
+            with torch.cuda.stream(self._stream):
+                self._work = dist.all_reduce(feature_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work = dist.all_reduce(feature_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._count += 1
+
+    def __enter__(self):
+        import diff_gaussian_rasterization as dgr
+        dgr.set_feature_grad_hook(self._hook, self.finish)
+        self._installed = True
+        return self
+
+    def __exit__(self, *exc):
+        import diff_gaussian_rasterization as dgr
+        if self._installed:
+            dgr.set_feature_grad_hook(None)
+            self._installed = False
+        return False
+
+    def finish(self) -> None:
+        """Join (called by the op when its backward call has returned): work queued on the current stream from here
+        on sees the reduced tensor.  No host synchronisation."""
+        if self._work is not None:
+            self._work.wait()          # NCCL/RCCL: the current stream waits for the collective
+            if self._stream is not None:
+                torch.cuda.current_stream(self._tensor.device).wait_stream(self._stream)
+            self._work = None
+            self._tensor = None
+
+    def reduced(self, feature_keys: Iterable[str]) -> List[str]:
+        """`feature_keys` if a feature gradient was reduced by this object since it was entered, else nothing."""
+        return list(feature_keys) if self._count > 0 else []
+
+
+def shard_range(P: int, rank: int, world: int):
+    """Gaussians [lo, hi) owned by `rank` under the contiguous sharding used by the sharded-optimiser path."""
+    per = (P + world - 1) // world
+    return min(P, rank * per), min(P, (rank + 1) * per)
+
+
+def reduce_scatter_gaussian_grads(grads: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
+    """Sharded-optimiser exchange: returns, per key, the SUM over ranks of the rows [lo, hi) this rank owns
+    (`shard_range`).  Moves (N-1)/N of the gradient bytes once instead of twice (all-reduce = reduce-scatter +
+    all-gather): the second half is replaced by `all_gather_params` of the UPDATED parameters, which a training
+    loop needs anyway after a sharded step and can overlap with the next view's preprocess.  With world size 1
+    it returns the full tensors."""
+    keys = _check(grads)
+    if not _active(group):
+        return {k: grads[k] for k in keys}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    out, works = {}, []
+    for k in keys:
+        g = grads[k]
+        P = g.shape[0]
+        per = (P + world - 1) // world
+        flat = g.reshape(P, -1)
+        if per * world != P:   # pad the row dimension to a multiple of the world size
+            pad = torch.zeros(per * world - P, flat.shape[1], dtype=g.dtype, device=g.device)
+            flat = torch.cat([flat, pad], 0)
+        flat = flat.contiguous()
+        mine = torch.empty(per, flat.shape[1], dtype=g.dtype, device=g.device)
+        works.append(dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        lo, hi = shard_range(P, rank, world)
+        out[k] = (mine, hi - lo, g.shape[1:])
+    for w in works:
+        w.wait()
+    return {k: m[:n].reshape((n,) + tuple(shp)) for k, (m, n, shp) in out.items()}
+
+
+def all_gather_params(shards: Dict[str, torch.Tensor], full: Dict[str, torch.Tensor], group=None) -> None:
+    """Inverse of the sharding above: every rank contributes its updated rows, `full[k]` receives all P rows."""
+    if not _active(group):
+        for k, s in shards.items():
+            full[k].copy_(s)
+        return
+    world = dist.get_world_size(group)
+    for k, s in shards.items():
+        P = full[k].shape[0]
+        per = (P + world - 1) // world
+        row = full[k].reshape(P, -1).shape[1]
+        send = torch.zeros(per, row, dtype=s.dtype, device=s.device)
+        send[:s.shape[0]].copy_(s.reshape(s.shape[0], -1))
+        recv = torch.empty(per * world, row, dtype=s.dtype, device=s.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        full[k].copy_(recv[:P].reshape(full[k].shape))
 
 
 def reduce_densification_stats(grad_norm_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,
                                group=None) -> None:
     """In-place: SUM the accumulated view-space gradient norms and visibility counts, MAX the radii."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _active(group):
         return
     w1 = dist.all_reduce(grad_norm_accum, op=dist.ReduceOp.SUM, group=group, async_op=True)
     w2 = dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -114,13 +270,22 @@ def reduce_densification_stats(grad_norm_accum: torch.Tensor, denom: torch.Tenso
         w.wait()
 
 
-def dp_step(render_and_backward, leaves: Dict[str, torch.Tensor], view_ids: Iterable[int], group=None,
-            buckets: Optional[GradBuckets] = None) -> Dict[str, torch.Tensor]:
+def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.Tensor], view_ids: Iterable[int],
+            group=None, buckets: Optional[GradBuckets] = None, overlap: bool = False,
+            feature_key: str = "semantic_feature") -> Dict[str, torch.Tensor]:
     """One data-parallel step: `render_and_backward(view_id)` must run the op forward+backward for that view
-    and accumulate into `leaves[k].grad`; afterwards the gradients of all ranks are summed."""
+    and accumulate into `leaves[k].grad`; afterwards `leaves[k].grad` holds the sum over all ranks' views for
+    EVERY leaf (any names).  `overlap=True` starts the all-reduce of `leaves[feature_key].grad` inside the backward
+    pass (one view per rank and step; the leaf must be fed to the op directly; needs the HIP extension)."""
     for v in leaves.values():
         v.grad = None
+    view_ids = list(view_ids)
+    if overlap and len(view_ids) == 1 and _active(group):
+        with FeatureGradOverlap(group) as ov:
+            render_and_backward(view_ids[0])
+            grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+            return all_reduce_gaussian_grads(grads, group=group, buckets=buckets, skip=ov.reduced((feature_key,)))
     for vid in view_ids:
         render_and_backward(vid)
-    grads = {k: leaves[k].grad for k in GRAD_KEYS if k in leaves and leaves[k].grad is not None}
+    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
     return all_reduce_gaussian_grads(grads, group=group, buckets=buckets)

@@ -202,6 +202,16 @@ int f3dgs_backward(
     void* stream /* hipStream_t */);
 
 /*
+ * Optional notification inside f3dgs_backward (no counterpart in the reference): `fn(ctx, stream)` is called on
+ * the calling host thread right after the blend backward has been ENQUEUED on `stream`, i.e. at the point of
+ * the stream from which dL_dsemantic_feature is final while the per-Gaussian stage still follows.  A
+ * data-parallel caller records an event there and starts the all-reduce of the feature gradient on another
+ * stream, overlapping it with the rest of the call.  Thread-local; NULL removes it.
+ */
+typedef void (*f3dgs_stage_fn)(void* ctx, void* stream /* hipStream_t */);
+void f3dgs_set_feature_grad_ready_callback(f3dgs_stage_fn fn, void* ctx);
+
+/*
  * Test / profiling hooks (not part of the reference surface).  They expose
  * the private state written by f3dgs_forward so that every stage can be
  * compared with the oracle in isolation.  Each copies `count` elements

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the view-sharded data-parallel step (CPU): the rasterizer op is replaced by the
+"""world_size-2 gloo tests of the view-sharded data-parallel step (CPU): the rasterizer op is replaced by the
 torch-autograd oracle on a tiny scene, the collectives and bucket packing are the product code (dp.py)."""
 import os
 import socket
@@ -9,6 +9,11 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+KEYS = ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")
+# the reference's own leaf names (scene/gaussian_model.py:41-50): any key must be reduced, none silently skipped
+REF_NAMES = {"means3D": "_xyz", "shs": "_features", "semantic_feature": "_semantic_feature", "opacities": "_opacity",
+             "scales": "_scaling", "rotations": "_rotation"}
+
 
 def _free_port():
     s = socket.socket()
@@ -18,13 +23,15 @@ def _free_port():
     return p
 
 
-def _grads_for_view(view_id, P=120, C=3):
-    from oracle import torch_oracle
+def _scene_for_view(view_id, P=120, C=3):
     from synth import make_scene
-    sc = make_scene(P, C, 48, 32, seed=77, yaw_deg=5.0 * view_id, scale_lo=0.05, scale_hi=0.3)
-    r = torch_oracle.forward_backward(sc, dtype=torch.float32)
-    g = r["grads"]
-    return {k: g[k].float() for k in ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")}, r
+    return make_scene(P, C, 48, 32, seed=77, yaw_deg=5.0 * view_id, scale_lo=0.05, scale_hi=0.3)
+
+
+def _grads_for_view(view_id):
+    from oracle import torch_oracle
+    r = torch_oracle.forward_backward(_scene_for_view(view_id), dtype=torch.float32)
+    return {k: r["grads"][k].float() for k in KEYS}
 
 
 def _worker(rank, world, port, out_dir):
@@ -37,32 +44,65 @@ def _worker(rank, world, port, out_dir):
     import dp
     vids = dp.views_for_rank(num_views=8, rank=rank, world=world, iteration=0)
     assert vids == [rank]
-    grads, r = _grads_for_view(vids[0])
-    summed = dp.all_reduce_gaussian_grads(grads, bucket_bytes=4096)   # tiny buckets: several collectives
+    # ---- dp_step: the SUM must land in leaf.grad of EVERY leaf, whatever it is called ---------
+    sc = _scene_for_view(vids[0])
+    leaves = {REF_NAMES[k]: sc[k].clone().requires_grad_(True) for k in KEYS}
+
+    def render_and_backward(view_id):
+        g = _grads_for_view(view_id)
+        for k in KEYS:     # stands in for loss.backward() through the op
+            leaf = leaves[REF_NAMES[k]]
+            leaf.grad = g[k].reshape(leaf.shape).clone() if leaf.grad is None else leaf.grad + g[k].reshape(leaf.shape)
+
+    returned = dp.dp_step(render_and_backward, leaves, vids, buckets=None)
+    for name, leaf in leaves.items():
+        assert returned[name] is leaf.grad, name          # in place: the very tensors the optimiser reads
+    # tiny buckets: several collectives, still in place
+    g2 = {k: v.clone() for k, v in _grads_for_view(vids[0]).items()}
+    keep = dict(g2)
+    out2 = dp.all_reduce_gaussian_grads(g2, bucket_bytes=4096)
+    assert all(out2[k] is keep[k] for k in keep)
+    with pytest.raises(TypeError):
+        dp.all_reduce_gaussian_grads({"x": torch.zeros(3, dtype=torch.float64)})
+    # ---- sharded exchange: reduce-scatter, "update", all-gather ----------------------------------------------
+    g3 = _grads_for_view(vids[0])
+    shards = dp.reduce_scatter_gaussian_grads(g3)
+    lo, hi = dp.shard_range(120, rank, world)
+    full = {k: torch.zeros_like(v) for k, v in g3.items()}
+    dp.all_gather_params(shards, full)
     acc = torch.full((120, 1), float(rank + 1))
     den = torch.ones(120, 1)
     rad = torch.arange(120, dtype=torch.float32) * (rank + 1)
     dp.reduce_densification_stats(acc, den, rad)
-    if rank == 0:
-        np.savez(os.path.join(out_dir, "dp.npz"), acc=acc.numpy(), den=den.numpy(), rad=rad.numpy(),
-                 **{k: v.numpy() for k, v in summed.items()})
+    np.savez(os.path.join(out_dir, f"dp{rank}.npz"), acc=acc.numpy(), den=den.numpy(), rad=rad.numpy(), lo=lo, hi=hi,
+             **{"leaf_" + k: leaves[REF_NAMES[k]].grad.numpy() for k in KEYS},
+             **{"small_" + k: g2[k].numpy() for k in KEYS},
+             **{"shard_" + k: shards[k].numpy() for k in KEYS},
+             **{"full_" + k: full[k].numpy() for k in KEYS})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_allreduce(tmp_path):
+def test_two_rank_gradient_exchange(tmp_path):
     world = 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    got = np.load(os.path.join(str(tmp_path), "dp.npz"))
     want = None
     for v in range(world):
-        g, _ = _grads_for_view(v)
+        g = _grads_for_view(v)
         want = g if want is None else {k: want[k] + g[k] for k in g}
-    for k, w in want.items():
-        assert np.allclose(got[k], w.numpy(), rtol=1e-5, atol=1e-8), k
-    assert np.allclose(got["acc"], 3.0) and np.allclose(got["den"], 2.0)
-    assert np.allclose(got["rad"], np.arange(120) * 2.0)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"dp{rank}.npz"))
+        lo, hi = int(got["lo"]), int(got["hi"])
+        for k, w in want.items():
+            w = w.numpy()
+            assert np.allclose(got["leaf_" + k].reshape(w.shape), w, rtol=1e-5, atol=1e-8), ("leaf.grad", k, rank)
+            assert np.allclose(got["small_" + k], w, rtol=1e-5, atol=1e-8), ("bucketed", k, rank)
+            assert np.allclose(got["shard_" + k], w[lo:hi], rtol=1e-5, atol=1e-8), ("reduce-scatter", k, rank)
+            assert np.allclose(got["full_" + k], w, rtol=1e-5, atol=1e-8), ("all-gather", k, rank)
+        assert np.allclose(got["acc"], 3.0) and np.allclose(got["den"], 2.0)
+        assert np.allclose(got["rad"], np.arange(120) * 2.0)
+    assert {int(np.load(os.path.join(str(tmp_path), f"dp{r}.npz"))["lo"]) for r in range(world)} == {0, 60}
 
 
 def test_bucket_layout_roundtrip():
@@ -72,8 +112,12 @@ def test_bucket_layout_roundtrip():
     assert len(b.buckets) > 1 and sum(x.numel() for x in b.buckets) == 10 * (3 + 48 + 5 + 1)
     g = {k: torch.randn(*s) for k, s in shapes.items()}
     b.pack(g)
-    for k, v in b.unpack().items():
+    for k, v in b.views().items():
         assert torch.equal(v, g[k])
+    out = {k: torch.zeros(*s) for k, s in shapes.items()}
+    b.unpack_into(out)
+    for k in g:
+        assert torch.equal(out[k], g[k])
 
 
 def test_view_sharding_covers_all_views():
@@ -83,3 +127,11 @@ def test_view_sharding_covers_all_views():
         for r in range(2):
             seen += dp.views_for_rank(8, r, 2, it)
     assert sorted(seen) == list(range(8))
+
+
+def test_world_size_one_is_a_no_op():
+    import dp
+    g = {"a": torch.ones(4, 3), "b": None}
+    assert dp.all_reduce_gaussian_grads(g) is g
+    s = dp.reduce_scatter_gaussian_grads({"a": g["a"]})
+    assert s["a"] is g["a"] and dp.shard_range(10, 0, 1) == (0, 10)

@@ -52,7 +52,7 @@ def main():
         out["_note"] = ("HBM bytes per launch at config c3 from rocprofv3 PMC, separate passes: "
                         "(2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 "
                         "reports half the bytes of wide coalesced reads; other widths and WRITE_SIZE uncalibrated). "
-                        "Raw counters: profiles/r01_pmc_hbm_raw.json; tool: tools/pmc_summary.py")
+                        f"Raw counters: profiles/{os.path.basename(sys.argv[3])}; tool: tools/pmc_summary.py")
         json.dump(out, open(sys.argv[2], "w"), indent=1)
     else:
         json.dump(aggregate(sys.argv[2:]), open(sys.argv[1], "w"), indent=1)
