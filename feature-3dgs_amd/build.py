@@ -2,6 +2,7 @@
 
   csrc/libf3dgs_hip.so                      the C-ABI product library (hipcc, hand-written HIP kernels)
   diff_gaussian_rasterization/_C*.so        pybind11/libtorch binding over the C ABI (g++)
+  simple_knn/_C*.so                         same, for distCUDA2
 
 Both are written next to their sources so that they travel with a `gpurun` snapshot.  hipcc
 cross-compiles for gfx950 without a GPU.  Run:  python feature-3dgs_amd/build.py [--force]
@@ -18,6 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 PKG = os.path.join(HERE, "diff_gaussian_rasterization")
 HIP_LIB = os.path.join(CSRC, "libf3dgs_hip.so")
 EXT = os.path.join(PKG, "_C" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+KNN_EXT = os.path.join(HERE, "simple_knn", "_C" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 
 def _newer(target: str, sources) -> bool:
@@ -34,9 +36,10 @@ def build_hip(force: bool = False) -> str:
     return HIP_LIB
 
 
-def build_binding(force: bool = False) -> str:
-    src = os.path.join(CSRC, "binding.cpp")
+def build_binding(force: bool = False, src_name: str = "binding.cpp", target: str = EXT) -> str:
+    src = os.path.join(CSRC, src_name)
     hdr = os.path.join(HERE, "..", "include", "f3dgs.h")
+    EXT = target
     if not force and _newer(EXT, [src, hdr, HIP_LIB]):
         return EXT
     import pybind11
@@ -59,6 +62,7 @@ def build_binding(force: bool = False) -> str:
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_binding(force)
+    build_binding(force, "binding_knn.cpp", KNN_EXT)      # simple_knn._C
 
 
 if __name__ == "__main__":

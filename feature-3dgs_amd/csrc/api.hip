@@ -454,6 +454,17 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     return F3DGS_OK;
 }
 
+size_t f3dgs_knn_scratch_bytes(int P) { return knn_scratch_bytes((size_t)(P > 0 ? P : 0)); }
+
+int f3dgs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* scratch, void* stream) {
+    if (P < 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "P < 0");
+    if (P == 0) return F3DGS_OK;
+    if (!points || !mean_dist2 || !scratch) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
+    launch_knn_mean_dist2(P, points, mean_dist2, static_cast<char*>(scratch), static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return F3DGS_OK;
+}
+
 int f3dgs_debug_read(const char* what, int P, int C, int R, int width, int height, const char* geom_buffer,
                      const char* binning_buffer, const char* image_buffer, void* host_dst, size_t dst_bytes,
                      void* stream) {

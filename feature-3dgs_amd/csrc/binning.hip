@@ -519,6 +519,24 @@ void launch_tile_sort_onesweep(const GeomState& g, const BinState& b, size_t n, 
                        g.tickets + 6, ranges);
 }
 
+// Stable sort of (keys[i], i) on key bits [0, nbits): the sorted indices end in val_a (8-bit passes; `keys` is only read).
+void launch_radix_sort_keys_to_order(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b,
+                                     size_t n, int nbits, uint32_t* hist, hipStream_t s) {
+    const int passes = (nbits + RADIX_BITS - 1) / RADIX_BITS;
+    if (n == 0 || passes == 0) return;
+    const uint32_t nb = (uint32_t)sort_blocks(n);
+    bool to_a = (passes % 2) == 1;        // the last pass must write the A side
+    const uint32_t* ki = keys;
+    const uint32_t* vi = nullptr;
+    for (int p = 0; p < passes; p++) {
+        uint32_t* ko = to_a ? key_a : key_b;
+        uint32_t* vo = to_a ? val_a : val_b;
+        radix_pass<RADIX_BITS>(ki, vi, ko, vo, n, p * RADIX_BITS, nb, hist, s);
+        ki = ko; vi = vo;
+        to_a = !to_a;
+    }
+}
+
 void launch_iota(uint32_t* dst, size_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, n);
 }

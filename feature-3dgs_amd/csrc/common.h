@@ -224,6 +224,12 @@ void launch_tile_sort_onesweep(const GeomState& g, const BinState& b, size_t n, 
 void launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
                        uint32_t* hist, hipStream_t s);
 void launch_iota(uint32_t* dst, size_t n, hipStream_t s);
+void launch_radix_sort_keys_to_order(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b,
+                                     size_t n, int nbits, uint32_t* hist, hipStream_t s);
+
+// knn.hip
+size_t knn_scratch_bytes(size_t P);
+void launch_knn_mean_dist2(int P, const float* points, float* out, char* scratch, hipStream_t s);
 
 // render_fwd.hip / render_bwd.hip
 void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc, uint2* ranges, const uint32_t* point_list,

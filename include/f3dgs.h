@@ -202,6 +202,16 @@ int f3dgs_backward(
     void* stream /* hipStream_t */);
 
 /*
+ * Replaces SimpleKNN::knn / distCUDA2 of the reference's second native module (submodules/simple-knn/
+ * simple_knn.cu:45-221, spatial.cu:15-25; caller scene/gaussian_model.py:146): mean_dist2[i] = mean of the squared
+ * distances from point i to its three nearest neighbours (exact; a missing neighbour counts as FLT_MAX, as there).
+ * points (P,3), mean_dist2 (P) device pointers; `scratch` = f3dgs_knn_scratch_bytes(P) bytes of device memory.
+ * Everything is enqueued on `stream`; nothing is read back to the host (the reference synchronises twice).
+ */
+size_t f3dgs_knn_scratch_bytes(int P);
+int f3dgs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* scratch, void* stream /* hipStream_t */);
+
+/*
  * Optional notification inside f3dgs_backward (no counterpart in the reference): `fn(ctx, stream)` is called on
  * the calling host thread right after the blend backward has been ENQUEUED on `stream`, i.e. at the point of
  * the stream from which dL_dsemantic_feature is final while the per-Gaussian stage still follows.  A

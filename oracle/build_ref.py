@@ -157,11 +157,82 @@ def build_callers(force: bool = False) -> list:
     return done
 
 
+# ---- the reference's second native module: simple-knn (distCUDA2) --------------------------------------------
+KNN_REF = "/root/reference/submodules/simple-knn"
+KNN_FILES = ["simple_knn.cu", "simple_knn.h", "spatial.cu", "spatial.h", "ext.cpp"]
+_KNN_FIXES = [
+    (r"#define __CUDACC__\n", "", "a CUDA-only workaround for cooperative_groups"),
+    (r"#include\s*<cooperative_groups/reduce\.h>", "", "header does not exist in HIP"),
+    (r"#include\s*<hip/hip_cooperative_groups/reduce\.h>", "", "same, after hipify"),
+    (r'#include\s*""', "", "hipify-perl maps device_launch_parameters.h to an empty include"),
+    (r"#include\s*<cub/device/device_radix_sort\.cuh>", "", "covered by <hipcub/hipcub.hpp>"),
+    (r"#define BOX_SIZE 1024", "#define BOX_SIZE 1024\n#include <cfloat>", "FLT_MAX comes in through CUDA's headers there"),
+]
+
+
+def knn_module_path() -> str:
+    return os.path.join(OUT, "_ref_simple_knn" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_knn(force: bool = False, keep_src: bool = False) -> str:
+    """`oracle/_ref/_ref_simple_knn*.so`: the reference's `simple_knn._C` (distCUDA2) compiled for gfx950."""
+    target = knn_module_path()
+    srcs = [os.path.join(KNN_REF, f) for f in KNN_FILES]
+    if not force and os.path.exists(target) and all(os.path.getmtime(s) <= os.path.getmtime(target) for s in srcs):
+        return target
+    import pybind11
+    import torch
+    from torch.utils import cpp_extension as ce
+    sdir = os.path.join(OUT, "src_knn")
+    shutil.rmtree(sdir, ignore_errors=True)
+    os.makedirs(sdir)
+    for f in KNN_FILES:
+        with open(os.path.join(KNN_REF, f)) as fh:
+            text = fh.read()
+        for pat, rep, _ in _PRE:
+            text = re.sub(pat, rep, text)
+        with tempfile.NamedTemporaryFile("w", suffix=os.path.splitext(f)[1], delete=False) as tf:
+            tf.write(text)
+            tmp = tf.name
+        try:
+            text = subprocess.run([HIPIFY, tmp], check=True, capture_output=True, text=True).stdout
+        finally:
+            os.unlink(tmp)
+        for pat, rep, _ in _KNN_FIXES:
+            text = re.sub(pat, rep, text)
+        with open(os.path.join(sdir, f if not f.endswith(".cu") else f[:-3] + ".hip"), "w") as fh:
+            fh.write(text)
+    inc = [sdir] + ce.include_paths() + [pybind11.get_include(), sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    libdirs = ce.library_paths()
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    common = (["--offload-arch=gfx950", "-mcode-object-version=5", "-O3", "-std=c++17", "-fPIC", "-w",
+               "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={abi}",
+               "-DTORCH_EXTENSION_NAME=_ref_simple_knn", "-DTORCH_API_INCLUDE_EXTENSION_H"] + [f"-I{p}" for p in inc])
+    objs, procs = [], []
+    for u in ("simple_knn.hip", "spatial.hip", "ext.cpp"):
+        o = os.path.join(sdir, u + ".o")
+        objs.append(o)
+        cmd = [HIPCC] + common + (["-x", "hip"] if u.endswith(".cpp") else []) + ["-c", os.path.join(sdir, u), "-o", o]
+        procs.append((u, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for u, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"oracle/_ref: compiling simple-knn {u} failed:\n{out[-6000:]}")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
+                          + [f"-L{p}" for p in libdirs]
+                          + ["-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python"]
+                          + [f"-Wl,-rpath,{p}" for p in libdirs])
+    if not keep_src:
+        shutil.rmtree(sdir, ignore_errors=True)
+    print("built", target)
+    return target
+
+
 def build_all(channels=DEFAULT_CHANNELS, force: bool = False, keep_src: bool = False) -> list:
     if not os.path.isdir(REF):
         raise FileNotFoundError(f"{REF} not present (the GPU box only uses the prebuilt oracle/_ref modules)")
     os.makedirs(OUT, exist_ok=True)
-    return build_callers(force) + [build_one(c, force, keep_src=keep_src) for c in channels]
+    return build_callers(force) + [build_knn(force, keep_src)] + [build_one(c, force, keep_src=keep_src) for c in channels]
 
 
 if __name__ == "__main__":
