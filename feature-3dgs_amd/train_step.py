@@ -1,0 +1,97 @@
+"""Data-parallel training step around the drop-in op.
+
+One call = the body of the reference's training loop between "pick a camera" and "optimizer step"
+(reference train.py:84-149): render, loss, backward, densification statistics.  With one process (world size 1)
+and one view per step it performs exactly the reference's updates:
+
+    train.py:91        render_pkg = render(viewpoint_cam, gaussians, pipe, background)
+    train.py:98-106    loss = (1-l) L1 + l (1 - ssim) + L1_feature        -> `loss_fn(render_pkg, camera)`
+    train.py:108       loss.backward()
+    train.py:132       gaussians.max_radii2D[vis] = max(gaussians.max_radii2D[vis], radii[vis])
+    train.py:133       gaussians.add_densification_stats(viewspace_point_tensor, vis)
+                       (scene/gaussian_model.py:436-438: xyz_gradient_accum[vis] += |grad_xy|, denom[vis] += 1)
+
+With N processes (one per GPU, `torch.distributed` initialised) every rank renders ITS views of the same Gaussians;
+afterwards every rank holds, for every parameter, the SUM of the gradients over all ranks' views (`dp.dp_step`), and
+the densification statistics of all views (per-step deltas reduced with SUM / SUM / MAX), so the replicas stay
+identical whatever they do next (optimizer step, densify_and_prune).  N views per step instead of one is a change of
+the training recipe ABOVE the op - the op, its gradients and the statistics per view are the reference's.
+
+`model` is duck-typed like the reference's `GaussianModel`: it needs `max_radii2D`, `xyz_gradient_accum`, `denom`
+(tensors of length P) and the parameter tensors named in `param_names` (default: the reference's `_xyz`,
+`_features_dc`, `_features_rest`, `_opacity`, `_scaling`, `_rotation`, `_semantic_feature`, scene/gaussian_model.py:41-50).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, NamedTuple, Optional, Sequence
+
+import torch
+
+import dp
+
+REFERENCE_PARAM_NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_semantic_feature")
+
+
+class StepResult(NamedTuple):
+    loss: torch.Tensor                    # sum over this rank's views (detached)
+    views: int                            # views rendered by this rank
+    grads: Dict[str, torch.Tensor]        # name -> summed gradient (the tensors in `param.grad`)
+
+
+def densification_deltas(render_pkg: dict, P: int, device) -> tuple:
+    """The per-view increments of scene/gaussian_model.py:436-438 and train.py:132, as dense tensors."""
+    vis = render_pkg["visibility_filter"]
+    vsp = render_pkg["viewspace_points"]
+    g = vsp.grad if vsp.grad is not None else torch.zeros_like(vsp)
+    norm = torch.zeros(P, 1, device=device)
+    norm[vis] = torch.norm(g[vis, :2], dim=-1, keepdim=True)
+    count = torch.zeros(P, 1, device=device)
+    count[vis] = 1.0
+    radii = torch.zeros(P, device=device, dtype=torch.float32)
+    radii[vis] = render_pkg["radii"][vis].float()
+    return norm, count, radii
+
+
+def dp_train_step(render: Callable, loss_fn: Callable, model, cameras: Iterable, pipe, background: torch.Tensor,
+                  group=None, overlap: bool = True, param_names: Sequence[str] = REFERENCE_PARAM_NAMES,
+                  feature_param: str = "_semantic_feature", densification_stats: bool = True) -> StepResult:
+    """Render + loss + backward for this rank's `cameras`, then make gradients and densification statistics
+    global.  `render(camera, model, pipe, background)` is the reference's `gaussian_renderer.render`;
+    `loss_fn(render_pkg, camera)` returns the scalar loss of one view.  The optimizer step stays with the caller
+    (train.py:146-151), exactly as in the reference."""
+    params = {n: getattr(model, n) for n in param_names if getattr(model, n, None) is not None}
+    cameras = list(cameras)
+    P = next(iter(params.values())).shape[0]
+    device = next(iter(params.values())).device
+    pkgs, losses = [], []
+
+    def render_and_backward(i):
+        pkg = render(cameras[i], model, pipe, background)
+        loss = loss_fn(pkg, cameras[i])
+        loss.backward()
+        pkgs.append(pkg)
+        losses.append(loss.detach())
+
+    # the overlap needs the feature parameter to be the op's direct input (true for the reference's model:
+    # get_semantic_feature returns the parameter itself, scene/gaussian_model.py:121-123)
+    grads = dp.dp_step(render_and_backward, params, range(len(cameras)), group=group,
+                       overlap=overlap and len(cameras) == 1, feature_key=feature_param)
+
+    if densification_stats:
+        with torch.no_grad():
+            norm = torch.zeros(P, 1, device=device)
+            count = torch.zeros(P, 1, device=device)
+            radii = torch.zeros(P, device=device, dtype=torch.float32)
+            for pkg in pkgs:
+                n, c, r = densification_deltas(pkg, P, device)
+                norm += n
+                count += c
+                radii = torch.maximum(radii, r)
+            dp.reduce_densification_stats(norm, count, radii, group=group)
+            model.xyz_gradient_accum += norm
+            model.denom += count
+            seen = count.squeeze(-1) > 0
+            mr = model.max_radii2D
+            mr[seen] = torch.maximum(mr[seen], radii[seen].to(mr.dtype))
+    total = torch.stack(losses).sum() if losses else torch.zeros((), device=device)
+    return StepResult(total, len(cameras), grads)

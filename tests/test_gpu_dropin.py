@@ -113,7 +113,7 @@ def test_reference_render_runs_unmodified(reference_render, debug):
     # tan(atan(x)/... ) round trip of the field of view: allow fp32 noise in the images, radii must agree
     assert torch.equal(out["radii"], raw[4]) and torch.equal(out["visibility_filter"], raw[4] > 0)
     for got, want in ((out["render"], raw[1]), (out["feature_map"], raw[2]), (out["depth"], raw[3])):
-        assert got.shape == want.shape and float((got - want).abs().max()) < 1e-5
+        assert got.shape == want.shape and float((got.detach() - want).abs().max()) < 1e-5
     # and it trains: backward through the reference's graph reaches every leaf and the screen-space points
     loss = (out["render"] * sc["dL_dcolor"].to(DEV)).sum() + (out["feature_map"] * sc["dL_dfeature"].to(DEV)).sum()
     loss.backward()
