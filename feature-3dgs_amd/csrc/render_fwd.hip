@@ -90,41 +90,70 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
         for (int c = 0; c < (CH > 0 ? CH : 1); c++) sf[p][c] = 0.f;
     }
 
+    // software pipeline (as in the matrix-pipe variant below): records of chunk k+1 and list ids of chunk k+2 are
+    // requested while chunk k is blended
+    uint32_t n_id = 0, f_id = 0;
+    float4 n_q0 = make_float4(0, 0, 0, 0), n_q1 = n_q0, n_q2 = n_q0;
+    if (r_lo + lane < r_hi) n_id = a.point_list[r_lo + lane];
+    if (r_lo + 64 + lane < r_hi) f_id = a.point_list[r_lo + 64 + lane];
+    if (r_lo + lane < r_hi) {
+        const SplatRec* rp = a.rec + n_id;
+        n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
+    }
     for (uint32_t base = r_lo; base < r_hi; base += 64) {
         bool alld = true;
 #pragma unroll
         for (int p = 0; p < PPL; p++) alld = alld && done[p];
         if (__all(alld)) break;
         const int cnt = (int)min(64u, r_hi - base);
-        // ---- stage one chunk: records ...
+        // ---- stage one chunk: records (from the prefetch registers) ...
         __builtin_amdgcn_wave_barrier();
         if (lane < cnt) {
-            const uint32_t g = a.point_list[base + lane];
-            const SplatRec* rp = a.rec + g;
-            const float4 q0 = rp->q0, q1 = rp->q1, q2 = rp->q2;
-            ck.geo[lane] = q0;
-            ck.co[lane] = make_float2(q1.x, q1.y);
-            ck.cd[lane] = make_float4(q1.z, q1.w, q2.x, q2.y);
-            ck.id[lane] = g;
+            ck.geo[lane] = n_q0;
+            ck.co[lane] = make_float2(n_q1.x, n_q1.y);
+            ck.cd[lane] = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
+            ck.id[lane] = n_id;
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- ... and feature vectors (coalesced: CHV lanes x 16 B per instance)
+        n_id = f_id;
+        if (base + 64 + lane < r_hi) {
+            const SplatRec* rp = a.rec + n_id;
+            n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
+        }
+        if (base + 128 + lane < r_hi) f_id = a.point_list[base + 128 + lane];
+        // ---- ... and feature vectors (coalesced: CHV lanes x 16 B per instance; LDS-direct loads when the window is full
+        // width: lane l of a request lands at base + 16 l = the row-major image, all requests in flight together)
         if constexpr (CH > 0) {
             const bool vec_ok = (a.C & 3) == 0 && (a.c0 & 3) == 0;
-            for (int e = lane; e < cnt * CHV; e += 64) {
-                const int inst = e / CHV, v = e % CHV;
-                const uint32_t g = ck.id[inst];
-                const float* src = a.feat + (size_t)g * a.C + a.c0 + 4 * v;
-                float4 f;
-                if (vec_ok && 4 * v + 3 < a.nc) {
-                    f = *reinterpret_cast<const float4*>(src);
-                } else {
-                    f.x = 4 * v + 0 < a.nc ? src[0] : 0.f;
-                    f.y = 4 * v + 1 < a.nc ? src[1] : 0.f;
-                    f.z = 4 * v + 2 < a.nc ? src[2] : 0.f;
-                    f.w = 4 * v + 3 < a.nc ? src[3] : 0.f;
+            if (vec_ok && a.nc == CH) {
+                using lds_ptr = __attribute__((address_space(3))) void*;
+                using gbl_ptr = const __attribute__((address_space(1))) void*;
+#pragma unroll
+                for (int it = 0; it < (64 * CHV + 63) / 64; it++) {
+                    const int e = it * 64 + lane;
+                    if (e < cnt * CHV) {
+                        const uint32_t g = ck.id[e / CHV];
+                        const float* src = a.feat + (size_t)g * a.C + a.c0 + 4 * (e % CHV);
+                        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(&ck.feat[0][0] + it * 256), 16, 0, 0);
+                    }
                 }
-                *reinterpret_cast<float4*>(&ck.feat[inst][4 * v]) = f;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                for (int e = lane; e < cnt * CHV; e += 64) {
+                    const int inst = e / CHV, v = e % CHV;
+                    const uint32_t g = ck.id[inst];
+                    const float* src = a.feat + (size_t)g * a.C + a.c0 + 4 * v;
+                    float4 f;
+                    if (vec_ok && 4 * v + 3 < a.nc) {
+                        f = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        f.x = 4 * v + 0 < a.nc ? src[0] : 0.f;
+                        f.y = 4 * v + 1 < a.nc ? src[1] : 0.f;
+                        f.z = 4 * v + 2 < a.nc ? src[2] : 0.f;
+                        f.w = 4 * v + 3 < a.nc ? src[3] : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(&ck.feat[inst][4 * v]) = f;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -230,7 +259,7 @@ struct FwdChunkMF {
 // (Fetching the B operand straight from global memory, prefetched two groups ahead, was measured slower
 // than staging the chunk's feature rows in LDS: 0.62 vs 0.57 ms at config c3.)
 template <int CH, int PPL, int CHK, int GI>
-__global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs a) {
+__device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     constexpr int NW = 4 / PPL;
     constexpr int NB = CH / 32;
     constexpr int NP = GI / 2;        // instance pairs (MFMA K = 2) per group
@@ -285,11 +314,13 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
                 for (int r = 0; r < 16; r++) acc[p][h][nb][r] = 0.f;
     }
 
-    // software pipeline, stage 0: ids + records of the first chunk
-    uint32_t n_id = 0;
+    // software pipeline: the splat records of chunk k+1 and the list ids of chunk k+2 are requested while chunk k
+    // is blended, so neither of the two dependent gathers (id, then record) is ever waited for on the spot
+    uint32_t n_id = 0, f_id = 0;
     float4 n_q0 = make_float4(0, 0, 0, 0), n_q1 = n_q0, n_q2 = n_q0;
+    if (lane < CHK && r_lo + lane < r_hi) n_id = a.point_list[r_lo + lane];
+    if (lane < CHK && r_lo + CHK + lane < r_hi) f_id = a.point_list[r_lo + CHK + lane];
     if (lane < CHK && r_lo + lane < r_hi) {
-        n_id = a.point_list[r_lo + lane];
         const SplatRec* rp = a.rec + n_id;
         n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
     }
@@ -316,17 +347,35 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
             ck.ent[slot] = en;
         }
         __builtin_amdgcn_wave_barrier();
-        // prefetch the next chunk (registers) while this one is blended
+        // prefetch: records of the next chunk (its ids arrived during the previous chunk), ids of the one after
+        n_id = f_id;
         if (lane < CHK && base + CHK + lane < r_hi) {
-            n_id = a.point_list[base + CHK + lane];
             const SplatRec* rp = a.rec + n_id;
             n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
         }
+        if (lane < CHK && base + 2 * CHK + lane < r_hi) f_id = a.point_list[base + 2 * CHK + lane];
 
-        // feature rows of the chunk -> LDS (coalesced: CH/4 lanes x 16 B per instance)
-        {
-            constexpr int CHV = CH / 4;
-            const bool vec_ok = (a.C & 3) == 0 && (a.c0 & 3) == 0;
+        // feature rows of the chunk -> LDS (coalesced: CH/4 lanes x 16 B per instance).  Full-width windows go through
+        // LDS-direct loads (global_load_lds_dwordx4: lane l of a request lands at base + 16 l, which IS the row-major
+        // image because element e = 64 it + lane sits at byte 16 e): all requests of the chunk are in flight together
+        // and no data register is involved; one wait before the blend.
+        constexpr int CHV = CH / 4;
+        const bool vec_ok = (a.C & 3) == 0 && (a.c0 & 3) == 0;
+        if (vec_ok && a.nc == CH) {
+            using lds_ptr = __attribute__((address_space(3))) void*;
+            using gbl_ptr = const __attribute__((address_space(1))) void*;
+#pragma unroll
+            for (int it = 0; it < CHK * CHV / 64; it++) {
+                const int e = it * 64 + lane;
+                if (e < cnt * CHV) {
+                    const uint32_t g = ck.ent[e / CHV].id;
+                    const float* src = a.feat + (size_t)g * a.C + a.c0 + 4 * (e % CHV);
+                    __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)&ck.feat[it * 256], 16, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);    // one address pair live at a time (the requests are asynchronous anyway)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
             for (int e = lane; e < cnt * CHV; e += 64) {
                 const int inst = e / CHV, v = e % CHV;
                 const uint32_t g = ck.ent[inst].id;
@@ -460,11 +509,26 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs 
     }
 }
 
+// Two entry points over one body: the C = 32 shape sits 12 registers above the three-waves-per-SIMD budget and is
+// faster squeezed into it (a few spills outside the blend loop: 0.443 vs 0.506 ms at c3); the C = 64 shape is
+// faster left alone at two waves (2.75 vs 2.98 ms at c4).
+template <int CH, int PPL, int CHK, int GI>
+__global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs a) {
+    render_forward_mfma_body<CH, PPL, CHK, GI>(a);
+}
+template <int CH, int PPL, int CHK, int GI>
+__global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(3, 4))) render_forward_mfma_kernel_w3(FwdArgs a) {
+    render_forward_mfma_body<CH, PPL, CHK, GI>(a);
+}
+
 template <int CH, int PPL, int CHK, int GI>
 void launch_one_mf2(const FwdArgs& a, hipStream_t s) {
     constexpr int NW = 4 / PPL;
     const size_t lds = NW * sizeof(FwdChunkMF<CH, CHK>);
-    hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
+    if (CH <= 32)
+        hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
+    else
+        hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
 }
 template <int CH, int PPL>
 void launch_one_mf(const FwdArgs& a, hipStream_t s) {
