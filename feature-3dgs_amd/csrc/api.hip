@@ -454,6 +454,30 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     return F3DGS_OK;
 }
 
+size_t f3dgs_feature_l1_scratch_bytes(int C, int Cout, int Hg, int Wg, int has_decoder) {
+    if (C <= 0 || Cout <= 0 || Hg <= 0 || Wg <= 0) return 0;
+    return feature_l1_scratch_bytes(C, Cout, Hg, Wg, has_decoder != 0);
+}
+
+int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
+                     const float* bias, const float* gt, float* loss, float* d_feature_map, float* d_weight,
+                     float* d_bias, void* scratch, void* stream) {
+    if (C <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Hg <= 0 || Wg <= 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (!feature_map || !gt || !loss || !d_feature_map || !scratch) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
+    if ((weight == nullptr) != (bias == nullptr)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "weight and bias go together");
+    if (weight) {
+        if (!d_weight || !d_bias) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null decoder gradient");
+        if (!feature_l1_decoder_supported(C))
+            return fail(F3DGS_ERR_UNSUPPORTED, "decoder input width %d: supported are 32, 64, 128", C);
+    } else if (Cout != C) {
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "without a decoder the ground truth must have C = %d channels, got %d", C, Cout);
+    }
+    if ((long long)Hg * Wg * (long long)(Cout > C ? Cout : C) >= (1ll << 40)) return fail(F3DGS_ERR_UNSUPPORTED, "too large");
+    HIP_TRY(launch_feature_l1(C, H, W, Cout, Hg, Wg, feature_map, weight, bias, gt, loss, d_feature_map, d_weight, d_bias,
+                              static_cast<char*>(scratch), static_cast<hipStream_t>(stream)));
+    return F3DGS_OK;
+}
+
 size_t f3dgs_knn_scratch_bytes(int P) { return knn_scratch_bytes((size_t)(P > 0 ? P : 0)); }
 
 int f3dgs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* scratch, void* stream) {

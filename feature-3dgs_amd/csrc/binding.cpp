@@ -198,12 +198,42 @@ torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, tor
     return present;
 }
 
+// fused resize -> 1x1 decoder -> L1 (include/f3dgs.h: f3dgs_feature_l1); returns (loss, d_feature_map, d_weight, d_bias)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+FeatureL1(const torch::Tensor& feature_map, const torch::Tensor& gt, const torch::Tensor& weight, const torch::Tensor& bias) {
+    TORCH_CHECK(feature_map.is_cuda() && gt.is_cuda(), "feature_l1: tensors must live on a HIP device (no CPU path)");
+    TORCH_CHECK(feature_map.dim() == 3 && gt.dim() == 3, "feature_l1: feature_map (C,H,W) and gt (Cout,Hg,Wg) expected");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(feature_map.device());
+    auto fm = dev_f32(feature_map, "feature_map"), g = dev_f32(gt, "gt_feature_map");
+    const bool dec = weight.numel() > 0;
+    torch::Tensor w = weight, b = bias;
+    if (dec) {
+        w = dev_f32(weight, "weight");
+        b = dev_f32(bias, "bias");
+        TORCH_CHECK(w.dim() == 2 && w.size(1) == fm.size(0) && w.size(0) == g.size(0) && b.numel() == g.size(0),
+                    "feature_l1: weight (Cout,C) / bias (Cout) do not match feature_map / gt");
+    }
+    const int C = fm.size(0), H = fm.size(1), W = fm.size(2), Cout = g.size(0), Hg = g.size(1), Wg = g.size(2);
+    auto o = fm.options();
+    torch::Tensor loss = torch::empty({}, o), d_fm = torch::empty_like(fm);
+    torch::Tensor d_w = dec ? torch::empty_like(w) : torch::empty({0}, o), d_b = dec ? torch::empty_like(b) : torch::empty({0}, o);
+    torch::Tensor scratch = torch::empty({(long long)f3dgs_feature_l1_scratch_bytes(C, Cout, Hg, Wg, dec ? 1 : 0)},
+                                         o.dtype(torch::kByte));
+    const int rc = f3dgs_feature_l1(C, H, W, Cout, Hg, Wg, fm.data_ptr<float>(), dec ? w.data_ptr<float>() : nullptr,
+                                    dec ? b.data_ptr<float>() : nullptr, g.data_ptr<float>(), loss.data_ptr<float>(),
+                                    d_fm.data_ptr<float>(), dec ? d_w.data_ptr<float>() : nullptr,
+                                    dec ? d_b.data_ptr<float>() : nullptr, scratch.data_ptr(), current_stream(fm));
+    check_status(rc, "feature_l1");
+    return std::make_tuple(loss, d_fm, d_w, d_b);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_C, m) {
     m.def("rasterize_gaussians", &RasterizeGaussians);
     m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
     m.def("mark_visible", &markVisible);
+    m.def("feature_l1", &FeatureL1);
     m.def("version", []() { return f3dgs_version(); });
     m.def("set_feature_grad_hook", [](py::object fn) { feature_grad_hook() = std::move(fn); },
           "callable(dL_dsemantic_feature) run inside rasterize_gaussians_backward once that tensor is final on the stream; None removes it");

@@ -227,6 +227,13 @@ void launch_iota(uint32_t* dst, size_t n, hipStream_t s);
 void launch_radix_sort_keys_to_order(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b,
                                      size_t n, int nbits, uint32_t* hist, hipStream_t s);
 
+// feature_loss.hip
+size_t feature_l1_scratch_bytes(int C, int Cout, int Hg, int Wg, bool decoder);
+bool feature_l1_decoder_supported(int C);
+hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
+                             const float* bias, const float* gt, float* loss, float* d_feature_map, float* d_weight,
+                             float* d_bias, char* scratch, hipStream_t s);
+
 // knn.hip
 size_t knn_scratch_bytes(size_t P);
 void launch_knn_mean_dist2(int P, const float* points, float* out, char* scratch, hipStream_t s);

@@ -1,0 +1,52 @@
+"""Fused feature-map loss: bilinear resize (align_corners=True) -> optional 1x1-conv decoder
+-> L1 against the ground-truth feature map, forward AND backward in one pass over the data.
+
+Replaces these lines of the reference's training loop (train.py:99-105; decoder: models/networks.py:107-119):
+
+    feature_map = F.interpolate(feature_map.unsqueeze(0), size=(Hg, Wg), mode='bilinear', align_corners=True).squeeze(0)
+    if dataset.speedup: feature_map = cnn_decoder(feature_map)
+    Ll1_feature = l1_loss(feature_map, gt_feature_map)
+
+with
+
+    Ll1_feature = fused_feature_l1(feature_map, gt_feature_map, cnn_decoder.conv.weight, cnn_decoder.conv.bias)
+
+The (C, H, W) rendered map is read once, the (4C, Hg, Wg) decoded map never exists in memory, and the gradient with
+respect to the rendered map - what the rasterizer's backward consumes as dL_dout_feature - is produced by the same
+call.  The decoder is the one dense contraction next to the rasterizer: it runs on the fp32 matrix pipe
+(v_mfma_f32_32x32x2_f32, exact fp32).  HIP only (csrc/feature_loss.hip behind include/f3dgs.h); no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from diff_gaussian_rasterization import _C
+
+
+class _FusedFeatureL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feature_map, gt, weight, bias):
+        loss, d_fm, d_w, d_b = _C.feature_l1(feature_map, gt, weight, bias)
+        ctx.save_for_backward(d_fm, d_w, d_b)
+        ctx.has_decoder = weight.numel() > 0
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d_fm, d_w, d_b = ctx.saved_tensors
+        # the gradients were produced for dL/dloss = 1; the loss is a scalar, so they scale linearly
+        return d_fm * g, None, (d_w * g) if ctx.has_decoder else None, (d_b * g) if ctx.has_decoder else None
+
+
+def fused_feature_l1(feature_map: torch.Tensor, gt_feature_map: torch.Tensor, weight: Optional[torch.Tensor] = None,
+                     bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mean |decode(resize(feature_map)) - gt|.  feature_map (C, H, W), gt (Cout, Hg, Wg), weight (Cout, C) or
+    (Cout, C, 1, 1) and bias (Cout) of the 1x1 decoder, or None for no decoder (then Cout == C)."""
+    e = torch.Tensor([])
+    if weight is None:
+        return _FusedFeatureL1.apply(feature_map, gt_feature_map, e, e)
+    w2 = weight.reshape(weight.shape[0], -1)
+    return _FusedFeatureL1.apply(feature_map, gt_feature_map, w2, bias if bias is not None else torch.zeros(
+        weight.shape[0], device=weight.device, dtype=weight.dtype))

@@ -202,6 +202,21 @@ int f3dgs_backward(
     void* stream /* hipStream_t */);
 
 /*
+ * Fused feature-map loss around the rasterizer (no single counterpart in the reference: it replaces the three
+ * PyTorch calls of train.py:99-105 - F.interpolate(bilinear, align_corners=True) to the ground truth's size, the
+ * optional 1x1-conv decoder `CNN_decoder` (models/networks.py:107-119) and l1_loss (utils/loss_utils.py:17-18) - and
+ * their autograd backward).  feature_map (C,H,W); gt (Cout,Hg,Wg); weight (Cout,C) + bias (Cout) or both NULL for
+ * "no decoder" (then Cout must equal C).  Outputs: *loss (device scalar) = mean |decode(resize(feature_map)) - gt|,
+ * d_feature_map (C,H,W), d_weight (Cout,C), d_bias (Cout): the gradients of that loss (upstream gradient 1; they
+ * scale linearly).  With a decoder C must be 32, 64 or 128 (the contraction runs on the fp32 matrix pipe in
+ * 32-channel blocks); other shapes return F3DGS_ERR_UNSUPPORTED.  `scratch`: f3dgs_feature_l1_scratch_bytes(...) bytes.
+ */
+size_t f3dgs_feature_l1_scratch_bytes(int C, int Cout, int Hg, int Wg, int has_decoder);
+int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
+                     const float* bias, const float* gt, float* loss, float* d_feature_map, float* d_weight,
+                     float* d_bias, void* scratch, void* stream /* hipStream_t */);
+
+/*
  * Replaces SimpleKNN::knn / distCUDA2 of the reference's second native module (submodules/simple-knn/
  * simple_knn.cu:45-221, spatial.cu:15-25; caller scene/gaussian_model.py:146): mean_dist2[i] = mean of the squared
  * distances from point i to its three nearest neighbours (exact; a missing neighbour counts as FLT_MAX, as there).

@@ -112,9 +112,15 @@ for tile in tiles:
             # number of live pixels over the chunk positions
             surv = torch.nonzero(actb & qq).reshape(-1)
             sq_t = torch.from_numpy(sq.astype(np.int64)).to(dev).reshape(-1)
+            # the kernel fills chunks walking BACK to FRONT: the partially filled chunk is the front-most one
+            rs = torch.flip(surv, dims=[0])
             for k in range(0, nb_inst, 64):
-                pmin = int(surv[k])
-                tot["bodies_b"] += int((sq_t > pmin).sum())
+                grp = rs[k:k + 64]
+                pmin = int(grp.min())
+                nb_ = int((sq_t > pmin).sum())
+                tot["bodies_b"] += nb_
+                key = "bodies_le16" if len(grp) <= 16 else ("bodies_le32" if len(grp) <= 32 else "bodies_gt32")
+                tot[key] = tot.get(key, 0) + nb_
             for ry in range(8):
                 qr = rect_min_q(mx, my, a, b, c, float(x0), float(x0 + 7), float(y0 + ry), float(y0 + ry)) <= thr
                 tot["row"] += int((actb & qr).sum())
