@@ -478,6 +478,16 @@ int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float*
     return F3DGS_OK;
 }
 
+int f3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                    double beta2, double eps, int step, void* stream) {
+    if (n == 0) return F3DGS_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
+    if (step < 1) return fail(F3DGS_ERR_INVALID_ARGUMENT, "step counts from 1");
+    launch_adam_step(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return F3DGS_OK;
+}
+
 size_t f3dgs_knn_scratch_bytes(int P) { return knn_scratch_bytes((size_t)(P > 0 ? P : 0)); }
 
 int f3dgs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* scratch, void* stream) {

@@ -227,6 +227,21 @@ FeatureL1(const torch::Tensor& feature_map, const torch::Tensor& gt, const torch
     return std::make_tuple(loss, d_fm, d_w, d_b);
 }
 
+void AdamStep(torch::Tensor& param, const torch::Tensor& grad, torch::Tensor& exp_avg, torch::Tensor& exp_avg_sq, double lr,
+              double beta1, double beta2, double eps, int64_t step) {
+    TORCH_CHECK(param.is_cuda() && grad.is_cuda() && exp_avg.is_cuda() && exp_avg_sq.is_cuda(), "adam_step: HIP tensors only");
+    TORCH_CHECK(param.scalar_type() == torch::kFloat32 && grad.scalar_type() == torch::kFloat32, "adam_step: float32 only");
+    TORCH_CHECK(param.is_contiguous() && exp_avg.is_contiguous() && exp_avg_sq.is_contiguous(), "adam_step: contiguous state");
+    TORCH_CHECK(grad.numel() == param.numel() && exp_avg.numel() == param.numel() && exp_avg_sq.numel() == param.numel(),
+                "adam_step: size mismatch");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(param.device());
+    auto g = grad.contiguous();
+    check_status(f3dgs_adam_step((size_t)param.numel(), param.data_ptr<float>(), g.data_ptr<float>(), exp_avg.data_ptr<float>(),
+                                 exp_avg_sq.data_ptr<float>(), lr, beta1, beta2, eps, (int)step,
+                                 current_stream(param)),
+                 "adam_step");
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_C, m) {
@@ -234,6 +249,7 @@ PYBIND11_MODULE(_C, m) {
     m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
     m.def("mark_visible", &markVisible);
     m.def("feature_l1", &FeatureL1);
+    m.def("adam_step", &AdamStep);
     m.def("version", []() { return f3dgs_version(); });
     m.def("set_feature_grad_hook", [](py::object fn) { feature_grad_hook() = std::move(fn); },
           "callable(dL_dsemantic_feature) run inside rasterize_gaussians_backward once that tensor is final on the stream; None removes it");

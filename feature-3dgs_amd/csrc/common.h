@@ -234,6 +234,10 @@ hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, cons
                              const float* bias, const float* gt, float* loss, float* d_feature_map, float* d_weight,
                              float* d_bias, char* scratch, hipStream_t s);
 
+// adam.hip
+void launch_adam_step(size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps,
+                      int step, hipStream_t s);
+
 // knn.hip
 size_t knn_scratch_bytes(size_t P);
 void launch_knn_mean_dist2(int P, const float* points, float* out, char* scratch, hipStream_t s);

@@ -217,6 +217,14 @@ int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float*
                      float* d_bias, void* scratch, void* stream /* hipStream_t */);
 
 /*
+ * One torch.optim.Adam step (no weight decay, no amsgrad: the reference's configuration,
+ * scene/gaussian_model.py:163-178) over one tensor of n floats, in place; `step` is the 1-based step count of that
+ * tensor.  param / grad / exp_avg / exp_avg_sq are device pointers.
+ */
+int f3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                    double beta2, double eps, int step, void* stream /* hipStream_t */);
+
+/*
  * Replaces SimpleKNN::knn / distCUDA2 of the reference's second native module (submodules/simple-knn/
  * simple_knn.cu:45-221, spatial.cu:15-25; caller scene/gaussian_model.py:146): mean_dist2[i] = mean of the squared
  * distances from point i to its three nearest neighbours (exact; a missing neighbour counts as FLT_MAX, as there).
