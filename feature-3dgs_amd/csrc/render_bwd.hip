@@ -27,6 +27,8 @@
 // recurrence is evaluated in closed form; both are algebraically identical and agree to fp32 round-off
 // (the gradient tolerance of the path is 1e-3 relative).
 
+#include <cstdio>
+
 #include "render_common.h"
 
 namespace f3dgs {
@@ -52,7 +54,8 @@ struct BwdArgs {
     int strip;        // NPIX = 64: 16x4 pixel strips instead of 8x8 quadrants
     int no_wave_cull; // option bwd_wave_cull = 0: no wave-level footprint culling / compaction
 #ifdef F3DGS_DEV
-    int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs
+    int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs, bit3 phase timing
+    unsigned long long* dev_cycles;   // [0] staging, [1] window walk, [2] pixel trips, [3] flush, [4] waves
 #endif
 };
 
@@ -114,8 +117,8 @@ constexpr int FLUSH_STRIDE = FLUSH_GROUP + 1; // odd: conflict-free lane-major w
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int CH, int NPIX, bool MF>
 struct BwdLds {
-    // Row stride (floats) of the MF image: unpadded.  The operand reads of the matrix pipe take one aligned
-    // 32-float row per half-wave (conflict-free); only the one-off staging writes conflict.  Together with
+    // Row stride (floats) of the MF image: unpadded, columns XOR-swizzled by the pixel index (staging writes and
+    // matrix-pipe operand reads are both conflict-free).  Together with
     // the ids riding in the padding column of the flush tile and `touched` as a ballot this makes the NPIX = 64, CH = 32 image 13312 B, i.e. 12
     // waves (3 per SIMD) per CU instead of 11.
     static constexpr int GS = CH;
@@ -130,8 +133,13 @@ struct BwdLds {
 
 #ifdef F3DGS_DEV
 #define F3DGS_DEV_SKIP(bit) (a.dev & (bit))
+// phase timing (dev builds, option dev bit 3): per-wave s_memtime deltas summed into a.dev_cycles[phase]
+#define F3DGS_PHASE_BEGIN() unsigned long long ph_t0_ = (a.dev & 8) ? __builtin_readcyclecounter() : 0ull
+#define F3DGS_PHASE_END(ACC) do { if (a.dev & 8) { const unsigned long long t1_ = __builtin_readcyclecounter(); ACC += t1_ - ph_t0_; ph_t0_ = t1_; } } while (0)
 #else
 #define F3DGS_DEV_SKIP(bit) false      // release builds: compiled out
+#define F3DGS_PHASE_BEGIN() do {} while (0)
+#define F3DGS_PHASE_END(ACC) do {} while (0)
 #endif
 
 struct SplatLane { // one chunk entry per lane
@@ -151,6 +159,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds& L = *reinterpret_cast<Lds*>(smem);
     const int lane = threadIdx.x;
+#ifdef F3DGS_DEV
+    unsigned long long cyc_stage = 0, cyc_walk = 0, cyc_trip = 0, cyc_flush = 0;
+#endif
+    F3DGS_PHASE_BEGIN();
 
     const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
     // a.part_major: the PARTS waves of one tile are scheduled far apart (fewer simultaneous atomics on the same
@@ -179,14 +191,23 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         const int x = px0 + p % PW, y = py0 + p / PW;
         const bool inside = p < NPIX && x < a.W && y < a.H;
         const size_t pid = (size_t)y * a.W + x;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        float Tf = 0.f;
-        v_last[it] = 0;
-        if (inside) {
-            g.x = a.dL_dpix[pid]; g.y = a.dL_dpix[HW + pid]; g.z = a.dL_dpix[2 * HW + pid];
-            g.w = a.dL_ddepth[pid];
-            Tf = a.final_T[pid];
-            v_last[it] = a.n_contrib[pid];
+        // every lane reads a valid address (pixel 0 stands in outside the image) and the values are masked afterwards:
+        // no branch between the loads, so all 6 + CH of them are in flight together - one memory latency per wave
+        // instead of one per plane (measured with per-phase cycle counters: staging was 28 % of a wave's lifetime)
+        const size_t pid_s = inside ? pid : 0;
+        float4 g = make_float4(a.dL_dpix[pid_s], a.dL_dpix[HW + pid_s], a.dL_dpix[2 * HW + pid_s], a.dL_ddepth[pid_s]);
+        float Tf = a.final_T[pid_s];
+        v_last[it] = a.n_contrib[pid_s];
+        float fv[CH > 0 ? CH : 1];
+        if constexpr (CH > 0) {
+            const int ncm1 = a.nc - 1;
+#pragma unroll
+            for (int c = 0; c < CH; c++) fv[c] = a.dL_dfeat[(size_t)(a.c0 + min(c, ncm1)) * HW + pid_s];   // min: wave-uniform
+        }
+        if (!inside) {
+            g = make_float4(0.f, 0.f, 0.f, 0.f);
+            Tf = 0.f;
+            v_last[it] = 0;
         }
         if (p < NPIX) {
             L.pa[p] = make_float4((float)x, (float)y, Tf, Tf * (a.bg[0] * g.x + a.bg[1] * g.y + a.bg[2] * g.z));
@@ -197,17 +218,19 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         if (CH > 0 && p < NPIX) {
 #pragma unroll
             for (int v = 0; v < CHV; v++) {
-                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (inside) {
-                    const size_t cb = (size_t)(a.c0 + 4 * v);
-                    if (4 * v + 0 < a.nc) f.x = a.dL_dfeat[(cb + 0) * HW + pid];
-                    if (4 * v + 1 < a.nc) f.y = a.dL_dfeat[(cb + 1) * HW + pid];
-                    if (4 * v + 2 < a.nc) f.z = a.dL_dfeat[(cb + 2) * HW + pid];
-                    if (4 * v + 3 < a.nc) f.w = a.dL_dfeat[(cb + 3) * HW + pid];
-                }
+                float4 f;
+                f.x = (inside && 4 * v + 0 < a.nc) ? fv[4 * v + 0] : 0.f;
+                f.y = (inside && 4 * v + 1 < a.nc) ? fv[4 * v + 1] : 0.f;
+                f.z = (inside && 4 * v + 2 < a.nc) ? fv[4 * v + 2] : 0.f;
+                f.w = (inside && 4 * v + 3 < a.nc) ? fv[4 * v + 3] : 0.f;
                 if constexpr (MF) {
-                    L.gfm[p * Lds::GS + 4 * v + 0] = f.x; L.gfm[p * Lds::GS + 4 * v + 1] = f.y;
-                    L.gfm[p * Lds::GS + 4 * v + 2] = f.z; L.gfm[p * Lds::GS + 4 * v + 3] = f.w;
+                    // XOR-swizzled columns (c ^ (p & 31)): with lane = pixel the 64 lanes of a store hit 32 different banks
+                    // (unswizzled they all hit bank c: a 64-way conflict on each of the 32 stores, ~2000 LDS cycles per
+                    // wave), and the matrix-pipe reads below (lane = channel, one pixel per half-wave) stay a permutation
+                    // of one 32-float row.  No padding: the image stays 13312 B = 12 waves per CU.
+                    const int sw = p & 31, row = p * Lds::GS + (4 * v & ~31);
+                    L.gfm[row + (((4 * v + 0) & 31) ^ sw)] = f.x; L.gfm[row + (((4 * v + 1) & 31) ^ sw)] = f.y;
+                    L.gfm[row + (((4 * v + 2) & 31) ^ sw)] = f.z; L.gfm[row + (((4 * v + 3) & 31) ^ sw)] = f.w;
                 } else {
                     L.gf[v][p] = f;
                 }
@@ -216,10 +239,12 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     }
     max_last = wave_max_u32(max_last);
     __builtin_amdgcn_wave_barrier();
+    F3DGS_PHASE_END(cyc_stage);
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
     // ---- one (compacted) chunk of up to 64 splats against all live pixels of the wave ---------------------
     auto process = [&](const SplatLane& sl, const uint32_t gid, const uint32_t pos_min) {
+        F3DGS_PHASE_END(cyc_walk);
         float acc[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) acc[k] = 0.f;
@@ -266,7 +291,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     // LDS latency is covered by the alpha evaluation
 #pragma unroll
                     for (int u = 0; u < U; u += 2) {
-                        const int prow = (lane < 32 ? qi[u] : qi[u + 1]) * Lds::GS + (lane & 31);
+                        const int pq = lane < 32 ? qi[u] : qi[u + 1];
+                        const int prow = pq * Lds::GS + ((lane & 31) ^ (pq & 31));        // swizzled column, see the staging
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) Bv[u / 2][nb] = L.gfm[prow + 32 * nb];
                     }
@@ -355,6 +381,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
 
         // ---- flush this chunk: transpose through LDS in groups of 16 values, coalesced atomics -----------
         const unsigned long long tmask = __ballot(touched);
+        F3DGS_PHASE_END(cyc_trip);
         if (tmask == 0 || F3DGS_DEV_SKIP(1)) return;
         L.flush[lane * Lds::FS + Lds::FS - 1] = __uint_as_float(gid);   // the stride's padding column carries the ids
         constexpr int CHF = MF ? 0 : CH;            // feature channels that travel through the LDS transpose
@@ -408,6 +435,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 }
         }
         __builtin_amdgcn_wave_barrier();
+        F3DGS_PHASE_END(cyc_flush);
     };
 
     // ---- walk the list back to front in windows of 64 positions; splats whose 1/255 footprint misses this
@@ -423,14 +451,19 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // software pipeline: the ids + records of window k0 - 64 are requested before window k0 is tested,
     // compacted and (possibly) processed, so the two dependent gathers never sit on the critical path
-    auto load_window = [&](int k0w, float (&f)[10], uint32_t& gid, bool& have) {
+    // three-stage software pipeline over the windows: while window k0 is tested / compacted / processed, the splat
+    // records of window k0 - 64 and the list ids of window k0 - 128 are in flight - neither of the two dependent
+    // gathers is waited for on the spot (per-phase counters: the walk was 10 % of a wave's lifetime with one stage)
+    auto load_ids = [&](int k0w) -> uint32_t {
+        const uint32_t pos = (uint32_t)(k0w + 63 - lane);
+        return (k0w >= 0 && pos < max_last) ? a.point_list[r_lo + pos] : 0u;
+    };
+    auto load_recs = [&](int k0w, uint32_t gid, float (&f)[10], bool& have) {
         const uint32_t pos = (uint32_t)(k0w + 63 - lane);
         have = k0w >= 0 && pos < max_last;
 #pragma unroll
         for (int k = 0; k < 10; k++) f[k] = 0.f;
-        gid = 0;
         if (have) {
-            gid = a.point_list[r_lo + pos];
             const SplatRec* rp = a.rec + gid;
             const float4 q0 = rp->q0, q1 = rp->q1, q2 = rp->q2;
             f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w; f[4] = q1.x; f[5] = q1.y;
@@ -438,10 +471,12 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         }
     };
     float nf[10];
-    uint32_t ngid;
+    uint32_t ngid, fgid;
     bool nhave;
     const int k_top = (int)((max_last + 63) / 64) * 64 - 64;
-    load_window(k_top, nf, ngid, nhave);
+    ngid = load_ids(k_top);
+    fgid = load_ids(k_top - 64);
+    load_recs(k_top, ngid, nf, nhave);
     for (int k0 = k_top; k0 >= 0; k0 -= 64) {
         const uint32_t pos = (uint32_t)(k0 + 63 - lane);     // lane 0 = farthest back within the window
         float f[10];
@@ -449,7 +484,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         for (int k = 0; k < 10; k++) f[k] = nf[k];
         const uint32_t gid = ngid;
         const bool have = nhave;
-        load_window(k0 - 64, nf, ngid, nhave);
+        ngid = fgid;
+        load_recs(k0 - 64, ngid, nf, nhave);
+        fgid = load_ids(k0 - 128);
         const bool hit = have && (a.no_wave_cull || rect_hit(f[0], f[1], f[2], f[3], f[4], f[5], wx0, wx1, wy0, wy1));
         const unsigned long long hmask = __ballot(hit);
         const int c2 = __popcll(hmask);
@@ -475,6 +512,13 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         cur_min = (uint32_t)k0;      // every survivor of this window sits at a position >= k0
     }
     if (count > 0) process(cur, cur_gid, cur_min);
+    F3DGS_PHASE_END(cyc_walk);
+#ifdef F3DGS_DEV
+    if ((a.dev & 8) && lane == 0) {
+        atomicAdd(&a.dev_cycles[0], cyc_stage); atomicAdd(&a.dev_cycles[1], cyc_walk); atomicAdd(&a.dev_cycles[2], cyc_trip);
+        atomicAdd(&a.dev_cycles[3], cyc_flush); atomicAdd(&a.dev_cycles[4], 1ull);
+    }
+#endif
 }
 
 template <int CH, int NPIX, bool MF>
@@ -508,6 +552,22 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     const Options& opt = options();
 #ifdef F3DGS_DEV
     a.dev = opt.dev;
+    static unsigned long long* dev_cycles = nullptr;
+    if (!dev_cycles) (void)hipMalloc(&dev_cycles, 8 * sizeof(unsigned long long));
+    a.dev_cycles = dev_cycles;
+    if (a.dev & 8) (void)hipMemsetAsync(dev_cycles, 0, 8 * sizeof(unsigned long long), s);
+    struct Report {     // prints the phase totals of this launch when it goes out of scope (synchronises: dev only)
+        unsigned long long* d; hipStream_t s; bool on;
+        ~Report() {
+            if (!on) return;
+            unsigned long long h[8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+            const double w = (double)(h[4] ? h[4] : 1);
+            fprintf(stderr, "[f3dgs dev] blend backward, cycles per wave: staging %.0f  window walk %.0f  pixel trips %.0f  flush %.0f  (%llu waves)\n",
+                    h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4]);
+        }
+    } report{dev_cycles, s, (a.dev & 8) != 0};
 #endif
     const int npix = opt.bwd_npix ? opt.bwd_npix : 64;
     a.part_major = opt.bwd_part_major;
