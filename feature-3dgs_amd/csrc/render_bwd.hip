@@ -103,6 +103,23 @@ __device__ __forceinline__ void wave_incl_sum2(float& a, float& b) { F3DGS_SCAN2
 __device__ __forceinline__ void wave_incl_prod4(float& a, float& b, float& c, float& d) { F3DGS_SCAN4("v_mul_f32_dpp"); }
 __device__ __forceinline__ void wave_incl_sum4(float& a, float& b, float& c, float& d) { F3DGS_SCAN4("v_add_f32_dpp"); }
 #undef F3DGS_SCAN4
+// Sums, out of place: the first step reads the inputs (an out-of-range DPP source reads as 0 with bound_ctrl, so
+// the lane still gets its own value) and writes fresh registers - the callers need the inputs afterwards, and this
+// saves the four copies an in-place scan would start with.
+#define F3DGS_STEP4_FIRST(OP, CTRL)                             \
+    OP " %0, %4, %4 " CTRL " bank_mask:0xf bound_ctrl:0\n\t"    \
+    OP " %1, %5, %5 " CTRL " bank_mask:0xf bound_ctrl:0\n\t"    \
+    OP " %2, %6, %6 " CTRL " bank_mask:0xf bound_ctrl:0\n\t"    \
+    OP " %3, %7, %7 " CTRL " bank_mask:0xf bound_ctrl:0\n\t"
+__device__ __forceinline__ void wave_incl_sum4_to(float (&o)[4], float a, float b, float c, float d) {
+    asm volatile("s_nop 1\n\t" F3DGS_STEP4_FIRST("v_add_f32_dpp", "row_shr:1 row_mask:0xf")
+                 F3DGS_STEP4("v_add_f32_dpp", "row_shr:2 row_mask:0xf") F3DGS_STEP4("v_add_f32_dpp", "row_shr:4 row_mask:0xf")
+                 F3DGS_STEP4("v_add_f32_dpp", "row_shr:8 row_mask:0xf") F3DGS_STEP4("v_add_f32_dpp", "row_bcast:15 row_mask:0xa")
+                 F3DGS_STEP4("v_add_f32_dpp", "row_bcast:31 row_mask:0xc") "s_nop 1"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+                 : "v"(a), "v"(b), "v"(c), "v"(d));
+}
+#undef F3DGS_STEP4_FIRST
 #undef F3DGS_STEP4
 
 // LDS image of one wave.  Per-pixel data is wave-uniform in the bodies and is fetched with broadcast
@@ -311,17 +328,18 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                         for (int nb = 0; nb < NB; nb++) Bv[u / 2][nb] = L.gfm[prow + 32 * nb];
                     }
                 }
-                float dx[U], dy[U], G[U], al[U], f[U], q[U], D[U], P[U], Tb[U], w[U], Sinc[U];
+                float dx[U], dy[U], au[U], al[U], f[U], q[U], D[U], P[U], Tb[U], w[U], Sinc[U];
                 bool ok[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     dx[u] = sl.mx - pa[u].x; dy[u] = sl.my - pa[u].y;
-                    const float power = splat_power(dx[u], dy[u], sl.ca, sl.cb, sl.cc);
-                    G[u] = __expf(power);
-                    const float alpha = fminf(ALPHA_MAX, sl.op * G[u]);
+                    const float power2 = splat_power2(dx[u], dy[u], sl.ca, sl.cb, sl.cc);   // conic pre-scaled at staging
+                    const float v = sl.op * __builtin_amdgcn_exp2f(power2);                 // op G, not yet clamped
                     // bitwise, not short-circuit: nothing here may turn into a branch that waits on one broadcast alone
-                    ok[u] = (int)sl.have & (int)act[u] & (int)(sl.pos < lastq[u]) & (int)!(power > 0.0f) & (int)!(alpha < ALPHA_MIN);
-                    al[u] = ok[u] ? alpha : 0.f;
+                    // (min(0.99, v) < 1/255  <=>  v < 1/255)
+                    ok[u] = (int)sl.have & (int)act[u] & (int)(sl.pos < lastq[u]) & (int)!(power2 > 0.0f) & (int)!(v < ALPHA_MIN);
+                    au[u] = ok[u] ? v : 0.f;              // exp2 may be inf where power > 0: selected away, never multiplied
+                    al[u] = fminf(ALPHA_MAX, au[u]);
                     f[u] = __builtin_amdgcn_rcpf(1.f - al[u]);   // 1/(1-alpha); exactly 1 for skipped lanes
                     P[u] = f[u];
                     q[u] = fmaf(sl.cr, pb[u].x, fmaf(sl.cg, pb[u].y, fmaf(sl.cbl, pb[u].z, sl.dep * pb[u].w)));
@@ -334,10 +352,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     Tb[u] = pa[u].z * P[u];           // transmittance in front of this splat
                     w[u] = al[u] * Tb[u];
                     D[u] = w[u] * q[u];
-                    Sinc[u] = D[u];
                 }
-                if constexpr (U == 4) wave_incl_sum4(Sinc[0], Sinc[1], Sinc[2], Sinc[3]);
-                else wave_incl_sum2(Sinc[0], Sinc[1]);
+                if constexpr (U == 4) wave_incl_sum4_to(Sinc, D[0], D[1], D[2], D[3]);
+                else { Sinc[0] = D[0]; Sinc[1] = D[1]; wave_incl_sum2(Sinc[0], Sinc[1]); }
                 // lane 63 holds the chunk totals: it carries the pixel state to the next (nearer) chunk
                 if (lane == 63) {
 #pragma unroll
@@ -349,17 +366,16 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     const float Sbehind = pa[u].w + (Sinc[u] - D[u]);
                     // finite on skipped lanes too (f = 1 there), and every use below is multiplied by Gs = 0 or w = 0
                     const float dL_dalpha = fmaf(Tb[u], q[u], -(Sbehind * f[u]));
-                    const float Gs = ok[u] ? G[u] : 0.f;      // exp(power) may be inf where power > 0
-                    // raw moments of s = G dL/dG over the pixels; the conic and the pixel scale are applied once per
-                    // chunk, before the flush (9 VALU instructions less per pair than accumulating the products)
-                    const float sg = Gs * (sl.op * dL_dalpha);
+                    // raw moments of s = op G dL/dalpha over the pixels; the conic, the pixel scale and 1/op (for
+                    // dL/dopacity = sum G dL/dalpha) are applied once per chunk, before the flush
+                    const float sg = au[u] * dL_dalpha;
                     const float sdx = sg * dx[u], sdy = sg * dy[u];
                     acc[0] += sdx;
                     acc[1] += sdy;
                     acc[2] = fmaf(sdx, dx[u], acc[2]);
                     acc[3] = fmaf(sdx, dy[u], acc[3]);
                     acc[4] = fmaf(sdy, dy[u], acc[4]);
-                    acc[5] = fmaf(Gs, dL_dalpha, acc[5]);
+                    acc[5] += sg;
                     acc[6] = fmaf(w[u], pb[u].x, acc[6]);
                     acc[7] = fmaf(w[u], pb[u].y, acc[7]);
                     acc[8] = fmaf(w[u], pb[u].z, acc[8]);
@@ -398,10 +414,13 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         if (tmask == 0 || F3DGS_DEV_SKIP(1)) return;
         L.flush[lane * Lds::FS + Lds::FS - 1] = __uint_as_float(gid);   // the stride's padding column carries the ids
         {
-            // moments -> dL/d(mean2D) and dL/d(conic):  dG/ddelx = -G (a dx + b dy),  dG/da = -G dx^2 / 2, ...
+            // moments -> dL/d(mean2D), dL/d(conic), dL/d(opacity):  dG/ddelx = -G (a dx + b dy),  dG/da = -G dx^2 / 2, ...
+            // (sl.ca.. are the staged, pre-scaled conic: undo the scale here, once per chunk)
+            const float ca = sl.ca * CONIC_UNSCALE_AC, cb = sl.cb * CONIC_UNSCALE_B, cc = sl.cc * CONIC_UNSCALE_AC;
             const float m1 = acc[0], m2 = acc[1];
-            acc[0] = -ddelx_dx * fmaf(sl.ca, m1, sl.cb * m2);
-            acc[1] = -ddely_dy * fmaf(sl.cc, m2, sl.cb * m1);
+            acc[0] = -ddelx_dx * fmaf(ca, m1, cb * m2);
+            acc[1] = -ddely_dy * fmaf(cc, m2, cb * m1);
+            acc[5] *= __builtin_amdgcn_rcpf(sl.op);      // touched => alpha >= 1/255 somewhere => op > 0
             acc[2] *= -0.5f; acc[3] *= -0.5f; acc[4] *= -0.5f;
         }
         constexpr int CHF = MF ? 0 : CH;            // feature channels that travel through the LDS transpose
@@ -516,7 +535,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         const uint32_t mp = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)pos);
         const uint32_t mg = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)gid);
         if (recv) {
-            cur.mx = m0; cur.my = m1; cur.ca = m2; cur.cb = m3; cur.cc = m4; cur.op = m5;
+            cur.mx = m0; cur.my = m1; cur.op = m5;
+            cur.ca = m2 * CONIC_SCALE_AC; cur.cb = m3 * CONIC_SCALE_B; cur.cc = m4 * CONIC_SCALE_AC;   // see splat_power2
             cur.cr = m6; cur.cg = m7; cur.cbl = m8; cur.dep = m9; cur.pos = mp; cur_gid = mg;
         }
         count += c2;

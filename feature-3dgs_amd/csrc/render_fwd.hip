@@ -109,8 +109,8 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
         // ---- stage one chunk: records (from the prefetch registers) ...
         __builtin_amdgcn_wave_barrier();
         if (lane < cnt) {
-            ck.geo[lane] = n_q0;
-            ck.co[lane] = make_float2(n_q1.x, n_q1.y);
+            ck.geo[lane] = make_float4(n_q0.x, n_q0.y, n_q0.z * CONIC_SCALE_AC, n_q0.w * CONIC_SCALE_B);   // see splat_power2
+            ck.co[lane] = make_float2(n_q1.x * CONIC_SCALE_AC, n_q1.y);
             ck.cd[lane] = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
             ck.id[lane] = n_id;
         }
@@ -167,8 +167,8 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 const float dx = g0.x - pxf[p], dy = g0.y - pyf[p];
-                const float power = splat_power(dx, dy, g0.z, g0.w, g1.x);
-                const float alpha = fminf(ALPHA_MAX, g1.y * __expf(power));
+                const float power = splat_power2(dx, dy, g0.z, g0.w, g1.x);
+                const float alpha = fminf(ALPHA_MAX, g1.y * __builtin_amdgcn_exp2f(power));
                 bool ok = !done[p] && !(power > 0.0f) && !(alpha < ALPHA_MIN);
                 const float test_T = T[p] * (1.0f - alpha);
                 if (ok && test_T < T_MIN) {
@@ -339,9 +339,9 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
         __builtin_amdgcn_wave_barrier();
         if (hit) {
             FwdEntry en;
-            en.geo = n_q0;
+            en.geo = make_float4(n_q0.x, n_q0.y, n_q0.z * CONIC_SCALE_AC, n_q0.w * CONIC_SCALE_B);   // see splat_power2
             en.cd = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
-            en.co_c = n_q1.x; en.co_o = n_q1.y;
+            en.co_c = n_q1.x * CONIC_SCALE_AC; en.co_o = n_q1.y;
             en.pos = base - r_lo + lane + 1;
             en.id = n_id;
             ck.ent[slot] = en;
@@ -427,8 +427,8 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
 #pragma unroll
                 for (int e = 0; e < GI; e++) {
                     const float dx = g0[e].x - pxf[p], dy = g0[e].y - pyf[p];
-                    const float power = splat_power(dx, dy, g0[e].z, g0[e].w, g1[e].x);
-                    araw[e] = fminf(ALPHA_MAX, g1[e].y * __expf(power));
+                    const float power = splat_power2(dx, dy, g0[e].z, g0[e].w, g1[e].x);
+                    araw[e] = fminf(ALPHA_MAX, g1[e].y * __builtin_amdgcn_exp2f(power));
                     valid[e] = live_e[e] && !(power > 0.0f) && !(araw[e] < ALPHA_MIN);
                 }
 #pragma unroll
