@@ -488,6 +488,25 @@ int f3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, f
     return F3DGS_OK;
 }
 
+int f3dgs_densify_gather(size_t n_out, const int32_t* src_row, const uint8_t* kind, const int32_t* override_row, int n_tensors,
+                         const f3dgs_densify_tensor* tensors, void* stream) {
+    if (n_tensors < 0 || n_tensors > F3DGS_DENSIFY_MAX_TENSORS)
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "n_tensors = %d: at most %d per call", n_tensors, F3DGS_DENSIFY_MAX_TENSORS);
+    if (n_out == 0 || n_tensors == 0) return F3DGS_OK;
+    if (!src_row || !kind || !tensors) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
+    for (int i = 0; i < n_tensors; i++) {
+        const f3dgs_densify_tensor& t = tensors[i];
+        if (!t.src || !t.dst || t.width < 1) return fail(F3DGS_ERR_INVALID_ARGUMENT, "tensor %d: null pointer or width < 1", i);
+        if (t.mode < F3DGS_DENSIFY_COPY || t.mode > F3DGS_DENSIFY_OVERRIDE_CHILD)
+            return fail(F3DGS_ERR_INVALID_ARGUMENT, "tensor %d: unknown mode %d", i, t.mode);
+        if (t.mode == F3DGS_DENSIFY_OVERRIDE_CHILD && (!t.override_src || !override_row))
+            return fail(F3DGS_ERR_INVALID_ARGUMENT, "tensor %d: OVERRIDE_CHILD needs override_src and override_row", i);
+    }
+    launch_densify_gather(n_out, src_row, kind, override_row, n_tensors, tensors, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return F3DGS_OK;
+}
+
 size_t f3dgs_knn_scratch_bytes(int P) { return knn_scratch_bytes((size_t)(P > 0 ? P : 0)); }
 
 int f3dgs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* scratch, void* stream) {

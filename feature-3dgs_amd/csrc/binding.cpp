@@ -242,6 +242,44 @@ void AdamStep(torch::Tensor& param, const torch::Tensor& grad, torch::Tensor& ex
                  "adam_step");
 }
 
+// One gather over all per-Gaussian tensors (densify.py builds the plan).  `modes[i]`: F3DGS_DENSIFY_*;
+// `overrides[i]` is the child-row array for mode OVERRIDE_CHILD (an empty tensor otherwise).
+void DensifyGather(const torch::Tensor& src_row, const torch::Tensor& kind, const torch::Tensor& override_row,
+                   const std::vector<torch::Tensor>& srcs, std::vector<torch::Tensor>& dsts,
+                   const std::vector<torch::Tensor>& overrides, const std::vector<int64_t>& modes) {
+    const size_t n_out = (size_t)src_row.numel();
+    TORCH_CHECK(src_row.is_cuda() && src_row.scalar_type() == torch::kInt32 && src_row.is_contiguous(), "densify_gather: src_row must be a contiguous int32 HIP tensor");
+    TORCH_CHECK(kind.is_cuda() && kind.scalar_type() == torch::kUInt8 && kind.is_contiguous() && (size_t)kind.numel() == n_out, "densify_gather: kind must be uint8 of the same length");
+    TORCH_CHECK(override_row.is_cuda() && override_row.scalar_type() == torch::kInt32 && override_row.is_contiguous() && (size_t)override_row.numel() == n_out,
+                "densify_gather: override_row must be int32 of the same length");
+    TORCH_CHECK(srcs.size() == dsts.size() && srcs.size() == modes.size() && srcs.size() == overrides.size(), "densify_gather: list lengths differ");
+    std::vector<f3dgs_densify_tensor> table(srcs.size());
+    for (size_t i = 0; i < srcs.size(); i++) {
+        const auto& a = srcs[i];
+        auto& d = dsts[i];
+        TORCH_CHECK(a.is_cuda() && d.is_cuda() && a.scalar_type() == torch::kFloat32 && d.scalar_type() == torch::kFloat32, "densify_gather: float32 HIP tensors only");
+        TORCH_CHECK(a.is_contiguous() && d.is_contiguous(), "densify_gather: contiguous tensors only");
+        int64_t width = 1;
+        for (int64_t k = 1; k < a.dim(); k++) width *= a.size(k);
+        TORCH_CHECK(a.dim() >= 1 && width >= 1, "densify_gather: tensors are (rows, ...) with non-empty rows");
+        TORCH_CHECK((size_t)d.numel() >= n_out * (size_t)width, "densify_gather: destination ", i, " too small");
+        table[i].src = a.data_ptr<float>();
+        table[i].dst = d.data_ptr<float>();
+        table[i].width = (int)width;
+        table[i].mode = (int)modes[i];
+        table[i].override_src = nullptr;
+        if (modes[i] == F3DGS_DENSIFY_OVERRIDE_CHILD) {
+            const auto& o = overrides[i];
+            TORCH_CHECK(o.is_cuda() && o.scalar_type() == torch::kFloat32 && o.is_contiguous(), "densify_gather: override must be a contiguous float32 HIP tensor");
+            table[i].override_src = o.numel() ? o.data_ptr<float>() : a.data_ptr<float>();   // no children: never read
+        }
+    }
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(src_row.device());
+    check_status(f3dgs_densify_gather(n_out, src_row.data_ptr<int32_t>(), kind.data_ptr<uint8_t>(), override_row.data_ptr<int32_t>(),
+                                      (int)table.size(), table.data(), current_stream(src_row)),
+                 "densify_gather");
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_C, m) {
@@ -250,6 +288,7 @@ PYBIND11_MODULE(_C, m) {
     m.def("mark_visible", &markVisible);
     m.def("feature_l1", &FeatureL1);
     m.def("adam_step", &AdamStep);
+    m.def("densify_gather", &DensifyGather);
     m.def("version", []() { return f3dgs_version(); });
     m.def("set_feature_grad_hook", [](py::object fn) { feature_grad_hook() = std::move(fn); },
           "callable(dL_dsemantic_feature) run inside rasterize_gaussians_backward once that tensor is final on the stream; None removes it");

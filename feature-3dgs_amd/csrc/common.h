@@ -238,6 +238,13 @@ hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, cons
 void launch_adam_step(size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps,
                       int step, hipStream_t s);
 
+// densify.hip
+using DensifyTensor = f3dgs_densify_tensor;
+constexpr int DENSIFY_MAX_TENSORS = F3DGS_DENSIFY_MAX_TENSORS;
+constexpr int DENSIFY_ZERO_NEW = F3DGS_DENSIFY_ZERO_NEW, DENSIFY_OVERRIDE_CHILD = F3DGS_DENSIFY_OVERRIDE_CHILD;
+void launch_densify_gather(size_t n_out, const int32_t* src_row, const uint8_t* kind, const int32_t* override_row, int n_tensors,
+                           const DensifyTensor* tensors, hipStream_t s);
+
 // knn.hip
 size_t knn_scratch_bytes(size_t P);
 void launch_knn_mean_dist2(int P, const float* points, float* out, char* scratch, hipStream_t s);

@@ -225,6 +225,29 @@ int f3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, f
                     double beta2, double eps, int step, void* stream /* hipStream_t */);
 
 /*
+ * Row movement of one densification (scene/gaussian_model.py:300-431: densify_and_clone, densify_and_split,
+ * prune_points and the optimizer-state edits of cat_tensors_to_optimizer / _prune_optimizer) as ONE gather over all
+ * per-Gaussian tensors.  Output row j of every tensor comes from source row src_row[j]; kind[j] says how:
+ *   0 kept original (row and Adam moments copied), 1 clone (row copied, moments zero),
+ *   2 split child (as a clone, but tensors in mode OVERRIDE_CHILD take row override_row[j] of `override_src`:
+ *     the child's new xyz and scaling).
+ * All pointers are device pointers; `dst` buffers are the caller's (capacity-sized, never the same memory as `src`).
+ */
+#define F3DGS_DENSIFY_COPY 0            /* parameters: always the source row */
+#define F3DGS_DENSIFY_ZERO_NEW 1        /* optimizer moments: source row for kind 0, zeros for kinds 1 and 2 */
+#define F3DGS_DENSIFY_OVERRIDE_CHILD 2  /* xyz, scaling: source row for kinds 0/1, override row for kind 2 */
+#define F3DGS_DENSIFY_MAX_TENSORS 32
+typedef struct f3dgs_densify_tensor {
+    const float* src;           /* (n_in, width) */
+    float* dst;                 /* (>= n_out, width) */
+    const float* override_src;  /* (n_children, width) or NULL */
+    int width;                  /* floats per row */
+    int mode;                   /* F3DGS_DENSIFY_* */
+} f3dgs_densify_tensor;
+int f3dgs_densify_gather(size_t n_out, const int32_t* src_row, const uint8_t* kind, const int32_t* override_row, int n_tensors,
+                         const f3dgs_densify_tensor* tensors /* host array */, void* stream /* hipStream_t */);
+
+/*
  * Replaces SimpleKNN::knn / distCUDA2 of the reference's second native module (submodules/simple-knn/
  * simple_knn.cu:45-221, spatial.cu:15-25; caller scene/gaussian_model.py:146): mean_dist2[i] = mean of the squared
  * distances from point i to its three nearest neighbours (exact; a missing neighbour counts as FLT_MAX, as there).

@@ -142,7 +142,12 @@ def build_one(channels: int, force: bool = False, verbose: bool = True, keep_src
 # The reference's Python CALLER of the op, compiled to bytecode (a binary, like the modules above: no reference
 # source enters the tree).  tests/test_gpu_dropin.py executes its `render()` unmodified against the product.
 PY_CALLERS = {"ref_gaussian_renderer.pyc": "/root/reference/gaussian_renderer/__init__.py",
-              "ref_sh_utils.pyc": "/root/reference/utils/sh_utils.py"}
+              "ref_sh_utils.pyc": "/root/reference/utils/sh_utils.py",
+              # the model class whose densification / optimizer-state edits tests/test_densify.py runs as the checker
+              "ref_gaussian_model.pyc": "/root/reference/scene/gaussian_model.py",
+              "ref_general_utils.pyc": "/root/reference/utils/general_utils.py",
+              "ref_graphics_utils.pyc": "/root/reference/utils/graphics_utils.py",
+              "ref_system_utils.pyc": "/root/reference/utils/system_utils.py"}
 
 
 def build_callers(force: bool = False) -> list:

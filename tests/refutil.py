@@ -197,3 +197,48 @@ def grad_errors(got, want):
     scale = np.abs(want).max() + 1e-30
     err = np.abs(got - want)
     return float(err.max() / scale), float((err / (1e-3 * np.abs(want) + 1e-5 * scale)).max())
+
+
+# ---- the reference's GaussianModel class (bytecode), for the densification checker ---------------------------------
+def load_reference_gaussian_model():
+    """`scene.gaussian_model.GaussianModel` of the reference, executed from `oracle/_ref/ref_gaussian_model.pyc`.
+    Its imports resolve to the reference's own utils (bytecode as well), the product's `simple_knn` and a stub
+    `plyfile` (not installed here; only load_ply/save_ply would touch it)."""
+    import importlib.machinery
+    import sys
+    import types
+
+    names = ("ref_gaussian_model.pyc", "ref_general_utils.pyc", "ref_graphics_utils.pyc", "ref_system_utils.pyc", "ref_sh_utils.pyc")
+    for n in names:
+        if not os.path.exists(os.path.join(REF_DIR, n)):
+            pytest.skip(f"oracle/_ref/{n} not built (python oracle/build_ref.py where /root/reference exists)")
+
+    def load(name, file):
+        loader = importlib.machinery.SourcelessFileLoader(name, os.path.join(REF_DIR, file))
+        spec = importlib.util.spec_from_loader(name, loader)
+        mod = importlib.util.module_from_spec(spec)
+        loader.exec_module(mod)
+        return mod
+
+    keys = ("utils", "utils.general_utils", "utils.graphics_utils", "utils.system_utils", "utils.sh_utils", "plyfile")
+    saved = {k: sys.modules.get(k) for k in keys}
+    try:
+        utils_pkg = types.ModuleType("utils")
+        sys.modules["utils"] = utils_pkg
+        for sub, file in (("general_utils", "ref_general_utils.pyc"), ("graphics_utils", "ref_graphics_utils.pyc"),
+                          ("system_utils", "ref_system_utils.pyc"), ("sh_utils", "ref_sh_utils.pyc")):
+            m = load("utils." + sub, file)
+            sys.modules["utils." + sub] = m
+            setattr(utils_pkg, sub, m)
+        if "plyfile" not in sys.modules or sys.modules["plyfile"] is None:
+            ply = types.ModuleType("plyfile")
+            ply.PlyData = ply.PlyElement = type("Unavailable", (), {})
+            sys.modules["plyfile"] = ply
+        import simple_knn._C  # noqa: F401  (the product's distCUDA2: the reference's import line finds it)
+        return load("ref_scene_gaussian_model", "ref_gaussian_model.pyc").GaussianModel
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

@@ -1,0 +1,233 @@
+"""Densification on stable-shape buffers (feature-3dgs_amd/densify.py, csrc/densify.hip).
+
+Checkers, strongest first:
+  * the REFERENCE'S OWN `GaussianModel.densify_and_prune` / `prune_points` (scene/gaussian_model.py:300-431), executed
+    from bytecode (`oracle/_ref/ref_gaussian_model.pyc`, oracle/build_ref.py) on the same device with the same seed:
+    every parameter, Adam moment and statistic must come out EQUAL (bit-exact: copies are copies, and the children
+    are computed with the same torch calls on the same random draw);
+  * `oracle/densify_oracle.py`, a numpy restatement that walks the reference's cat/cat/mask/mask sequence literally,
+    with the random draw injected.
+"""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import refutil as ru
+
+pytestmark = pytest.mark.gpu
+
+GROUPS = (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+          ("scaling", "_scaling"), ("rotation", "_rotation"), ("semantic_feature", "_semantic_feature"))
+
+
+def _tensors(P, C, seed, dev="cuda:0"):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    t = {"_xyz": r(P, 3), "_features_dc": r(P, 1, 3), "_features_rest": 0.1 * r(P, 15, 3),
+         "_opacity": 2.0 * r(P, 1) - 1.0, "_scaling": 0.7 * r(P, 3) - 3.0, "_rotation": r(P, 4),
+         "_semantic_feature": r(P, 1, C)}
+    stats = {"xyz_gradient_accum": torch.rand(P, 1, generator=g) * 4e-4 * 3, "denom": torch.randint(0, 4, (P, 1), generator=g).float(),
+             "max_radii2D": torch.rand(P, generator=g) * 40}
+    return {k: v.to(dev) for k, v in t.items()}, {k: v.to(dev) for k, v in stats.items()}
+
+
+class _Args:
+    percent_dense = 0.01
+    position_lr_init, position_lr_final, position_lr_delay_mult, position_lr_max_steps = 1.6e-4, 1.6e-6, 0.01, 30000
+    feature_lr, opacity_lr, scaling_lr, rotation_lr, semantic_feature_lr = 0.0025, 0.05, 0.005, 0.001, 0.001
+
+
+def _model(cls, tensors, stats, optimizer_cls, adam_steps=2, seed=5):
+    """A model of class `cls` (the reference's GaussianModel or a plain namespace) holding copies of the tensors, its
+    optimizer built the way training_setup does (:163-178) and stepped so that the Adam moments are non-trivial."""
+    if cls is None:
+        m = types.SimpleNamespace()
+    else:
+        m = cls(3)
+    for k, v in tensors.items():
+        setattr(m, k, torch.nn.Parameter(v.clone().requires_grad_(True)))
+    m.spatial_lr_scale = 1.0
+    if cls is None:
+        m.percent_dense = _Args.percent_dense
+        lrs = {"xyz": 1.6e-4, "f_dc": 0.0025, "f_rest": 0.0025 / 20, "opacity": 0.05, "scaling": 0.005, "rotation": 0.001,
+               "semantic_feature": 0.001}
+        m.optimizer = optimizer_cls([{"params": [getattr(m, a)], "lr": lrs[n], "name": n} for n, a in GROUPS], lr=0.0, eps=1e-15)
+    else:
+        m.training_setup(_Args)
+        assert isinstance(m.optimizer, torch.optim.Adam)
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    for _ in range(adam_steps):
+        for _, a in GROUPS:
+            p = getattr(m, a)
+            p.grad = torch.randn(p.shape, device=p.device, generator=g) * 0.01
+        m.optimizer.step()
+    for k, v in stats.items():
+        setattr(m, k, v.clone())
+    return m
+
+
+def _state(m):
+    out = {}
+    for n, a in GROUPS:
+        p = getattr(m, a)
+        out[n] = p.detach()
+        g = [g for g in m.optimizer.param_groups if g["name"] == n][0]
+        assert g["params"][0] is p, f"{n}: the optimizer group does not hold the model's parameter"
+        st = m.optimizer.state.get(p, None)
+        assert st is not None and set(st) >= {"step", "exp_avg", "exp_avg_sq"}, n
+        out[n + ".exp_avg"], out[n + ".exp_avg_sq"] = st["exp_avg"], st["exp_avg_sq"]
+        out[n + ".step"] = torch.as_tensor(st["step"]).float().reshape(1)
+        assert p.requires_grad and p.is_leaf
+    for k in ("xyz_gradient_accum", "denom", "max_radii2D"):
+        out[k] = getattr(m, k)
+    return out
+
+
+def _assert_same(a, b, exact=True):
+    assert a.keys() == b.keys()
+    for k in a:
+        x, y = a[k], b[k]
+        x = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        y = y.detach().cpu().numpy() if isinstance(y, torch.Tensor) else np.asarray(y)
+        assert x.shape == y.shape, (k, x.shape, y.shape)
+        if exact:
+            assert np.array_equal(x, y), (k, float(np.abs(x - y).max()) if x.size else 0)
+        else:
+            np.testing.assert_allclose(x, y, rtol=2e-6, atol=2e-6, err_msg=k)
+
+
+@pytest.fixture(scope="module")
+def RefModel():
+    return ru.load_reference_gaussian_model()
+
+
+CASES = [  # P, C, max_grad, min_opacity, extent, max_screen_size
+    (20000, 16, 0.0002, 0.005, 5.0, None),      # iterations <= opacity_reset_interval: no size threshold (train.py:139)
+    (20000, 32, 0.0002, 0.005, 5.0, 20),        # later: size_threshold = 20
+    (5000, 3, 0.0002, 0.3, 2.0, 20),            # aggressive pruning, small extent (many big_points_ws)
+    (3000, 8, 10.0, 0.005, 5.0, 20),            # nothing cloned or split
+    (3000, 8, 0.0, 0.0, 5.0, None),             # everything cloned or split (threshold 0: the clones' zero gradient passes too)
+]
+
+
+@pytest.mark.parametrize("P,C,max_grad,min_opacity,extent,mss", CASES)
+def test_densify_and_prune_equals_the_reference(RefModel, P, C, max_grad, min_opacity, extent, mss):
+    import densify
+    tensors, stats = _tensors(P, C, seed=P + C)
+    ref = _model(RefModel, tensors, stats, torch.optim.Adam)
+    mine = _model(RefModel, tensors, stats, torch.optim.Adam)
+    _assert_same(_state(ref), _state(mine))
+    torch.manual_seed(123)
+    ref.densify_and_prune(max_grad, min_opacity, extent, mss)
+    torch.manual_seed(123)
+    counts = densify.densify_and_prune(mine, max_grad, min_opacity, extent, mss)
+    assert counts["points"] == ref.get_xyz.shape[0]
+    _assert_same(_state(ref), _state(mine), exact=True)
+    # and the model keeps training: same Adam step on both afterwards
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    grads = {a: torch.randn(getattr(ref, a).shape, device="cuda:0", generator=g) * 0.01 for _, a in GROUPS}
+    for m in (ref, mine):
+        for _, a in GROUPS:
+            getattr(m, a).grad = grads[a].clone()
+        m.optimizer.step()
+    _assert_same(_state(ref), _state(mine), exact=True)
+
+
+def test_prune_points_equals_the_reference(RefModel):
+    import densify
+    tensors, stats = _tensors(10000, 16, seed=3)
+    ref = _model(RefModel, tensors, stats, torch.optim.Adam)
+    mine = _model(RefModel, tensors, stats, torch.optim.Adam)
+    mask = torch.rand(10000, device="cuda:0") < 0.37
+    ref.prune_points(mask)
+    densify.prune_points(mine, mask)
+    _assert_same(_state(ref), _state(mine), exact=True)
+    empty = torch.ones(mine._xyz.shape[0], dtype=torch.bool, device="cuda:0")
+    ref.prune_points(empty)
+    densify.prune_points(mine, empty)
+    assert mine._xyz.shape == (0, 3)
+    _assert_same(_state(ref), _state(mine), exact=True)
+
+
+def _np_state(m):
+    return {k: v.detach().cpu().numpy().copy() for k, v in _state(m).items() if not k.endswith(".step")}
+
+
+@pytest.mark.parametrize("P,C,max_grad,min_opacity,extent,mss", CASES[:3])
+def test_densify_and_prune_equals_the_numpy_restatement(P, C, max_grad, min_opacity, extent, mss):
+    """No reference needed: duck-typed model + FusedAdam against oracle/densify_oracle.py, random draw injected."""
+    import densify
+    from fused_adam import FusedAdam
+    from oracle import densify_oracle as orc
+    tensors, stats = _tensors(P, C, seed=P + 7 * C)
+    mine = _model(None, tensors, stats, FusedAdam)
+    state = _np_state(mine)
+    drawn = {}
+
+    def normal_gpu(mean, std):
+        z = torch.randn(std.shape, generator=torch.Generator().manual_seed(77)).to(std.device)
+        drawn["z"] = z.cpu().numpy()
+        return mean + z * std
+
+    def normal_np(std):
+        return drawn["z"] * std
+
+    counts = densify.densify_and_prune(mine, max_grad, min_opacity, extent, mss, normal=normal_gpu)
+    want = orc.densify_and_prune(state, max_grad, min_opacity, extent, mss, _Args.percent_dense, normal_np)
+    assert counts["cloned"] == want["cloned"] and counts["split"] == want["split"] and counts["points"] == want["points"]
+    got = _np_state(mine)
+    for k in state:
+        x, y = got[k], state[k]
+        assert x.shape == y.shape, (k, x.shape, y.shape)
+        if k in ("xyz", "scaling"):
+            np.testing.assert_allclose(x, y, rtol=3e-6, atol=3e-6, err_msg=k)     # children: exp/log/rotation on two libraries
+        else:
+            assert np.array_equal(x, y), k
+
+
+def test_buffers_keep_their_shape_between_densifications():
+    """Stable shapes: below the capacity nothing is reallocated, the parameters are views of the pool's buffers, and a
+    densification reads one buffer of a pair and writes the other."""
+    import densify
+    from fused_adam import FusedAdam
+    tensors, stats = _tensors(8000, 16, seed=11)
+    m = _model(None, tensors, stats, FusedAdam)
+    pool = densify.RowPool(growth=2.0)
+    densify.densify_and_prune(m, 0.0002, 0.005, 5.0, 20, pool=pool)
+    first = pool.reallocations
+    assert first > 0
+    ptr0 = m._xyz.untyped_storage().data_ptr()
+    for it in range(4):
+        n = m._xyz.shape[0]
+        m.xyz_gradient_accum = torch.rand(n, 1, device="cuda:0") * 3e-4
+        m.denom = torch.ones(n, 1, device="cuda:0")
+        if it % 2:
+            densify.prune_points(m, torch.rand(n, device="cuda:0") < 0.2, pool=pool)
+        else:
+            densify.densify_and_prune(m, 0.00025, 0.005, 5.0, 20, pool=pool)
+        assert m._xyz.shape[0] <= pool.capacity("_xyz")
+        for _, a in GROUPS:
+            p = getattr(m, a)
+            p.grad = torch.randn_like(p) * 0.01
+        m.optimizer.step()
+        assert torch.isfinite(m._xyz).all()
+    # the second buffer of each pair is allocated by the second operation; after that the pairs are reused
+    assert pool.reallocations <= 2 * first
+    assert m._xyz.untyped_storage().data_ptr() in {b.untyped_storage().data_ptr() for b in pool._bufs["_xyz"]}
+    assert ptr0 in {b.untyped_storage().data_ptr() for b in pool._bufs["_xyz"]}
+
+
+def test_c_abi_rejects_bad_plans():
+    import ctypes
+    import os
+    import diff_gaussian_rasterization  # noqa: F401 (loads libf3dgs_hip.so next to torch's HIP runtime)
+    from util import ROOT
+    lib = ctypes.CDLL(os.path.join(ROOT, "feature-3dgs_amd", "csrc", "libf3dgs_hip.so"))
+    lib.f3dgs_densify_gather.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.f3dgs_densify_gather(ctypes.c_size_t(4), None, None, None, 1, None, None) != 0
+    assert lib.f3dgs_densify_gather(ctypes.c_size_t(4), None, None, None, 99, None, None) != 0
+    assert lib.f3dgs_densify_gather(ctypes.c_size_t(0), None, None, None, 0, None, None) == 0
