@@ -11,11 +11,35 @@ namespace f3dgs {
 
 namespace {
 
+// One element's update; every loop below goes through it, so the vector path, the ragged tail and the masked
+// variant round identically (explicit fmaf: no contraction choices left to the compiler).
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float step_size, float b2, float omb1,
+                                            float omb2, float inv_sqrt_bc2, float eps) {
+    m = fmaf(omb1, g - m, m);                  // torch: exp_avg.lerp_(grad, 1 - beta1)
+    v = fmaf(b2, v, (omb2 * g) * g);
+    p -= step_size * (m / fmaf(sqrtf(v), inv_sqrt_bc2, eps));
+}
+
 __global__ void __launch_bounds__(256)
 adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-            float step_size, float b1, float b2, float omb1, float omb2, float inv_sqrt_bc2, float eps) {
+            float step_size, float b1, float b2, float omb1, float omb2, float inv_sqrt_bc2, float eps,
+            const uint8_t* __restrict__ row_mask, uint32_t width) {
     const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= n) return;
+    if (row_mask) {
+        // visibility-masked variant: rows whose mask byte is 0 keep parameter AND moments (no decay) - they cost one
+        // byte of traffic instead of 28 per element
+        const size_t last = (i4 + 4 <= n ? i4 + 4 : n) - 1;
+        const size_t r0 = i4 / width, r1 = last / width;
+        bool any = false;
+        for (size_t r = r0; r <= r1; r++) any = any || row_mask[r] != 0;
+        if (!any) return;
+        for (size_t i = i4; i <= last; i++) {
+            if (!row_mask[i / width]) continue;
+            adam_update(p[i], g[i], m[i], v[i], step_size, b2, omb1, omb2, inv_sqrt_bc2, eps);
+        }
+        return;
+    }
     if (i4 + 4 <= n && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                          reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
         float4 pp = *reinterpret_cast<float4*>(p + i4), mm = *reinterpret_cast<float4*>(m + i4), vv = *reinterpret_cast<float4*>(v + i4);
@@ -23,9 +47,7 @@ adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g, float*
         float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            ma[k] = fmaf(omb1, ga[k] - ma[k], ma[k]);          // torch: exp_avg.lerp_(grad, 1 - beta1)
-            va[k] = b2 * va[k] + omb2 * ga[k] * ga[k];
-            pa[k] -= step_size * (ma[k] / (sqrtf(va[k]) * inv_sqrt_bc2 + eps));
+            adam_update(pa[k], ga[k], ma[k], va[k], step_size, b2, omb1, omb2, inv_sqrt_bc2, eps);
         }
         *reinterpret_cast<float4*>(p + i4) = pp;
         *reinterpret_cast<float4*>(m + i4) = mm;
@@ -33,26 +55,21 @@ adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g, float*
         return;
     }
     for (size_t i = i4; i < n && i < i4 + 4; i++) {
-        const float gi = g[i];
-        const float mi = fmaf(omb1, gi - m[i], m[i]);
-        const float vi = b2 * v[i] + omb2 * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+        adam_update(p[i], g[i], m[i], v[i], step_size, b2, omb1, omb2, inv_sqrt_bc2, eps);
     }
 }
 
 }  // namespace
 
 void launch_adam_step(size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps, int step,
-                      hipStream_t s) {
+                      const uint8_t* row_mask, size_t width, hipStream_t s) {
     if (n == 0) return;
     // every derived constant is formed in double from the caller's doubles and rounded once, like torch does
     // (1 - 0.999f in float is off by 1.3e-5 relative)
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     const size_t threads = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, n, p, g, m, v, (float)(lr / bc1), (float)b1,
-                       (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)(1.0 / sqrt(bc2)), (float)eps);
+                       (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)(1.0 / sqrt(bc2)), (float)eps, row_mask, (uint32_t)(width ? width : 1));
 }
 
 }  // namespace f3dgs

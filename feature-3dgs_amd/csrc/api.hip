@@ -480,10 +480,17 @@ int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float*
 
 int f3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
                     double beta2, double eps, int step, void* stream) {
+    return f3dgs_adam_step_rows(n, 1, nullptr, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, stream);
+}
+
+int f3dgs_adam_step_rows(size_t n, size_t width, const uint8_t* row_mask, float* param, const float* grad, float* exp_avg,
+                         float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int step, void* stream) {
     if (n == 0) return F3DGS_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
     if (step < 1) return fail(F3DGS_ERR_INVALID_ARGUMENT, "step counts from 1");
-    launch_adam_step(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, static_cast<hipStream_t>(stream));
+    if (row_mask && (width == 0 || n % width != 0 || width > 0xFFFFFFFFull))
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "n = %zu is not a whole number of rows of %zu floats", n, width);
+    launch_adam_step(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, row_mask, width, static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());
     return F3DGS_OK;
 }
@@ -497,6 +504,7 @@ int f3dgs_densify_gather(size_t n_out, const int32_t* src_row, const uint8_t* ki
     for (int i = 0; i < n_tensors; i++) {
         const f3dgs_densify_tensor& t = tensors[i];
         if (!t.src || !t.dst || t.width < 1) return fail(F3DGS_ERR_INVALID_ARGUMENT, "tensor %d: null pointer or width < 1", i);
+        if (t.width > 65536) return fail(F3DGS_ERR_UNSUPPORTED, "tensor %d: rows of %d floats (at most 65536)", i, t.width);
         if (t.mode < F3DGS_DENSIFY_COPY || t.mode > F3DGS_DENSIFY_OVERRIDE_CHILD)
             return fail(F3DGS_ERR_INVALID_ARGUMENT, "tensor %d: unknown mode %d", i, t.mode);
         if (t.mode == F3DGS_DENSIFY_OVERRIDE_CHILD && (!t.override_src || !override_row))

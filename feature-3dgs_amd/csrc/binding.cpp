@@ -228,7 +228,7 @@ FeatureL1(const torch::Tensor& feature_map, const torch::Tensor& gt, const torch
 }
 
 void AdamStep(torch::Tensor& param, const torch::Tensor& grad, torch::Tensor& exp_avg, torch::Tensor& exp_avg_sq, double lr,
-              double beta1, double beta2, double eps, int64_t step) {
+              double beta1, double beta2, double eps, int64_t step, const c10::optional<torch::Tensor>& row_mask) {
     TORCH_CHECK(param.is_cuda() && grad.is_cuda() && exp_avg.is_cuda() && exp_avg_sq.is_cuda(), "adam_step: HIP tensors only");
     TORCH_CHECK(param.scalar_type() == torch::kFloat32 && grad.scalar_type() == torch::kFloat32, "adam_step: float32 only");
     TORCH_CHECK(param.is_contiguous() && exp_avg.is_contiguous() && exp_avg_sq.is_contiguous(), "adam_step: contiguous state");
@@ -236,9 +236,19 @@ void AdamStep(torch::Tensor& param, const torch::Tensor& grad, torch::Tensor& ex
                 "adam_step: size mismatch");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(param.device());
     auto g = grad.contiguous();
-    check_status(f3dgs_adam_step((size_t)param.numel(), param.data_ptr<float>(), g.data_ptr<float>(), exp_avg.data_ptr<float>(),
-                                 exp_avg_sq.data_ptr<float>(), lr, beta1, beta2, eps, (int)step,
-                                 current_stream(param)),
+    const uint8_t* mask = nullptr;
+    size_t width = 1;
+    torch::Tensor mk;
+    if (row_mask.has_value() && row_mask->defined()) {
+        TORCH_CHECK(param.dim() >= 1 && row_mask->numel() == param.size(0), "adam_step: one mask entry per row");
+        TORCH_CHECK(row_mask->is_cuda(), "adam_step: the mask must be a HIP tensor");
+        mk = row_mask->to(torch::kUInt8).contiguous();      // bool / uint8 / int masks alike
+        mask = mk.data_ptr<uint8_t>();
+        width = param.size(0) ? (size_t)(param.numel() / param.size(0)) : 1;
+    }
+    check_status(f3dgs_adam_step_rows((size_t)param.numel(), width, mask, param.data_ptr<float>(), g.data_ptr<float>(),
+                                      exp_avg.data_ptr<float>(), exp_avg_sq.data_ptr<float>(), lr, beta1, beta2, eps, (int)step,
+                                      current_stream(param)),
                  "adam_step");
 }
 
@@ -287,7 +297,8 @@ PYBIND11_MODULE(_C, m) {
     m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
     m.def("mark_visible", &markVisible);
     m.def("feature_l1", &FeatureL1);
-    m.def("adam_step", &AdamStep);
+    m.def("adam_step", &AdamStep, py::arg("param"), py::arg("grad"), py::arg("exp_avg"), py::arg("exp_avg_sq"), py::arg("lr"),
+          py::arg("beta1"), py::arg("beta2"), py::arg("eps"), py::arg("step"), py::arg("row_mask") = py::none());
     m.def("densify_gather", &DensifyGather);
     m.def("version", []() { return f3dgs_version(); });
     m.def("set_feature_grad_hook", [](py::object fn) { feature_grad_hook() = std::move(fn); },

@@ -236,7 +236,7 @@ hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, cons
 
 // adam.hip
 void launch_adam_step(size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps,
-                      int step, hipStream_t s);
+                      int step, const uint8_t* row_mask, size_t width, hipStream_t s);
 
 // densify.hip
 using DensifyTensor = f3dgs_densify_tensor;

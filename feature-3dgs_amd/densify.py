@@ -13,7 +13,8 @@ Drop-in for the two calls the reference's training loop makes on its model (trai
 `xyz_gradient_accum`, `denom`, `max_radii2D`, `percent_dense`, and `optimizer` with one param group per tensor named
 like the reference's (`xyz`, `f_dc`, ..., :168-176).  After the call the model is in the state the reference's methods
 leave it in - same row order, same values, same optimizer-state edits (new `nn.Parameter` objects registered in the
-groups, `exp_avg`/`exp_avg_sq` carried for kept rows and zero for new ones, `step` untouched):
+groups, `exp_avg`/`exp_avg_sq` carried for kept rows and zero for new ones, `step` untouched; everything bit for bit
+except the children's positions, which differ by the rounding of a 3-term dot product, see below):
 
   densify_and_clone (:398-413)   rows with |grad| >= t and max scale <= percent_dense * extent are appended as copies
   densify_and_split (:378-396)   rows (of the grown set; clones carry gradient 0) with grad >= t and max scale >
@@ -202,7 +203,9 @@ def densify_and_prune(model, max_grad: float, min_opacity: float, extent: float,
     means = torch.zeros((stds.size(0), 3), device=dev)
     samples = normal(mean=means, std=stds)                              # the reference's call, the reference's stream
     rots = _unit_rotation_matrices(model._rotation[sel]).repeat(N, 1, 1)
-    child_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + model._xyz[sel].repeat(N, 1)
+    # R s as three multiply-adds per row (the reference calls torch.bmm here: the same numbers up to the summation
+    # order of a 3-term dot product, but a batched-GEMM launch over ~10^6 3x3 matrices takes 13 ms, this takes 0.1)
+    child_xyz = (rots * samples[:, None, :]).sum(-1) + model._xyz[sel].repeat(N, 1)
     child_scaling = torch.log(scal[sel].repeat(N, 1) / (0.8 * N))       # scaling_inverse_activation = log
     child_src = sel.repeat(N)
 

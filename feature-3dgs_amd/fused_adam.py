@@ -20,7 +20,10 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, visibility=None):
+        """`visibility` (optional, (P,) bool/uint8 HIP tensor, e.g. `radii > 0`): an EXTENSION beyond the reference -
+        only those rows of every (P, ...) tensor are stepped, the others keep parameter and moments (torch.optim.Adam
+        would still move a never-visible Gaussian by its decaying first moment).  Default: the reference's dense Adam."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -36,6 +39,7 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
+                mask = visibility if visibility is not None and p.dim() >= 1 and p.shape[0] == visibility.shape[0] else None
                 _C.adam_step(p, p.grad, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
-                             int(st["step"]))
+                             int(st["step"]), mask)
         return loss

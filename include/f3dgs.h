@@ -223,6 +223,15 @@ int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float*
  */
 int f3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
                     double beta2, double eps, int step, void* stream /* hipStream_t */);
+/*
+ * The same step restricted to the rows (of `width` floats) whose row_mask byte is non-zero: the other rows keep
+ * parameter and moments untouched.  An EXTENSION (row f-4's "sparse-aware Adam using radii > 0"), not the reference's
+ * optimizer: torch.optim.Adam also moves never-visible Gaussians by their decaying first moment.  row_mask == NULL is
+ * f3dgs_adam_step.
+ */
+int f3dgs_adam_step_rows(size_t n, size_t width, const uint8_t* row_mask, float* param, const float* grad, float* exp_avg,
+                         float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int step,
+                         void* stream /* hipStream_t */);
 
 /*
  * Row movement of one densification (scene/gaussian_model.py:300-431: densify_and_clone, densify_and_split,

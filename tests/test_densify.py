@@ -86,14 +86,18 @@ def _state(m):
     return out
 
 
-def _assert_same(a, b, exact=True):
+def _assert_same(a, b, exact=True, loose=()):
+    """Equal, bit for bit; keys in `loose` (the split children's positions: a 3-term dot product summed by rocBLAS in
+    the reference, by three multiply-adds in the product) within 4 ulp of the coordinate scale."""
     assert a.keys() == b.keys()
     for k in a:
         x, y = a[k], b[k]
         x = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
         y = y.detach().cpu().numpy() if isinstance(y, torch.Tensor) else np.asarray(y)
         assert x.shape == y.shape, (k, x.shape, y.shape)
-        if exact:
+        if k in loose:
+            assert x.size == 0 or np.abs(x - y).max() <= 5e-7 * max(1.0, np.abs(y).max()), (k, float(np.abs(x - y).max()))
+        elif exact:
             assert np.array_equal(x, y), (k, float(np.abs(x - y).max()) if x.size else 0)
         else:
             np.testing.assert_allclose(x, y, rtol=2e-6, atol=2e-6, err_msg=k)
@@ -125,7 +129,9 @@ def test_densify_and_prune_equals_the_reference(RefModel, P, C, max_grad, min_op
     torch.manual_seed(123)
     counts = densify.densify_and_prune(mine, max_grad, min_opacity, extent, mss)
     assert counts["points"] == ref.get_xyz.shape[0]
-    _assert_same(_state(ref), _state(mine), exact=True)
+    _assert_same(_state(ref), _state(mine), exact=True, loose=("xyz",))
+    same_rows = (ref.get_xyz == mine._xyz).all(dim=1)
+    assert int((~same_rows).sum()) <= 2 * counts["split"]          # only children may differ at all
     # and the model keeps training: same Adam step on both afterwards
     g = torch.Generator(device="cuda:0").manual_seed(9)
     grads = {a: torch.randn(getattr(ref, a).shape, device="cuda:0", generator=g) * 0.01 for _, a in GROUPS}
@@ -133,7 +139,7 @@ def test_densify_and_prune_equals_the_reference(RefModel, P, C, max_grad, min_op
         for _, a in GROUPS:
             getattr(m, a).grad = grads[a].clone()
         m.optimizer.step()
-    _assert_same(_state(ref), _state(mine), exact=True)
+    _assert_same(_state(ref), _state(mine), exact=True, loose=("xyz",))
 
 
 def test_prune_points_equals_the_reference(RefModel):

@@ -60,3 +60,31 @@ def test_rejects_cpu_tensors():
     p.grad = torch.ones(4)
     with pytest.raises(Exception):
         FusedAdam([p]).step()
+
+
+def test_visibility_masked_step_touches_only_visible_rows():
+    """The opt-in sparse variant (row f-4): visible rows get exactly the dense update, the others keep parameter and
+    moments bit for bit."""
+    from fused_adam import FusedAdam
+    dev = "cuda:0"
+    ga, gb = _groups(dev, P=4099), _groups(dev, P=4099)
+    a, b = FusedAdam(ga, lr=0.0, eps=1e-15), FusedAdam(gb, lr=0.0, eps=1e-15)
+    gen = torch.Generator().manual_seed(5)
+    vis = (torch.rand(4099, generator=gen) < 0.4).to(dev)
+    for it in range(3):
+        for grp_a, grp_b in zip(a.param_groups, b.param_groups):
+            grad = torch.randn(grp_a["params"][0].shape, generator=gen).to(dev) * 0.01
+            grp_a["params"][0].grad, grp_b["params"][0].grad = grad.clone(), grad.clone()
+        before = [(g["params"][0].detach().clone(), {k: v.clone() for k, v in b.state[g["params"][0]].items() if k != "step"} if it else None)
+                  for g in b.param_groups]
+        a.step()
+        b.step(visibility=vis if it == 2 else None)          # two dense steps build state, the third is masked
+        if it < 2:
+            continue
+        for grp_a, grp_b, (p0, st0) in zip(a.param_groups, b.param_groups, before):
+            pa, pb = grp_a["params"][0].detach(), grp_b["params"][0].detach()
+            assert torch.equal(pa[vis], pb[vis]), grp_a["name"]
+            assert torch.equal(pb[~vis], p0[~vis]), grp_a["name"]
+            sa, sb = a.state[grp_a["params"][0]], b.state[grp_b["params"][0]]
+            for k in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(sa[k][vis], sb[k][vis]) and torch.equal(sb[k][~vis], st0[k][~vis]), (grp_a["name"], k)
