@@ -93,17 +93,18 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* __restr
 // consecutive items (lane = item within the step).  BITS = digit width (8 for tile ids, 11 for the 32-bit
 // depth keys: 3 passes instead of 4).  vals_in == nullptr means "value = item index" (first pass of the
 // depth sort: saves an iota kernel and a key copy).
-template <int BITS>
+template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
                                                                   int shift, uint32_t nb,
                                                                   uint32_t* __restrict__ hist) {
     constexpr int BINS = 1 << BITS;
+    constexpr int CHUNK = SORT_THREADS * ITEMS;
     __shared__ uint32_t h[BINS];
     for (int d = threadIdx.x; d < BINS; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
+    const size_t base = (size_t)blockIdx.x * CHUNK;
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         const size_t i = base + (size_t)k * SORT_THREADS + threadIdx.x;
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & (BINS - 1)], 1u);
     }
@@ -138,13 +139,14 @@ __device__ __forceinline__ void record_range(uint2* ranges_enc, uint32_t tile, b
     if (last) atomicMin(&ranges_enc[tile].y, 0xFFFFFFFFu - (pos + 1u));
 }
 
-template <int BITS, bool REORDER, bool RANGES>
+template <int BITS, int ITEMS, bool REORDER, bool RANGES>
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
                      uint32_t nb, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
                      uint2* __restrict__ ranges_enc) {
     constexpr int BINS = 1 << BITS;
+    constexpr int CHUNK = SORT_THREADS * ITEMS;
     constexpr int BPT = BINS / SORT_THREADS;   // bins per thread in the offset phase
     __shared__ uint32_t cnt[4][BINS];
     __shared__ uint32_t sh[8];
@@ -152,19 +154,19 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     // addresses per digit (16 items per digit on average) instead of 64 unrelated 4-byte scatters.
     __shared__ uint32_t gbase[REORDER ? BINS : 1];     // global offset of this workgroup's run of digit d
     __shared__ uint32_t lstart[REORDER ? BINS : 1];    // start of digit d inside the LDS-sorted chunk
-    __shared__ uint32_t skey[REORDER ? SORT_CHUNK : 1];
-    __shared__ uint32_t sval[REORDER ? SORT_CHUNK : 1];
+    __shared__ uint32_t skey[REORDER ? CHUNK : 1];
+    __shared__ uint32_t sval[REORDER ? CHUNK : 1];
     volatile uint32_t* vcnt = &cnt[0][0];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int d = threadIdx.x; d < 4 * BINS; d += SORT_THREADS) (&cnt[0][0])[d] = 0;
     __syncthreads();
 
-    const size_t wbase = (size_t)blockIdx.x * SORT_CHUNK + (size_t)w * (SORT_ITEMS * 64);
-    uint32_t key[SORT_ITEMS];
-    uint32_t rank[SORT_ITEMS];
+    const size_t wbase = (size_t)blockIdx.x * CHUNK + (size_t)w * (ITEMS * 64);
+    uint32_t key[ITEMS];
+    uint32_t rank[ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         const size_t i = wbase + (size_t)k * 64 + lane;
         const bool valid = i < n;
         key[k] = valid ? keys_in[i] : 0xFFFFFFFFu;
@@ -214,7 +216,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     __syncthreads();
     if (REORDER) {
 #pragma unroll
-        for (int k = 0; k < SORT_ITEMS; k++) {
+        for (int k = 0; k < ITEMS; k++) {
             const size_t i = wbase + (size_t)k * 64 + lane;
             if (i < n) {
                 const uint32_t d = (key[k] >> shift) & (BINS - 1);
@@ -224,10 +226,10 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
             }
         }
         __syncthreads();
-        const size_t cbase = (size_t)blockIdx.x * SORT_CHUNK;
-        const uint32_t have = (uint32_t)min((size_t)SORT_CHUNK, n - cbase);
+        const size_t cbase = (size_t)blockIdx.x * CHUNK;
+        const uint32_t have = (uint32_t)min((size_t)CHUNK, n - cbase);
 #pragma unroll
-        for (int k = 0; k < SORT_ITEMS; k++) {
+        for (int k = 0; k < ITEMS; k++) {
             const uint32_t j = (uint32_t)k * SORT_THREADS + threadIdx.x;
             if (j < have) {
                 const uint32_t kk = skey[j];
@@ -240,7 +242,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < SORT_ITEMS; k++) {
+        for (int k = 0; k < ITEMS; k++) {
             const size_t i = wbase + (size_t)k * 64 + lane;
             if (i < n) {
                 const uint32_t d = (key[k] >> shift) & (BINS - 1);
@@ -421,18 +423,23 @@ void launch_exclusive_scan(const uint32_t* in, const uint32_t* gather, uint32_t*
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, in, gather, n, tmp, out);
 }
 
-template <int BITS>
+// ITEMS = keys per thread: 8 for the depth sort (2048-key workgroups: P = 1M gives 489 workgroups, about two per CU;
+// with 16 there are fewer workgroups than CUs and every pass is one latency chain: 0.116 -> 0.097 ms at c3), 16 for
+// the tile sort (twice the instances, and the LDS reorder pays more on longer runs: 0.119 vs 0.128 ms with 8).
+template <int BITS, int ITEMS>
 static void radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n, int shift,
-                       uint32_t nb, uint32_t* hist, hipStream_t s, uint2* ranges_enc = nullptr) {
+                       uint32_t* hist, hipStream_t s, uint2* ranges_enc = nullptr) {
     constexpr int BINS = 1 << BITS;
+    static_assert(ITEMS >= SORT_ITEMS, "the histogram buffers are sized for SORT_ITEMS keys per thread");
+    const uint32_t nb = (uint32_t)((n + SORT_THREADS * ITEMS - 1) / (SORT_THREADS * ITEMS));
     uint32_t* totals = hist + (size_t)BINS * nb;
-    hipLaunchKernelGGL((radix_hist_kernel<BITS>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, n, shift, nb, hist);
+    hipLaunchKernelGGL((radix_hist_kernel<BITS, ITEMS>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, n, shift, nb, hist);
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(BINS), dim3(256), 0, s, hist, nb, totals);
     if (ranges_enc && BITS <= 8)
-        hipLaunchKernelGGL((radix_scatter_kernel<BITS, true, true>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko, vo, n,
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, ITEMS, true, true>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko, vo, n,
                            shift, nb, hist, totals, ranges_enc);
     else
-        hipLaunchKernelGGL((radix_scatter_kernel<BITS, (BITS <= 8), false>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko,
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, ITEMS, (BITS <= 8), false>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko,
                            vo, n, shift, nb, hist, totals, (uint2*)nullptr);
 }
 
@@ -441,14 +448,13 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
     // Input is expected in A when (#passes even) == result_in_a, else in B; the caller arranges that.
     const int passes = (nbits + RADIX_BITS - 1) / RADIX_BITS;
     if (n == 0 || passes == 0) return;
-    const uint32_t nb = (uint32_t)sort_blocks(n);
     bool in_a = (passes % 2 == 0) ? result_in_a : !result_in_a;
     for (int p = 0; p < passes; p++) {
         uint32_t* ki = in_a ? key_a : key_b;
         uint32_t* vi = in_a ? val_a : val_b;
         uint32_t* ko = in_a ? key_b : key_a;
         uint32_t* vo = in_a ? val_b : val_a;
-        radix_pass<RADIX_BITS>(ki, vi, ko, vo, n, p * RADIX_BITS, nb, hist, s, p == passes - 1 ? ranges_enc : nullptr);
+        radix_pass<RADIX_BITS, 16>(ki, vi, ko, vo, n, p * RADIX_BITS, hist, s, p == passes - 1 ? ranges_enc : nullptr);
         in_a = !in_a;
     }
 }
@@ -458,20 +464,19 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
 void launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
                        uint32_t* hist, hipStream_t s) {
     if (n == 0) return;
-    const uint32_t nb = (uint32_t)sort_blocks(n);
     if (n > 200000) {
         // large P: four 8-bit passes are faster than three 11-bit ones (measured at 1M: 0.105 vs 0.148 ms);
         // small P is launch-bound and prefers fewer passes.  Result must end in (key_a, val_a): A <- keys, then
         // A -> B -> A -> ... needs an odd number of remaining hops, so the first pass writes into B.
-        radix_pass<RADIX_BITS>(keys, nullptr, key_b, val_b, n, 0, nb, hist, s);
-        radix_pass<RADIX_BITS>(key_b, val_b, key_a, val_a, n, 8, nb, hist, s);
-        radix_pass<RADIX_BITS>(key_a, val_a, key_b, val_b, n, 16, nb, hist, s);
-        radix_pass<RADIX_BITS>(key_b, val_b, key_a, val_a, n, 24, nb, hist, s);
+        radix_pass<RADIX_BITS, SORT_ITEMS>(keys, nullptr, key_b, val_b, n, 0, hist, s);
+        radix_pass<RADIX_BITS, SORT_ITEMS>(key_b, val_b, key_a, val_a, n, 8, hist, s);
+        radix_pass<RADIX_BITS, SORT_ITEMS>(key_a, val_a, key_b, val_b, n, 16, hist, s);
+        radix_pass<RADIX_BITS, SORT_ITEMS>(key_b, val_b, key_a, val_a, n, 24, hist, s);
         return;
     }
-    radix_pass<DEPTH_RADIX_BITS>(keys, nullptr, key_a, val_a, n, 0, nb, hist, s);
-    radix_pass<DEPTH_RADIX_BITS>(key_a, val_a, key_b, val_b, n, DEPTH_RADIX_BITS, nb, hist, s);
-    radix_pass<DEPTH_RADIX_BITS>(key_b, val_b, key_a, val_a, n, 2 * DEPTH_RADIX_BITS, nb, hist, s);
+    radix_pass<DEPTH_RADIX_BITS, SORT_ITEMS>(keys, nullptr, key_a, val_a, n, 0, hist, s);
+    radix_pass<DEPTH_RADIX_BITS, SORT_ITEMS>(key_a, val_a, key_b, val_b, n, DEPTH_RADIX_BITS, hist, s);
+    radix_pass<DEPTH_RADIX_BITS, SORT_ITEMS>(key_b, val_b, key_a, val_a, n, 2 * DEPTH_RADIX_BITS, hist, s);
 }
 
 
@@ -524,14 +529,13 @@ void launch_radix_sort_keys_to_order(const uint32_t* keys, uint32_t* key_a, uint
                                      size_t n, int nbits, uint32_t* hist, hipStream_t s) {
     const int passes = (nbits + RADIX_BITS - 1) / RADIX_BITS;
     if (n == 0 || passes == 0) return;
-    const uint32_t nb = (uint32_t)sort_blocks(n);
     bool to_a = (passes % 2) == 1;        // the last pass must write the A side
     const uint32_t* ki = keys;
     const uint32_t* vi = nullptr;
     for (int p = 0; p < passes; p++) {
         uint32_t* ko = to_a ? key_a : key_b;
         uint32_t* vo = to_a ? val_a : val_b;
-        radix_pass<RADIX_BITS>(ki, vi, ko, vo, n, p * RADIX_BITS, nb, hist, s);
+        radix_pass<RADIX_BITS, SORT_ITEMS>(ki, vi, ko, vo, n, p * RADIX_BITS, hist, s);
         ki = ko; vi = vo;
         to_a = !to_a;
     }

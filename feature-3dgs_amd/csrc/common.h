@@ -48,7 +48,7 @@ constexpr int RADIX_BINS = 1 << RADIX_BITS;
 constexpr int DEPTH_RADIX_BITS = 11;          // depth-key passes: 11 + 11 + 10 bits
 constexpr int DEPTH_RADIX_BINS = 1 << DEPTH_RADIX_BITS;
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 16;                                  // items per thread
+constexpr int SORT_ITEMS = 8;                                   // fewest keys per thread of any pass (sizes the histograms)
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;           // items per workgroup
 constexpr int SCAN_CHUNK = 256 * 16;
 constexpr int DEPTH_SORT_ITEMS = 8;                             // onesweep depth passes: 2048 keys per workgroup
