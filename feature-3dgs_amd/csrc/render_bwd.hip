@@ -522,24 +522,40 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         const unsigned long long hmask = __ballot(hit);
         const int c2 = __popcll(hmask);
         if (c2 == 0) continue;
+        // push survivors [first, first + n) of this window (in lane order = back to front) to lanes at .. at + n - 1
+        // of the chunk; the other lanes aim at a lane whose result is unused
+        const int rank = __popcll(hmask & lt_mask);
+        auto append = [&](int first, int n, int at) {
+            const bool mine = hit && rank >= first && rank < first + n;
+            const int dest = mine ? at + rank - first : (at > 0 ? 0 : n & 63);
+            const bool recv = lane >= at && lane < at + n;
+            auto push = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(v))); };
+            const float m0 = push(f[0]), m1 = push(f[1]), m2 = push(f[2]), m3 = push(f[3]), m4 = push(f[4]);
+            const float m5 = push(f[5]), m6 = push(f[6]), m7 = push(f[7]), m8 = push(f[8]), m9 = push(f[9]);
+            const uint32_t mp = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)pos);
+            const uint32_t mg = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)gid);
+            if (recv) {
+                cur.mx = m0; cur.my = m1; cur.op = m5;
+                cur.ca = m2 * CONIC_SCALE_AC; cur.cb = m3 * CONIC_SCALE_B; cur.cc = m4 * CONIC_SCALE_AC;   // see splat_power2
+                cur.cr = m6; cur.cg = m7; cur.cbl = m8; cur.dep = m9; cur.pos = mp; cur_gid = mg;
+            }
+        };
         if (count + c2 > 64) {
+            // the window does not fit: its farthest survivors fill the chunk up to exactly 64 lanes (every body of a
+            // chunk costs the same whatever the number of live lanes), the rest opens the next chunk
+            const int room = 64 - count;
+            if (room > 0) {
+                append(0, room, count);
+                cur.have = true;
+                cur_min = (uint32_t)k0;
+            }
             process(cur, cur_gid, cur_min);
-            count = 0;
+            append(room, c2 - room, 0);
+            count = c2 - room;
+        } else {
+            append(0, c2, count);
+            count += c2;
         }
-        // push the survivors to lanes count .. count + c2 - 1; the others aim at a lane whose result is unused
-        const int dest = hit ? count + __popcll(hmask & lt_mask) : (count > 0 ? 0 : c2 & 63);
-        const bool recv = lane >= count && lane < count + c2;
-        auto push = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(v))); };
-        const float m0 = push(f[0]), m1 = push(f[1]), m2 = push(f[2]), m3 = push(f[3]), m4 = push(f[4]);
-        const float m5 = push(f[5]), m6 = push(f[6]), m7 = push(f[7]), m8 = push(f[8]), m9 = push(f[9]);
-        const uint32_t mp = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)pos);
-        const uint32_t mg = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)gid);
-        if (recv) {
-            cur.mx = m0; cur.my = m1; cur.op = m5;
-            cur.ca = m2 * CONIC_SCALE_AC; cur.cb = m3 * CONIC_SCALE_B; cur.cc = m4 * CONIC_SCALE_AC;   // see splat_power2
-            cur.cr = m6; cur.cg = m7; cur.cbl = m8; cur.dep = m9; cur.pos = mp; cur_gid = mg;
-        }
-        count += c2;
         cur.have = lane < count;
         cur_min = (uint32_t)k0;      // every survivor of this window sits at a position >= k0
     }
