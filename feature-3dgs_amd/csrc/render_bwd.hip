@@ -165,7 +165,10 @@ struct SplatLane { // one chunk entry per lane
     bool have;
 };
 
-template <int CH, int NPIX, bool MF, int U>
+// GEO = false: a later channel window of a wide feature (C > 64 runs in windows of 64): only dL/dfeature of the window
+// is produced - the colour/depth dot product, the sum scan, dL/dalpha and the ten geometric sums belong to the first
+// window's launch and are not computed again (about half of a body's instructions).
+template <int CH, int NPIX, bool MF, int U, bool GEO>
 __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     constexpr int NB = MF ? CH / 32 : 0;       // 32-channel column blocks on the matrix pipe
     constexpr int CHV = CH / 4;
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     al[u] = fminf(ALPHA_MAX, au[u]);
                     f[u] = __builtin_amdgcn_rcpf(1.f - al[u]);   // 1/(1-alpha); exactly 1 for skipped lanes
                     P[u] = f[u];
-                    q[u] = fmaf(sl.cr, pb[u].x, fmaf(sl.cg, pb[u].y, fmaf(sl.cbl, pb[u].z, sl.dep * pb[u].w)));
+                    if constexpr (GEO) q[u] = fmaf(sl.cr, pb[u].x, fmaf(sl.cg, pb[u].y, fmaf(sl.cbl, pb[u].z, sl.dep * pb[u].w)));
                     touched = touched || ok[u];
                 }
                 if constexpr (U == 4) wave_incl_prod4(P[0], P[1], P[2], P[3]);
@@ -351,35 +354,42 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 for (int u = 0; u < U; u++) {
                     Tb[u] = pa[u].z * P[u];           // transmittance in front of this splat
                     w[u] = al[u] * Tb[u];
-                    D[u] = w[u] * q[u];
+                    if constexpr (GEO) D[u] = w[u] * q[u];
                 }
-                if constexpr (U == 4) wave_incl_sum4_to(Sinc, D[0], D[1], D[2], D[3]);
-                else { Sinc[0] = D[0]; Sinc[1] = D[1]; wave_incl_sum2(Sinc[0], Sinc[1]); }
+                if constexpr (GEO) {
+                    if constexpr (U == 4) wave_incl_sum4_to(Sinc, D[0], D[1], D[2], D[3]);
+                    else { Sinc[0] = D[0]; Sinc[1] = D[1]; wave_incl_sum2(Sinc[0], Sinc[1]); }
+                }
                 // lane 63 holds the chunk totals: it carries the pixel state to the next (nearer) chunk
                 if (lane == 63) {
 #pragma unroll
-                    for (int u = 0; u < U; u++)
-                        if (act[u]) *reinterpret_cast<float2*>(&L.pa[qi[u]].z) = make_float2(Tb[u], pa[u].w + Sinc[u]);
+                    for (int u = 0; u < U; u++) {
+                        if (!act[u]) continue;
+                        if constexpr (GEO) *reinterpret_cast<float2*>(&L.pa[qi[u]].z) = make_float2(Tb[u], pa[u].w + Sinc[u]);
+                        else L.pa[qi[u]].z = Tb[u];
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const float Sbehind = pa[u].w + (Sinc[u] - D[u]);
-                    // finite on skipped lanes too (f = 1 there), and every use below is multiplied by Gs = 0 or w = 0
-                    const float dL_dalpha = fmaf(Tb[u], q[u], -(Sbehind * f[u]));
-                    // raw moments of s = op G dL/dalpha over the pixels; the conic, the pixel scale and 1/op (for
-                    // dL/dopacity = sum G dL/dalpha) are applied once per chunk, before the flush
-                    const float sg = au[u] * dL_dalpha;
-                    const float sdx = sg * dx[u], sdy = sg * dy[u];
-                    acc[0] += sdx;
-                    acc[1] += sdy;
-                    acc[2] = fmaf(sdx, dx[u], acc[2]);
-                    acc[3] = fmaf(sdx, dy[u], acc[3]);
-                    acc[4] = fmaf(sdy, dy[u], acc[4]);
-                    acc[5] += sg;
-                    acc[6] = fmaf(w[u], pb[u].x, acc[6]);
-                    acc[7] = fmaf(w[u], pb[u].y, acc[7]);
-                    acc[8] = fmaf(w[u], pb[u].z, acc[8]);
-                    acc[9] = fmaf(w[u], pb[u].w, acc[9]);
+                    if constexpr (GEO) {
+                        const float Sbehind = pa[u].w + (Sinc[u] - D[u]);
+                        // finite on skipped lanes too (f = 1 there), and every use below is multiplied by Gs = 0 or w = 0
+                        const float dL_dalpha = fmaf(Tb[u], q[u], -(Sbehind * f[u]));
+                        // raw moments of s = op G dL/dalpha over the pixels; the conic, the pixel scale and 1/op (for
+                        // dL/dopacity = sum G dL/dalpha) are applied once per chunk, before the flush
+                        const float sg = au[u] * dL_dalpha;
+                        const float sdx = sg * dx[u], sdy = sg * dy[u];
+                        acc[0] += sdx;
+                        acc[1] += sdy;
+                        acc[2] = fmaf(sdx, dx[u], acc[2]);
+                        acc[3] = fmaf(sdx, dy[u], acc[3]);
+                        acc[4] = fmaf(sdy, dy[u], acc[4]);
+                        acc[5] += sg;
+                        acc[6] = fmaf(w[u], pb[u].x, acc[6]);
+                        acc[7] = fmaf(w[u], pb[u].y, acc[7]);
+                        acc[8] = fmaf(w[u], pb[u].z, acc[8]);
+                        acc[9] = fmaf(w[u], pb[u].w, acc[9]);
+                    }
                     if constexpr (CH > 0 && !MF) {
 #pragma unroll
                         for (int v = 0; v < CH / 4; v++) {
@@ -413,7 +423,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         F3DGS_PHASE_END(cyc_trip);
         if (tmask == 0 || F3DGS_DEV_SKIP(1)) return;
         L.flush[lane * Lds::FS + Lds::FS - 1] = __uint_as_float(gid);   // the stride's padding column carries the ids
-        {
+        if constexpr (GEO) {
             // moments -> dL/d(mean2D), dL/d(conic), dL/d(opacity):  dG/ddelx = -G (a dx + b dy),  dG/da = -G dx^2 / 2, ...
             // (sl.ca.. are the staged, pre-scaled conic: undo the scale here, once per chunk)
             const float ca = sl.ca * CONIC_UNSCALE_AC, cb = sl.cb * CONIC_UNSCALE_B, cc = sl.cc * CONIC_UNSCALE_AC;
@@ -424,7 +434,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
             acc[2] *= -0.5f; acc[3] *= -0.5f; acc[4] *= -0.5f;
         }
         constexpr int CHF = MF ? 0 : CH;            // feature channels that travel through the LDS transpose
-        constexpr int NG = (CHF + 10 + FLUSH_GROUP - 1) / FLUSH_GROUP;
+        constexpr int NGEO = GEO ? 10 : 0;          // geometric sums ride with the first channel window only
+        constexpr int NG = (CHF + NGEO + FLUSH_GROUP - 1) / FLUSH_GROUP;
+        if constexpr (NG == 0) __builtin_amdgcn_wave_barrier();   // the id column above is read below
         const int fsub = lane >> 4, fk = lane & 15;   // 4 instances per atomic instruction, 16 values each
 #pragma unroll
         for (int g = 0; g < NG; g++) {
@@ -435,7 +447,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 if (k >= Lds::FS - 1) continue;        // MF tile holds 10 values per instance
                 float v = 0.f;
                 if (idx < CHF) v = fac[idx < CHF ? idx : 0];
-                else if (idx < CHF + 10) v = acc[idx - CHF < 10 ? (idx - CHF >= 0 ? idx - CHF : 0) : 0];
+                else if (idx < CHF + NGEO) v = acc[idx - CHF < 10 ? (idx - CHF >= 0 ? idx - CHF : 0) : 0];
                 L.flush[lane * Lds::FS + k] = v;
             }
             __builtin_amdgcn_wave_barrier();
@@ -450,7 +462,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 const float v = fk < Lds::FS - 1 ? L.flush[inst * Lds::FS + fk] : 0.f;
                 if (idx < CHF) {
                     if (idx < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + idx, v);
-                } else if (idx < CHF + 10) {
+                } else if (idx < CHF + NGEO) {
                     if (a.write_base) unsafeAtomicAdd(a.grec + (size_t)gg * GREC + (idx - CHF), v);
                 }
             }
@@ -573,7 +585,15 @@ template <int CH, int NPIX, bool MF>
 void launch_one(const BwdArgs& a, hipStream_t s) {
     const size_t lds = sizeof(BwdLds<CH, NPIX, MF>);
     const dim3 grid(a.gx * a.gy * (256 / NPIX));
-    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4>), grid, dim3(64), lds, s, a);
+    // later channel windows skip the geometric half of the work (default pixel-block size only: the other sizes are
+    // experiment options and keep the one kernel, which tests write_base at the flush)
+    if constexpr (NPIX == 64 && CH > 0) {
+        if (!a.write_base) {
+            hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, false>), grid, dim3(64), lds, s, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, true>), grid, dim3(64), lds, s, a);
 }
 
 template <int CH, bool MF>

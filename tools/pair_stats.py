@@ -121,6 +121,15 @@ for tile in tiles:
                 tot["bodies_b"] += nb_
                 key = "bodies_le16" if len(grp) <= 16 else ("bodies_le32" if len(grp) <= 32 else "bodies_gt32")
                 tot[key] = tot.get(key, 0) + nb_
+            # the same with chunks of 32 instances against two pixel halves (a body then costs half)
+            for k in range(0, nb_inst, 32):
+                grp = rs[k:k + 32]
+                nb_ = int((sq_t > int(grp.min())).sum())
+                tot["half_bodies_cap32"] = tot.get("half_bodies_cap32", 0) + 8 * ((nb_ + 7) // 8)     # trips of 8 pixels
+            for k in range(0, nb_inst, 64):
+                grp = rs[k:k + 64]
+                nb_ = int((sq_t > int(grp.min())).sum())
+                tot["bodies_trips_cap64"] = tot.get("bodies_trips_cap64", 0) + 4 * ((nb_ + 3) // 4)   # trips of 4 pixels
             for ry in range(8):
                 qr = rect_min_q(mx, my, a, b, c, float(x0), float(x0 + 7), float(y0 + ry), float(y0 + ry)) <= thr
                 tot["row"] += int((actb & qr).sum())
