@@ -258,7 +258,9 @@ struct FwdChunkMF {
 // The next chunk's ids and splat records are prefetched into registers while the current chunk is blended.
 // (Fetching the B operand straight from global memory, prefetched two groups ahead, was measured slower
 // than staging the chunk's feature rows in LDS: 0.62 vs 0.57 ms at config c3.)
-template <int CH, int PPL, int CHK, int GI>
+// BASE = false: a later channel window of a wide feature (C > 64): colour, depth, final_T and n_contrib were written by
+// the first window's launch; only the blend weights and the feature contraction are needed again.
+template <int CH, int PPL, int CHK, int GI, bool BASE>
 __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     constexpr int NW = 4 / PPL;
     constexpr int NB = CH / 32;
@@ -440,11 +442,13 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                     const float wv = ok ? araw[e] * T[p] : 0.0f;
                     w[e][p] = wv;
                     T[p] = ok ? test_T : (term ? -fabsf(T[p]) : T[p]);
-                    last[p] = ok ? pos_e[e] : last[p];
-                    col[p][0] = fmaf(cdv[e].x, wv, col[p][0]);
-                    col[p][1] = fmaf(cdv[e].y, wv, col[p][1]);
-                    col[p][2] = fmaf(cdv[e].z, wv, col[p][2]);
-                    dep[p] = fmaf(cdv[e].w, wv, dep[p]);
+                    if constexpr (BASE) {
+                        last[p] = ok ? pos_e[e] : last[p];
+                        col[p][0] = fmaf(cdv[e].x, wv, col[p][0]);
+                        col[p][1] = fmaf(cdv[e].y, wv, col[p][1]);
+                        col[p][2] = fmaf(cdv[e].z, wv, col[p][2]);
+                        dep[p] = fmaf(cdv[e].w, wv, dep[p]);
+                    }
                     any_blend = any_blend || ok;
                 }
             }
@@ -476,7 +480,7 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     const size_t HW = (size_t)a.W * a.H;
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
-        if (a.write_base && inside[p]) {
+        if (BASE && a.write_base && inside[p]) {
             const size_t pid = (size_t)pix_id[p];
             const float Tf = fabsf(T[p]);
             a.final_T[pid] = Tf;
@@ -512,23 +516,29 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
 // Two entry points over one body: the C = 32 shape sits 12 registers above the three-waves-per-SIMD budget and is
 // faster squeezed into it (a few spills outside the blend loop: 0.443 vs 0.506 ms at c3); the C = 64 shape is
 // faster left alone at two waves (2.75 vs 2.98 ms at c4).
-template <int CH, int PPL, int CHK, int GI>
+template <int CH, int PPL, int CHK, int GI, bool BASE>
 __global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs a) {
-    render_forward_mfma_body<CH, PPL, CHK, GI>(a);
+    render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
 }
-template <int CH, int PPL, int CHK, int GI>
+template <int CH, int PPL, int CHK, int GI, bool BASE>
 __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(3, 4))) render_forward_mfma_kernel_w3(FwdArgs a) {
-    render_forward_mfma_body<CH, PPL, CHK, GI>(a);
+    render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
 }
 
 template <int CH, int PPL, int CHK, int GI>
 void launch_one_mf2(const FwdArgs& a, hipStream_t s) {
     constexpr int NW = 4 / PPL;
     const size_t lds = NW * sizeof(FwdChunkMF<CH, CHK>);
-    if (CH <= 32)
-        hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
-    else
-        hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
+    const dim3 grid(a.gx * a.gy), block(256 / PPL);
+    if constexpr (CHK == 64 && GI == 4) {      // the default shape also exists without the colour / depth half
+        if (!a.write_base) {
+            if (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI, false>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI, false>), grid, block, lds, s, a);
+            return;
+        }
+    }
+    if (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI, true>), grid, block, lds, s, a);
 }
 template <int CH, int PPL>
 void launch_one_mf(const FwdArgs& a, hipStream_t s) {
