@@ -362,6 +362,24 @@ def main():
                     break
                 except Exception:
                     pass
+        # VALU-issue fraction of the dominant kernel from the committed SQ counters (same caveat: a separate run)
+        sq_name = {"render_bwd": "render_backward_kernel", "render_fwd": "render_forward", "preprocess": "preprocess_kernel",
+                   "preprocess_bwd": "preprocess_backward_kernel"}[dom]
+        f = os.path.join(ROOT, "profiles", "r02_pmc_sq_counters.json")
+        if profiled is not None and os.path.exists(f):
+            try:
+                rows = [v for k, v in json.load(open(f)).items() if k.startswith(sq_name)]
+                if rows:
+                    r = max(rows, key=lambda v: v.get("SQ_INSTS_VALU", 0))
+                    # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MICROARCH.md); SQ_BUSY_CYCLES is summed over the 32
+                    # shader engines, so /32 is the kernel's duration in shader cycles; 1024 SIMDs
+                    profiled["valu_issue"] = {
+                        "frac": 4.0 * r["SQ_ACTIVE_INST_VALU"] / (r["SQ_BUSY_CYCLES"] / 32.0 * 1024.0),
+                        "valu_instructions_per_launch": r["SQ_INSTS_VALU"], "mfma_instructions_per_launch": r["SQ_INSTS_MFMA"],
+                        "formula": "4 x SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs)",
+                        "source": "profiles/r02_pmc_sq_counters.json (rocprofv3 --pmc, a separate run of this config)"}
+            except Exception:
+                pass
         per = sorted(per_step)
         pct = lambda q: per[min(len(per) - 1, int(q * len(per)))]
         out = {
