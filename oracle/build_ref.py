@@ -147,7 +147,9 @@ PY_CALLERS = {"ref_gaussian_renderer.pyc": "/root/reference/gaussian_renderer/__
               "ref_gaussian_model.pyc": "/root/reference/scene/gaussian_model.py",
               "ref_general_utils.pyc": "/root/reference/utils/general_utils.py",
               "ref_graphics_utils.pyc": "/root/reference/utils/graphics_utils.py",
-              "ref_system_utils.pyc": "/root/reference/utils/system_utils.py"}
+              "ref_system_utils.pyc": "/root/reference/utils/system_utils.py",
+              # l1_loss / ssim of the training loop (tests/test_gpu_train_loop.py)
+              "ref_loss_utils.pyc": "/root/reference/utils/loss_utils.py"}
 
 
 def build_callers(force: bool = False) -> list:
