@@ -102,89 +102,135 @@ fl_resize_kernel(ResizeGeom g, int C, const float* __restrict__ fm, float* __res
     if (gt && threadIdx.x == 0) loss_partial[blockIdx.y * gridDim.x + blockIdx.x] = (lsum[0] + lsum[1] + lsum[2] + lsum[3]) * inv_n;
 }
 
-// ---- K2: decoder forward + residual + g_x, one workgroup = 64 pixels x all Cout ---------------------------------------
+// ---- K2: decoder forward + residual + g_x; a WAVE owns 32 pixels for all Cout, a workgroup = 4 waves = 128 pixels ----
+// Everything per pixel stays in registers; the only shared data is the current 32-row tile of W (LDS, double-buffered).
+// With lane l = (px = l & 31, h = l >> 5) and the K index of an MFMA step s defined as c = h C/2 + s (any bijection
+// of K works as long as both operands use it):
+//   phase A   y^T[co][px] = W[co][:] . X[px][:]      A = W tile row (b128 LDS reads: four steps per read),
+//                                                    B = this lane's half row of X, loaded ONCE into C/2 registers
+//   in place  r = y + b - gt,  loss += |r|,  sign byte out,  g = sign(r) / (N Cout)        (accumulator registers)
+//   phase B   g_x^T[c][px] += W^T[c][co] g^T[co][px]  A = W tile column (b32 LDS reads), B = the accumulator register r
+//             of phase A itself: D's layout (lane = column px, register r = row co(r, h)) IS the B layout when step r
+//             contracts co(r, 0) with co(r, 1) - no transpose, no LDS round trip, no barrier between the phases.
+// Per W tile a wave issues C MFMAs and 1.25 LDS reads per MFMA; the decoded (Cout, Hg, Wg) map is never written.
+// (First version: 64 pixels x 128 Cout per workgroup through three LDS tiles of 132 KB - one workgroup of four waves per
+// CU, every operand a 4-byte LDS read behind a barrier: 1.59 ms at 128 -> 512; `profiles/r02_notes.md`.)
 template <int C>
 struct GemmLds {
-    float Xs[64][C + 1];       // pixel tile, row-major, odd stride: the A-operand reads (lane = row) are conflict-free
-    float Ws[128][C + 1];      // decoder rows co0 .. co0+127 of the current iteration
-    float Gs[64][129];         // g_y of the current iteration
+    static constexpr int WS = C + 4;          // row stride: 16-byte aligned rows, b128 reads of 32 rows hit all banks evenly
+    float Ws[2][32][WS];
     float red[4];
 };
 
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // 32x32 D layout
+
 template <int C>
-__global__ void __launch_bounds__(256)
-fl_decoder_kernel(int N, int Cout, const float* __restrict__ X, const float* __restrict__ Wd, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+fl_decoder_kernel(int N, int Np, int Cout, const float* __restrict__ X, const float* __restrict__ Wd, const float* __restrict__ bias,
                   const float* __restrict__ gt, float inv_n, float* __restrict__ GX, int8_t* __restrict__ S,
                   float* __restrict__ loss_partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GemmLds<C>& L = *reinterpret_cast<GemmLds<C>*>(smem);
+    constexpr int NCB = C / 32, HC = C / 2;
+    constexpr int LPT = (32 * C / 4) / 256;       // float4 loads per thread for one W tile (C = 32: 1, 64: 2, 128: 4)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int p0 = blockIdx.x * 64;
-    constexpr int NCB = C / 32;                   // channel blocks of the g_x accumulation: wave w owns block w
-    for (int e = threadIdx.x; e < 64 * C; e += 256) {
-        const int px = e / C, c = e - px * C;
-        L.Xs[px][c] = p0 + px < N ? X[(size_t)(p0 + px) * C + c] : 0.f;
-    }
-    f32x16 gx[2];
+    const int li = lane & 31, h = lane >> 5;
+    const int p = blockIdx.x * 128 + 32 * w + li;
+    const bool p_ok = p < N;
+    // this lane's half row of X
+    float xr[HC];
+    {
+        const float4* src = reinterpret_cast<const float4*>(X + (size_t)(p_ok ? p : 0) * C + h * HC);
 #pragma unroll
-    for (int r = 0; r < 16; r++) { gx[0][r] = 0.f; gx[1][r] = 0.f; }
+        for (int k = 0; k < HC / 4; k++) {
+            const float4 v = src[k];
+            xr[4 * k] = p_ok ? v.x : 0.f; xr[4 * k + 1] = p_ok ? v.y : 0.f; xr[4 * k + 2] = p_ok ? v.z : 0.f; xr[4 * k + 3] = p_ok ? v.w : 0.f;
+        }
+    }
+    f32x16 gx[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) gx[cb][r] = 0.f;
     float loss = 0.f;
-    const int li = lane & 31, lk = lane >> 5;
-    for (int co0 = 0; co0 < Cout; co0 += 128) {
-        __syncthreads();                          // previous iteration's readers of Ws / Gs are done
-        for (int e = threadIdx.x; e < 128 * C; e += 256) {
-            const int r = e / C, c = e - r * C;
-            L.Ws[r][c] = co0 + r < Cout ? Wd[(size_t)(co0 + r) * C + c] : 0.f;
+    // W tile staging: thread t moves float4 #(t + 256 k) of the 32 x C tile
+    auto load_tile = [&](int co0, float4 (&v)[LPT]) {
+#pragma unroll
+        for (int k = 0; k < LPT; k++) {
+            const int e = (threadIdx.x + 256 * k) * 4, r = e / C, c = e - r * C;
+            v[k] = co0 + r < Cout ? *reinterpret_cast<const float4*>(Wd + (size_t)(co0 + r) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
-        // ---- phase A: y[64 px][32 co of this wave] = Xs Ws^T
-        f32x16 acc[2];
+    };
+    auto store_tile = [&](int buf, const float4 (&v)[LPT]) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-#pragma unroll 4
-        for (int ks = 0; ks < C / 2; ks++) {
-            const float b = L.Ws[32 * w + li][2 * ks + lk];              // B[k][n] = W[co = n][c = k]
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.Xs[li][2 * ks + lk], b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.Xs[32 + li][2 * ks + lk], b, acc[1], 0, 0, 0);
+        for (int k = 0; k < LPT; k++) {
+            const int e = (threadIdx.x + 256 * k) * 4, r = e / C, c = e - r * C;
+            *reinterpret_cast<float4*>(&L.Ws[buf][r][c]) = v[k];
         }
-        // ---- residual, loss, g_y (this lane: column co, rows = pixels)
-        const int co = co0 + 32 * w + li;
-        const bool co_ok = co < Cout;
-        const float bv = co_ok ? bias[co] : 0.f;
+    };
+    float4 wnext[LPT];
+    load_tile(0, wnext);
+    store_tile(0, wnext);
+    __syncthreads();
+    const int ntiles = (Cout + 31) / 32;
+    for (int t = 0; t < ntiles; t++) {
+        const int co0 = 32 * t, buf = t & 1;
+        if (t + 1 < ntiles) load_tile(co0 + 32, wnext);          // in flight during this tile's MFMAs
+        // ground truth and bias of this tile's rows, requested before phase A
+        float gtv[16];
+        f32x16 acc;                                              // starts at the bias: y = W x + b
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++)
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + mfma_row(r, h);
+            const bool ok = p_ok && co < Cout;
+            gtv[r] = ok ? gt[(size_t)co * N + p] : 0.f;
+            acc[r] = co < Cout ? bias[co] : 0.f;
+        }
+        // ---- phase A (scheduling fences: without them every LDS read of the unrolled loop is hoisted to the top and
+        //      the kernel needs > 256 registers)
+        const float* wrow = &L.Ws[buf][li][h * HC];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int px = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int p = p0 + px;
-                float gv = 0.f;
-                if (co_ok && p < N) {
-                    const float res = acc[rb][r] + bv - gt[(size_t)co * N + p];
-                    loss += fabsf(res);
-                    gv = res > 0.f ? inv_n : (res < 0.f ? -inv_n : 0.f);
-                    S[(size_t)p * Cout + co] = res > 0.f ? 1 : (res < 0.f ? -1 : 0);
-                }
-                L.Gs[px][32 * w + li] = gv;
+        for (int s4 = 0; s4 < HC / 4; s4++) {
+            const float4 a = *reinterpret_cast<const float4*>(wrow + 4 * s4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xr[4 * s4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xr[4 * s4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xr[4 * s4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xr[4 * s4 + 3], acc, 0, 0, 0);
+            if ((s4 & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- residual, loss, sign, g (in place)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + mfma_row(r, h);
+            float gv = 0.f;
+            if (p_ok && co < Cout) {
+                const float res = acc[r] - gtv[r];
+                loss += fabsf(res);
+                gv = res > 0.f ? inv_n : (res < 0.f ? -inv_n : 0.f);
+                S[(size_t)co * Np + p] = res > 0.f ? 1 : (res < 0.f ? -1 : 0);     // co-major: 32 consecutive bytes per half-wave
             }
-        __syncthreads();
-        // ---- phase B: g_x[64 px][32 c of this wave] += Gs[64][128] Ws[128][c block]
-        if (w < NCB) {
-#pragma unroll 4
-            for (int ks = 0; ks < 64; ks++) {
-                const float b = L.Ws[2 * ks + lk][32 * w + li];          // B[k][n] = W[co = k][c = n]
-                gx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.Gs[li][2 * ks + lk], b, gx[0], 0, 0, 0);
-                gx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.Gs[32 + li][2 * ks + lk], b, gx[1], 0, 0, 0);
-            }
+            acc[r] = gv;
         }
+        // ---- phase B
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float* wr = &L.Ws[buf][mfma_row(r, h)][li];
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) gx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], acc[r], gx[cb], 0, 0, 0);
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1, wnext);          // the other buffer: its readers finished a tile ago
+        __syncthreads();
     }
-    if (w < NCB) {
+    // g_x^T[c][px]: this lane holds column px, register r of block cb = row c = 32 cb + row(r, h): four consecutive c per
+    // register quad -> one 16-byte store
+    if (p_ok) {
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++)
+        for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int px = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (p0 + px < N) GX[(size_t)(p0 + px) * C + 32 * w + li] = gx[rb][r];
-            }
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<float4*>(GX + (size_t)p * C + 32 * cb + 8 * q + 4 * h) =
+                    make_float4(gx[cb][4 * q], gx[cb][4 * q + 1], gx[cb][4 * q + 2], gx[cb][4 * q + 3]);
     }
     loss = wave_sum(loss);
     if (lane == 0) L.red[w] = loss;
@@ -193,62 +239,90 @@ fl_decoder_kernel(int N, int Cout, const float* __restrict__ X, const float* __r
 }
 
 // ---- K3: dW = g_y^T X, db = sum g_y over a range of pixel tiles; grid (ceil(Cout / 128), splits) ------------------
+// A = g^T[co][px] comes straight from the co-major sign bytes: with the K index of step s defined as px = 32 h + s, a
+// lane's 32 steps of a 64-pixel tile are 32 CONSECUTIVE bytes of its own row (two 16-byte loads, no LDS); B = X tile in
+// LDS, shared by the four waves (four 32-row blocks of Cout), double-buffered with the next tile in flight in registers.
 template <int C>
 struct DwLds {
-    float Xs[64][C + 1];
-    float Ss[64][129];
+    static constexpr int XS = C + 4;
+    float Xs[2][64][XS];
 };
 
 template <int C>
 __global__ void __launch_bounds__(256)
-fl_dweight_kernel(int N, int Cout, const float* __restrict__ X, const int8_t* __restrict__ S, float inv_n,
+fl_dweight_kernel(int N, int Np, int Cout, const float* __restrict__ X, const int8_t* __restrict__ S, float inv_n,
                   float* __restrict__ dW, float* __restrict__ db) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DwLds<C>& L = *reinterpret_cast<DwLds<C>*>(smem);
     constexpr int NCB = C / 32;
+    constexpr int LPT = (64 * C / 4) / 256;       // float4 loads per thread for one X tile
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int li = lane & 31, lk = lane >> 5;
-    const int co0 = blockIdx.x * 128;
+    const int li = lane & 31, h = lane >> 5;
+    const int co = blockIdx.x * 128 + 32 * w + li;
+    const bool co_ok = co < Cout;
     const int tiles = (N + 63) / 64;
     const int per = (tiles + gridDim.y - 1) / gridDim.y;
     const int t_lo = blockIdx.y * per, t_hi = min(tiles, t_lo + per);
+    if (t_lo >= t_hi) return;
     f32x16 acc[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
     float dbacc = 0.f;
-    for (int tI = t_lo; tI < t_hi; tI++) {
-        const int p0 = tI * 64;
-        __syncthreads();
-        for (int e = threadIdx.x; e < 64 * C; e += 256) {
-            const int px = e / C, c = e - px * C;
-            L.Xs[px][c] = p0 + px < N ? X[(size_t)(p0 + px) * C + c] : 0.f;
-        }
-        for (int e = threadIdx.x; e < 64 * 128; e += 256) {
-            const int px = e >> 7, r = e & 127;
-            L.Ss[px][r] = (p0 + px < N && co0 + r < Cout) ? (float)S[(size_t)(p0 + px) * Cout + co0 + r] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int ks = 0; ks < 32; ks++) {
-            const float a = L.Ss[2 * ks + lk][32 * w + li];              // A[i = co][k = pixel]
-            dbacc += a;
+    auto load_x = [&](int tI, float4 (&v)[LPT]) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; cb++)
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.Xs[2 * ks + lk][32 * cb + li], acc[cb], 0, 0, 0);
+        for (int k = 0; k < LPT; k++) {
+            const int e = (threadIdx.x + 256 * k) * 4, px = e / C, c = e - px * C;
+            const int p = tI * 64 + px;
+            v[k] = p < N ? *reinterpret_cast<const float4*>(X + (size_t)p * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto store_x = [&](int buf, const float4 (&v)[LPT]) {
+#pragma unroll
+        for (int k = 0; k < LPT; k++) {
+            const int e = (threadIdx.x + 256 * k) * 4, px = e / C, c = e - px * C;
+            *reinterpret_cast<float4*>(&L.Xs[buf][px][c]) = v[k];
+        }
+    };
+    auto load_s = [&](int tI, uint4 (&v)[2]) {      // rows are padded to Np (a multiple of 64): aligned 16-byte loads
+        const uint4* src = reinterpret_cast<const uint4*>(S + (size_t)(co_ok ? co : 0) * Np + (size_t)tI * 64 + 32 * h);
+        v[0] = src[0]; v[1] = src[1];
+    };
+    float4 xn[LPT];
+    uint4 sn[2];
+    load_x(t_lo, xn);
+    load_s(t_lo, sn);
+    store_x(0, xn);
+    __syncthreads();
+    for (int tI = t_lo; tI < t_hi; tI++) {
+        const int buf = (tI - t_lo) & 1;
+        uint4 sc[2] = {sn[0], sn[1]};
+        if (tI + 1 < t_hi) { load_x(tI + 1, xn); load_s(tI + 1, sn); }
+        const uint32_t words[8] = {sc[0].x, sc[0].y, sc[0].z, sc[0].w, sc[1].x, sc[1].y, sc[1].z, sc[1].w};
+        const int valid = co_ok ? N - (tI * 64 + 32 * h) : 0;     // steps s < valid are real pixels (the pad bytes are not)
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            float a = (float)(int)(int8_t)(words[s >> 2] >> (8 * (s & 3)));
+            a = s < valid ? a : 0.f;
+            dbacc += a;
+            const float* xrow = &L.Xs[buf][32 * h + s][li];
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xrow[32 * cb], acc[cb], 0, 0, 0);
+        }
+        if (tI + 1 < t_hi) store_x(buf ^ 1, xn);
+        __syncthreads();
     }
-    // D: column l&31 = channel, rows = co
+    // D: column l&31 = channel, rows = co of this wave's block
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int co = co0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (co < Cout && acc[cb][r] != 0.f) atomicAdd(&dW[(size_t)co * C + 32 * cb + li], acc[cb][r] * inv_n);
+            const int cor = blockIdx.x * 128 + 32 * w + mfma_row(r, h);
+            if (cor < Cout && acc[cb][r] != 0.f) atomicAdd(&dW[(size_t)cor * C + 32 * cb + li], acc[cb][r] * inv_n);
         }
     dbacc += __shfl_xor(dbacc, 32, 64);
-    if (lk == 0 && co0 + 32 * w + li < Cout && dbacc != 0.f) atomicAdd(&db[co0 + 32 * w + li], dbacc * inv_n);
+    if (h == 0 && co_ok && dbacc != 0.f) atomicAdd(&db[co], dbacc * inv_n);
 }
 
 // ---- K4: transpose of the resize: d_fm (C,H,W) gathered from g_x[N][C]; grid (ceil(W / 64), H, ceil(C / 32)) ----
@@ -373,8 +447,8 @@ struct Scratch {
         Scratch s;
         s.X = c.take<float>((size_t)N * C);
         s.GX = decoder ? c.take<float>((size_t)N * C) : s.X;     // without a decoder K1 writes g_x straight away
-        s.S = c.take<int8_t>(decoder ? (size_t)N * Cout : 0);
-        s.n_partial = decoder ? (size_t)(N + 63) / 64 : (size_t)((N + 63) / 64) * ((C + 31) / 32);
+        s.S = c.take<int8_t>(decoder ? (size_t)((N + 63) / 64 * 64) * Cout : 0);      // [Cout][N padded to 64] sign bytes
+        s.n_partial = decoder ? (size_t)(N + 127) / 128 : (size_t)((N + 63) / 64) * ((C + 31) / 32);
         s.loss_partial = c.take<float>(s.n_partial);
         if (bytes) *bytes = c.total();
         return s;
@@ -391,15 +465,16 @@ hipError_t run_decoder(int N, int Cout, const Scratch& sc, const float* Wd, cons
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fl_dweight_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds3);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fl_decoder_kernel<C>), dim3((N + 63) / 64), dim3(256), lds2, s, N, Cout, sc.X, Wd, bias, gt, inv_n, sc.GX,
-                       sc.S, sc.loss_partial);
+    const int Np = (N + 63) / 64 * 64;
+    hipLaunchKernelGGL((fl_decoder_kernel<C>), dim3((N + 127) / 128), dim3(256), lds2, s, N, Np, Cout, sc.X, Wd, bias, gt, inv_n,
+                       sc.GX, sc.S, sc.loss_partial);
     e = hipMemsetAsync(dW, 0, (size_t)Cout * C * sizeof(float), s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s);
     if (e != hipSuccess) return e;
     const int cblocks = (Cout + 127) / 128, tiles = (N + 63) / 64;
     const int splits = max(1, min(tiles, 512 / cblocks));
-    hipLaunchKernelGGL((fl_dweight_kernel<C>), dim3(cblocks, splits), dim3(256), lds3, s, N, Cout, sc.X, sc.S, inv_n, dW, db);
+    hipLaunchKernelGGL((fl_dweight_kernel<C>), dim3(cblocks, splits), dim3(256), lds3, s, N, Np, Cout, sc.X, sc.S, inv_n, dW, db);
     return hipGetLastError();
 }
 
