@@ -364,6 +364,15 @@ fl_resize_backward_kernel(ResizeGeom g, int C, const float* __restrict__ GX, flo
     int yo[RB_MAXT];
     float wy[RB_MAXT];
     const int ny = build(y, g.sy, g.H, g.Hg, yo, wy);           // uniform over the workgroup
+    if (ny == 0) {      // no output samples this source row (two rows of three when shrinking 3x): zeros, straight out
+        const int xl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = cb + cg * 8 + k;
+            if (x0 + xl < g.W && c < C) dfm[(size_t)c * g.H * g.W + (size_t)y * g.W + x0 + xl] = 0.f;
+        }
+        return;
+    }
     if (threadIdx.x < 64) {
         int xo[RB_MAXT];
         float wx[RB_MAXT];
