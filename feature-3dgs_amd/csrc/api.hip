@@ -167,6 +167,7 @@ const OptionDesc kOptions[] = {
     {"bwd_npix", "F3DGS_BWD_NPIX", &Options::bwd_npix, 0},
     {"bwd_part_major", "F3DGS_BWD_PART_MAJOR", &Options::bwd_part_major, 0},
     {"bwd_strip", "F3DGS_BWD_STRIP", &Options::bwd_strip, 0},
+    {"bwd_half", "F3DGS_BWD_HALF", &Options::bwd_half, 1},
     {"bwd_wave_cull", "F3DGS_BWD_WAVE_CULL", &Options::bwd_wave_cull, 1},
     {"fwd_ppl", "F3DGS_FWD_PPL", &Options::fwd_ppl, 0},
     {"fwd_variant", "F3DGS_FWD_VARIANT", &Options::fwd_variant, 0},

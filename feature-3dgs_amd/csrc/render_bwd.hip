@@ -52,6 +52,7 @@ struct BwdArgs {
     int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
     int part_major;  // workgroup -> (tile, part) order, see kernel
     int strip;        // NPIX = 64: 16x4 pixel strips instead of 8x8 quadrants
+    int half;         // NPIX = 64: chunks of 32 instances, the two halves of the wave take different pixels
     int no_wave_cull; // option bwd_wave_cull = 0: no wave-level footprint culling / compaction
 #ifdef F3DGS_DEV
     int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs, bit3 phase timing
@@ -119,6 +120,22 @@ __device__ __forceinline__ void wave_incl_sum4_to(float (&o)[4], float a, float 
                  : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
                  : "v"(a), "v"(b), "v"(c), "v"(d));
 }
+// The same two scans over each HALF of the wave separately (lanes 0-31 and 32-63 hold the same 32 instances against
+// two different pixels): the step across the half boundary (row_bcast:31) is simply not taken.
+__device__ __forceinline__ void half_incl_prod4(float& a, float& b, float& c, float& d) {
+    asm volatile("s_nop 1\n\t" F3DGS_STEP4("v_mul_f32_dpp", "row_shr:1 row_mask:0xf") F3DGS_STEP4("v_mul_f32_dpp", "row_shr:2 row_mask:0xf")
+                 F3DGS_STEP4("v_mul_f32_dpp", "row_shr:4 row_mask:0xf") F3DGS_STEP4("v_mul_f32_dpp", "row_shr:8 row_mask:0xf")
+                 F3DGS_STEP4("v_mul_f32_dpp", "row_bcast:15 row_mask:0xa") "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void half_incl_sum4_to(float (&o)[4], float a, float b, float c, float d) {
+    asm volatile("s_nop 1\n\t" F3DGS_STEP4_FIRST("v_add_f32_dpp", "row_shr:1 row_mask:0xf")
+                 F3DGS_STEP4("v_add_f32_dpp", "row_shr:2 row_mask:0xf") F3DGS_STEP4("v_add_f32_dpp", "row_shr:4 row_mask:0xf")
+                 F3DGS_STEP4("v_add_f32_dpp", "row_shr:8 row_mask:0xf") F3DGS_STEP4("v_add_f32_dpp", "row_bcast:15 row_mask:0xa")
+                 "s_nop 1"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+                 : "v"(a), "v"(b), "v"(c), "v"(d));
+}
 #undef F3DGS_STEP4_FIRST
 #undef F3DGS_STEP4
 
@@ -168,8 +185,16 @@ struct SplatLane { // one chunk entry per lane
 // GEO = false: a later channel window of a wide feature (C > 64 runs in windows of 64): only dL/dfeature of the window
 // is produced - the colour/depth dot product, the sum scan, dL/dalpha and the ten geometric sums belong to the first
 // window's launch and are not computed again (about half of a body's instructions).
-template <int CH, int NPIX, bool MF, int U, bool GEO>
-__global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
+// HALF = true: a chunk holds 32 instances and the two halves of the wave run them against two different pixels
+// (lane l = instance l & 31, pixel half l >> 5; eight pixels per trip).  A body costs the same per (pixel, instance)
+// pair, but the front-most, partially filled chunk of a wave wastes at most 31 lanes x its pixels instead of 63, a
+// chunk's pixels are cut off at a finer depth, and the scans and the matrix-pipe operands need no step across the
+// half boundary (`tools/pair_stats.py`: 12.6 % fewer body-equivalents at c3).
+template <int CH, int NPIX, bool MF, int U, bool GEO, bool HALF>
+__device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
+    static_assert(!HALF || (NPIX == 64 && U == 4), "half-wave chunks: 64-pixel blocks, four pixels per half and trip");
+    constexpr int CAP = HALF ? 32 : 64;        // instances per chunk
+    constexpr int MH = HALF ? 1 : 2;           // 32-row accumulator blocks per chunk on the matrix pipe
     constexpr int NB = MF ? CH / 32 : 0;       // 32-channel column blocks on the matrix pipe
     constexpr int CHV = CH / 4;
     constexpr int PARTS = 256 / NPIX;          // waves (workgroups) per tile
@@ -277,19 +302,30 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
     // ---- one (compacted) chunk of up to 64 splats against all live pixels of the wave ---------------------
-    auto process = [&](const SplatLane& sl, const uint32_t gid, const uint32_t pos_min) {
+    auto process = [&](const SplatLane& sl_in, const uint32_t gid_in, const uint32_t pos_min, const int n_inst) {
         F3DGS_PHASE_END(cyc_walk);
+        SplatLane sl = sl_in;
+        uint32_t gid = gid_in;
+        if constexpr (HALF) {      // both halves of the wave hold the chunk's 32 instances
+            const int src = lane & 31;
+            sl.mx = __shfl(sl_in.mx, src); sl.my = __shfl(sl_in.my, src); sl.ca = __shfl(sl_in.ca, src); sl.cb = __shfl(sl_in.cb, src);
+            sl.cc = __shfl(sl_in.cc, src); sl.op = __shfl(sl_in.op, src); sl.cr = __shfl(sl_in.cr, src); sl.cg = __shfl(sl_in.cg, src);
+            sl.cbl = __shfl(sl_in.cbl, src); sl.dep = __shfl(sl_in.dep, src);
+            sl.pos = (uint32_t)__shfl((int)sl_in.pos, src);
+            gid = (uint32_t)__shfl((int)gid_in, src);
+            sl.have = src < n_inst;
+        }
         float acc[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) acc[k] = 0.f;
         float fac[(CH > 0 && !MF) ? CH : 1];
 #pragma unroll
         for (int c = 0; c < ((CH > 0 && !MF) ? CH : 1); c++) fac[c] = 0.f;
-        f32x16 macc[NB > 0 ? NB : 1][2];           // [column block][instances 0-31 | 32-63]
+        f32x16 macc[NB > 0 ? NB : 1][MH];          // [column block][instances 0-31 | 32-63]
 #pragma unroll
         for (int nb = 0; nb < (NB > 0 ? NB : 1); nb++)
 #pragma unroll
-            for (int hh = 0; hh < 2; hh++)
+            for (int hh = 0; hh < MH; hh++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) macc[nb][hh][r] = 0.f;
         bool touched = false;
@@ -302,14 +338,32 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
             if (F3DGS_DEV_SKIP(2)) { touched = sl.have; live = 0; }
             while (live) {
                 // take up to U live pixels; missing ones repeat the first with n_contrib = 0 (inert bodies)
-                int qi[U];
-                bool act[U];
+                int qs[U];
+                bool acts[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    act[u] = live != 0;
-                    const int b = act[u] ? __builtin_ctzll(live) : 0;
+                    acts[u] = live != 0;
+                    const int b = acts[u] ? __builtin_ctzll(live) : 0;
                     live &= live - 1;   // (0 & anything) stays 0
-                    qi[u] = act[u] ? it * 64 + b : qi[0];
+                    qs[u] = acts[u] ? it * 64 + b : qs[0];
+                }
+                // qi / act: this LANE's pixel of body u - wave-uniform, or (HALF) the upper half of the wave takes its
+                // own U pixels from the top of the live mask
+                int qi[U];
+                bool act[U];
+                if constexpr (HALF) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const bool ah = live != 0;
+                        const int b = ah ? 63 - __builtin_clzll(live) : 0;
+                        live &= ~((ah ? 1ull : 0ull) << b);
+                        const int qh = ah ? b : qs[0];
+                        qi[u] = lane < 32 ? qs[u] : qh;
+                        act[u] = lane < 32 ? acts[u] : ah;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; u++) { qi[u] = qs[u]; act[u] = acts[u]; }
                 }
                 float4 pa[U], pb[U];
                 uint32_t lastq[U];
@@ -319,16 +373,17 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     pb[u] = L.pb[qi[u]];
                     lastq[u] = L.plast[qi[u]];   // unconditional: keeps all broadcasts of the body in flight together
                 }
-                float Bv[MF ? U / 2 : 1][NB > 0 ? NB : 1];
+                constexpr int NBV = HALF ? U : U / 2;       // B operands per trip (one per matrix-pipe step of K = 2 pixels)
+                float Bv[MF ? NBV : 1][NB > 0 ? NB : 1];
                 if constexpr (MF) {
                     // B[k][j] = dO[pixel k][channel j] of the matrix-pipe contraction below; requested here so that the
                     // LDS latency is covered by the alpha evaluation
 #pragma unroll
-                    for (int u = 0; u < U; u += 2) {
-                        const int pq = lane < 32 ? qi[u] : qi[u + 1];
+                    for (int b = 0; b < NBV; b++) {
+                        const int pq = HALF ? qi[b] : (lane < 32 ? qi[2 * b] : qi[2 * b + 1]);
                         const int prow = pq * Lds::GS + ((lane & 31) ^ (pq & 31));        // swizzled column, see the staging
 #pragma unroll
-                        for (int nb = 0; nb < NB; nb++) Bv[u / 2][nb] = L.gfm[prow + 32 * nb];
+                        for (int nb = 0; nb < NB; nb++) Bv[b][nb] = L.gfm[prow + 32 * nb];
                     }
                 }
                 float dx[U], dy[U], au[U], al[U], f[U], q[U], D[U], P[U], Tb[U], w[U], Sinc[U];
@@ -348,7 +403,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     if constexpr (GEO) q[u] = fmaf(sl.cr, pb[u].x, fmaf(sl.cg, pb[u].y, fmaf(sl.cbl, pb[u].z, sl.dep * pb[u].w)));
                     touched = touched || ok[u];
                 }
-                if constexpr (U == 4) wave_incl_prod4(P[0], P[1], P[2], P[3]);
+                if constexpr (HALF) half_incl_prod4(P[0], P[1], P[2], P[3]);
+                else if constexpr (U == 4) wave_incl_prod4(P[0], P[1], P[2], P[3]);
                 else wave_incl_prod2(P[0], P[1]);
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -357,11 +413,12 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                     if constexpr (GEO) D[u] = w[u] * q[u];
                 }
                 if constexpr (GEO) {
-                    if constexpr (U == 4) wave_incl_sum4_to(Sinc, D[0], D[1], D[2], D[3]);
+                    if constexpr (HALF) half_incl_sum4_to(Sinc, D[0], D[1], D[2], D[3]);
+                    else if constexpr (U == 4) wave_incl_sum4_to(Sinc, D[0], D[1], D[2], D[3]);
                     else { Sinc[0] = D[0]; Sinc[1] = D[1]; wave_incl_sum2(Sinc[0], Sinc[1]); }
                 }
-                // lane 63 holds the chunk totals: it carries the pixel state to the next (nearer) chunk
-                if (lane == 63) {
+                // the last lane (of each half) holds the chunk totals: it carries the pixel state to the next (nearer) chunk
+                if ((lane & (CAP - 1)) == CAP - 1) {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         if (!act[u]) continue;
@@ -404,14 +461,23 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 if constexpr (MF) if (!F3DGS_DEV_SKIP(4)) {
                     // A = W^T block: rows = instances, k = two pixels.  One half-wave swap builds both 32-instance
                     // operands:  X = [w_a lanes 0-31 | w_b lanes 0-31],  Y = [w_a lanes 32-63 | w_b lanes 32-63].
+                    if constexpr (HALF) {
+                        // the halves already ARE the operand: row = instance l & 31, k = pixel half l >> 5
 #pragma unroll
-                    for (int u = 0; u < U; u += 2) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[u]), __float_as_int(w[u + 1]), false, false);
-                        const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
+                        for (int u = 0; u < U; u++)
 #pragma unroll
-                        for (int nb = 0; nb < NB; nb++) {
-                            macc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv[u / 2][nb], macc[nb][0], 0, 0, 0);
-                            macc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv[u / 2][nb], macc[nb][1], 0, 0, 0);
+                            for (int nb = 0; nb < NB; nb++)
+                                macc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u], Bv[u][nb], macc[nb][0], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; u += 2) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[u]), __float_as_int(w[u + 1]), false, false);
+                            const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
+#pragma unroll
+                            for (int nb = 0; nb < NB; nb++) {
+                                macc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv[u / 2][nb], macc[nb][0], 0, 0, 0);
+                                macc[nb][MH - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv[u / 2][nb], macc[nb][MH - 1], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -419,10 +485,21 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
         }
 
         // ---- flush this chunk: transpose through LDS in groups of 16 values, coalesced atomics -----------
-        const unsigned long long tmask = __ballot(touched);
+        unsigned long long tmask = __ballot(touched);
+        if constexpr (HALF) tmask = (tmask | (tmask >> 32)) & 0xFFFFFFFFull;      // an instance is touched in either half
         F3DGS_PHASE_END(cyc_trip);
         if (tmask == 0 || F3DGS_DEV_SKIP(1)) return;
-        L.flush[lane * Lds::FS + Lds::FS - 1] = __uint_as_float(gid);   // the stride's padding column carries the ids
+        const int frow = lane & (CAP - 1);          // this lane's instance row in the flush tile
+        L.flush[frow * Lds::FS + Lds::FS - 1] = __uint_as_float(gid);   // the stride's padding column carries the ids
+        if constexpr (HALF) {
+            // the two halves hold partial sums over their own pixels: add them up (both halves end with the total)
+            if constexpr (GEO) {
+#pragma unroll
+                for (int k = 0; k < 10; k++) acc[k] += __shfl_xor(acc[k], 32);
+            }
+#pragma unroll
+            for (int c = 0; c < ((CH > 0 && !MF) ? CH : 0); c++) fac[c] += __shfl_xor(fac[c], 32);
+        }
         if constexpr (GEO) {
             // moments -> dL/d(mean2D), dL/d(conic), dL/d(opacity):  dG/ddelx = -G (a dx + b dy),  dG/da = -G dx^2 / 2, ...
             // (sl.ca.. are the staged, pre-scaled conic: undo the scale here, once per chunk)
@@ -448,12 +525,12 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 float v = 0.f;
                 if (idx < CHF) v = fac[idx < CHF ? idx : 0];
                 else if (idx < CHF + NGEO) v = acc[idx - CHF < 10 ? (idx - CHF >= 0 ? idx - CHF : 0) : 0];
-                L.flush[lane * Lds::FS + k] = v;
+                L.flush[frow * Lds::FS + k] = v;
             }
             __builtin_amdgcn_wave_barrier();
             const int idx = g * FLUSH_GROUP + fk;       // this lane's value index within the instance
 #pragma unroll 4
-            for (int i0 = 0; i0 < 64; i0 += 4) {
+            for (int i0 = 0; i0 < CAP; i0 += 4) {
                 const int inst = i0 + fsub;
                 // scalar shift by the compile-time part, per-lane shift by the small remainder (a 64-bit per-lane
                 // mask per instance would be hoisted out of the chunk loop and cost two registers apiece)
@@ -472,7 +549,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
             // i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (instance = original lane index): every store is one
             // contiguous 32-float run per half-wave.
 #pragma unroll
-            for (int hh = 0; hh < 2; hh++)
+            for (int hh = 0; hh < MH; hh++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int inst = 32 * hh + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -552,26 +629,23 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
                 cur.cr = m6; cur.cg = m7; cur.cbl = m8; cur.dep = m9; cur.pos = mp; cur_gid = mg;
             }
         };
-        if (count + c2 > 64) {
-            // the window does not fit: its farthest survivors fill the chunk up to exactly 64 lanes (every body of a
-            // chunk costs the same whatever the number of live lanes), the rest opens the next chunk
-            const int room = 64 - count;
-            if (room > 0) {
-                append(0, room, count);
-                cur.have = true;
-                cur_min = (uint32_t)k0;
+        // chunks are filled to exactly CAP lanes (every body of a chunk costs the same whatever the number of live
+        // lanes): the farthest survivors of the window top the open chunk up, the rest opens the next one(s)
+        int first = 0;
+        while (first < c2) {
+            if (count == CAP) {
+                process(cur, cur_gid, cur_min, count);
+                count = 0;
             }
-            process(cur, cur_gid, cur_min);
-            append(room, c2 - room, 0);
-            count = c2 - room;
-        } else {
-            append(0, c2, count);
-            count += c2;
+            const int n = min(c2 - first, CAP - count);
+            append(first, n, count);
+            count += n;
+            first += n;
+            cur.have = lane < count;
+            cur_min = (uint32_t)k0;      // every survivor of this window sits at a position >= k0
         }
-        cur.have = lane < count;
-        cur_min = (uint32_t)k0;      // every survivor of this window sits at a position >= k0
     }
-    if (count > 0) process(cur, cur_gid, cur_min);
+    if (count > 0) process(cur, cur_gid, cur_min, count);
     F3DGS_PHASE_END(cyc_walk);
 #ifdef F3DGS_DEV
     if ((a.dev & 8) && lane == 0) {
@@ -581,19 +655,40 @@ __global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
 #endif
 }
 
+// Two entry points over one body: the half-wave shape sits a few registers above the three-waves-per-SIMD budget
+// (156 + 16 against 168) and loses a third of its occupancy there; squeezed into the budget it keeps three waves.
+template <int CH, int NPIX, bool MF, int U, bool GEO, bool HALF>
+__global__ void __launch_bounds__(64) render_backward_kernel(BwdArgs a) {
+    render_backward_body<CH, NPIX, MF, U, GEO, HALF>(a);
+}
+template <int CH, int NPIX, bool MF, int U, bool GEO, bool HALF>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) render_backward_kernel_w3(BwdArgs a) {
+    render_backward_body<CH, NPIX, MF, U, GEO, HALF>(a);
+}
+
 template <int CH, int NPIX, bool MF>
 void launch_one(const BwdArgs& a, hipStream_t s) {
     const size_t lds = sizeof(BwdLds<CH, NPIX, MF>);
     const dim3 grid(a.gx * a.gy * (256 / NPIX));
     // later channel windows skip the geometric half of the work (default pixel-block size only: the other sizes are
     // experiment options and keep the one kernel, which tests write_base at the flush)
-    if constexpr (NPIX == 64 && CH > 0) {
-        if (!a.write_base) {
-            hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, false>), grid, dim3(64), lds, s, a);
+    if constexpr (NPIX == 64) {
+        if (a.half) {        // chunks of 32 instances against two pixel halves (default)
+            if constexpr (CH <= 32) {
+                if (CH > 0 && !a.write_base) hipLaunchKernelGGL((render_backward_kernel_w3<CH, NPIX, MF, 4, (CH == 0), true>), grid, dim3(64), lds, s, a);
+                else hipLaunchKernelGGL((render_backward_kernel_w3<CH, NPIX, MF, 4, true, true>), grid, dim3(64), lds, s, a);
+            } else {
+                if (!a.write_base) hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, false, true>), grid, dim3(64), lds, s, a);
+                else hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, true, true>), grid, dim3(64), lds, s, a);
+            }
+            return;
+        }
+        if (CH > 0 && !a.write_base) {
+            hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, (CH == 0), false>), grid, dim3(64), lds, s, a);
             return;
         }
     }
-    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, true>), grid, dim3(64), lds, s, a);
+    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, true, false>), grid, dim3(64), lds, s, a);
 }
 
 template <int CH, bool MF>
@@ -641,6 +736,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     a.part_major = opt.bwd_part_major;
     a.no_wave_cull = !opt.bwd_wave_cull;
     a.strip = opt.bwd_strip;
+    a.half = opt.bwd_half && !a.strip;
     const bool mf = opt.feature_mfma != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
