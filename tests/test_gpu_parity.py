@@ -264,3 +264,22 @@ def test_tile_culling_changes_lists_not_results(seed, P, W, H, C, needles, optio
         a_, b_ = pl_ref[rg_ref[t_, 0]:rg_ref[t_, 1]], pl_cul[rg_cul[t_, 0]:rg_cul[t_, 1]]
         it = iter(a_.tolist())
         assert all(x in it for x in b_.tolist()), f"tile {t_}: culled list is not an ordered subsequence"
+
+
+@pytest.mark.parametrize("C", [16, 32, 96])
+def test_chunk_shapes_of_the_blend_backward_agree(C, option):
+    """Option bwd_half (default 1: chunks of 32 instances against two pixel halves; 0: 64-lane chunks) changes only the
+    order of the float sums: both shapes give the same gradients (C = 16: VALU feature path, 32: matrix pipe, 96: a
+    second channel window that skips the geometric half of the body)."""
+    from synth import make_scene
+    sc = make_scene(P=30000, C=C, width=320, height=208, seed=23)
+    option("bwd_half", 1)
+    _, g1 = run_hip(sc)
+    option("bwd_half", 0)
+    _, g0 = run_hip(sc)
+    for k, a in g1.items():
+        if a is None:
+            continue
+        b = g0[k]
+        scale = float(np.abs(b).max()) + 1e-30
+        assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
