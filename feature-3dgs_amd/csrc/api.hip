@@ -74,9 +74,10 @@ hipEvent_t take_event_locked() {
 struct StageTimer {
     hipStream_t s;
     bool on;
+    bool blend_only;      // option profile = 2: only the two blend kernels are bracketed (4 events per step instead of 11)
     hipEvent_t prev;
-    explicit StageTimer(hipStream_t st) : s(st), on(profiling()), prev(nullptr) {
-        if (on) {
+    explicit StageTimer(hipStream_t st) : s(st), on(profiling()), blend_only(options().profile == 2), prev(nullptr) {
+        if (on && !blend_only) {
             {
                 std::lock_guard<std::mutex> lk(g_prof_mu);
                 prev = take_event_locked();
@@ -94,6 +95,24 @@ struct StageTimer {
     StageTimer& operator=(const StageTimer&) = delete;
     void mark(const char* name) {
         if (!on) return;
+        if (blend_only) {
+            const bool opens = strcmp(name, "tile_sort") == 0 || strcmp(name, "zero") == 0;      // the stage before a blend kernel
+            const bool closes = strcmp(name, "render_fwd") == 0 || strcmp(name, "render_bwd") == 0;
+            if (!opens && !closes) return;
+            hipEvent_t ev;
+            {
+                std::lock_guard<std::mutex> lk(g_prof_mu);
+                if (g_pending.size() >= MAX_PENDING_SPANS) resolve_pending_locked();
+                ev = take_event_locked();
+            }
+            (void)hipEventRecord(ev, s);
+            if (opens) { prev = ev; return; }           // (the destructor hands it back if no blend kernel follows)
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            if (prev) g_pending.push_back({name, prev, ev});
+            g_pending.push_back({nullptr, ev, nullptr});
+            prev = nullptr;
+            return;
+        }
         hipEvent_t e;
         {
             std::lock_guard<std::mutex> lk(g_prof_mu);

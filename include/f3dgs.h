@@ -69,7 +69,7 @@ const char* f3dgs_last_error(void);
  *                    could not blend at any of its pixels, so outputs are unchanged); 0: the reference's
  *                    bounding-rectangle lists, bit-identical private state (used by the parity tests)
  *   "feature_mfma"   1 (default): feature contraction of the blend kernels on the matrix pipe (exact fp32)
- *   "profile"        1: per-stage HIP events, see f3dgs_profile_read
+ *   "profile"        1: per-stage HIP events, see f3dgs_profile_read; 2: only around the two blend kernels
  *   "sort_onesweep"  1 (default): single-pass radix scatter with decoupled look-back; 0: three-kernel passes
  *   "bwd_npix", "bwd_part_major", "bwd_strip", "bwd_half", "bwd_wave_cull", "fwd_ppl", "fwd_variant":
  *                    kernel-shape tuning knobs (0 = automatic where applicable)
