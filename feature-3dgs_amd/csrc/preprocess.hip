@@ -357,28 +357,59 @@ __global__ void __launch_bounds__(256) count_totals_kernel(const uint32_t* __res
 }
 
 // Emit (tile, id) instances in depth order (same tile test as the count above).
+// A lane owns one Gaussian and produces its run of the list; the 64 runs of a wave are adjacent in the list (offsets are
+// an exclusive scan in this very order), so the wave first lays them out in LDS and then copies the whole range out with
+// contiguous stores (a lane storing straight to its own run writes one dword to 64 different places per instruction:
+// 0.061 ms for 42 MB at c3).  Waves whose range exceeds the LDS slice (a few huge splats) store directly.
+constexpr int EMIT_CAP = 1024;      // list entries per wave in LDS (8 KB)
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint32_t* __restrict__ tiles_touched, const SplatRec* __restrict__ rec, int gx, int gy,
                       int cull, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_id) {
+    __shared__ uint32_t s_tile[4][EMIT_CAP];
+    __shared__ uint32_t s_id[4][EMIT_CAP];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t g = order[i];
-    if (tiles_touched[g] == 0) return;
-    uint32_t off = offsets[i];
-    const float4 q0 = rec[g].q0, q1 = rec[g].q1;
-    const int radius = __float_as_int(rec[g].q2.z);  // integer bits stored by preprocess_kernel
-    int x0, y0, x1, y1;
-    tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
-    const CullParams ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-    const float cdet_inv = 1.0f / (q0.z * q1.x - q0.w * q0.w);
-    for (int y = y0; y < y1; y++) {
-        int xa = x0, xb = x1 - 1;
-        if (cull && !row_span(ck, cdet_inv, y, x0, x1, xa, xb)) continue;
-        for (int x = xa; x <= xb; x++) {
-            inst_tile[off] = (uint32_t)(y * gx + x);
-            inst_id[off] = g;
-            off++;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool valid = i < P;
+    const uint32_t g = valid ? order[i] : 0u;
+    const uint32_t cnt = valid ? tiles_touched[g] : 0u;
+    const uint32_t off0 = valid ? offsets[i] : 0u;
+    // the wave's range of the list: [offset of its first Gaussian, end of its last one)
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)off0);    // lane 0 of a launched wave is always < P
+    uint32_t end = valid ? off0 + cnt : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) end = max(end, (uint32_t)__shfl_xor((int)end, d, 64));
+    const uint32_t total = end - base;
+    const bool staged = total <= (uint32_t)EMIT_CAP;          // wave-uniform
+    if (cnt != 0) {
+        uint32_t off = off0;
+        const float4 q0 = rec[g].q0, q1 = rec[g].q1;
+        const int radius = __float_as_int(rec[g].q2.z);  // integer bits stored by preprocess_kernel
+        int x0, y0, x1, y1;
+        tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
+        const CullParams ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+        const float cdet_inv = 1.0f / (q0.z * q1.x - q0.w * q0.w);
+        for (int y = y0; y < y1; y++) {
+            int xa = x0, xb = x1 - 1;
+            if (cull && !row_span(ck, cdet_inv, y, x0, x1, xa, xb)) continue;
+            for (int x = xa; x <= xb; x++) {
+                if (staged) {
+                    s_tile[w][off - base] = (uint32_t)(y * gx + x);
+                    s_id[w][off - base] = g;
+                } else {
+                    inst_tile[off] = (uint32_t)(y * gx + x);
+                    inst_id[off] = g;
+                }
+                off++;
+            }
+        }
+    }
+    if (staged) {
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes have landed
+        for (uint32_t k = lane; k < total; k += 64) {
+            inst_tile[base + k] = s_tile[w][k];
+            inst_id[base + k] = s_id[w][k];
         }
     }
 }
