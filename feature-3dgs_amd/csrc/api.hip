@@ -187,6 +187,7 @@ const OptionDesc kOptions[] = {
     {"bwd_part_major", "F3DGS_BWD_PART_MAJOR", &Options::bwd_part_major, 0},
     {"bwd_strip", "F3DGS_BWD_STRIP", &Options::bwd_strip, 0},
     {"bwd_half", "F3DGS_BWD_HALF", &Options::bwd_half, 1},
+    {"fwd_w4", "F3DGS_FWD_W4", &Options::fwd_w4, 1},
     {"bwd_wave_cull", "F3DGS_BWD_WAVE_CULL", &Options::bwd_wave_cull, 1},
     {"fwd_ppl", "F3DGS_FWD_PPL", &Options::fwd_ppl, 0},
     {"fwd_variant", "F3DGS_FWD_VARIANT", &Options::fwd_variant, 0},

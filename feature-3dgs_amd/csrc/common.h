@@ -166,6 +166,7 @@ struct Options {
     int bwd_part_major;  // blend backward workgroup order
     int bwd_strip;       // blend backward: 16x4 strips instead of 8x8 quadrants
     int bwd_half;        // blend backward: chunks of 32 instances against two pixel halves (64-pixel blocks only)
+    int fwd_w4;          // blend forward, 32 channels, one quadrant per wave: four waves per SIMD (default 1)
     int bwd_wave_cull;   // blend backward: wave-level footprint culling (default 1)
     int fwd_ppl;         // quadrants per wave of the blend forward: 0 = automatic, 1/2/4
     int fwd_variant;     // blend forward chunk/group shape: 0 = default

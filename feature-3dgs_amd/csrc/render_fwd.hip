@@ -525,20 +525,37 @@ __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(
     render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
 }
 
-template <int CH, int PPL, int CHK, int GI>
-void launch_one_mf2(const FwdArgs& a, hipStream_t s) {
+template <int CH, int PPL, int CHK, int GI, bool BASE>
+__global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(4, 4))) render_forward_mfma_kernel_w4(FwdArgs a) {
+    render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
+}
+// Entry point by shape.  32 channels, one quadrant per wave, 32-instance chunks: 135 registers and 5.7 KB of LDS per wave -
+// squeezed into the four-waves-per-SIMD budget (128) it is the fastest shape at c3 (0.39 ms; 0.45 at three waves, 0.42-0.43
+// for two quadrants per wave with 64-instance chunks at three waves: 168 registers, 11.4 KB).
+template <int CH, int PPL, int CHK, int GI, bool BASE>
+void launch_shape(const FwdArgs& a, hipStream_t s) {
     constexpr int NW = 4 / PPL;
     const size_t lds = NW * sizeof(FwdChunkMF<CH, CHK>);
     const dim3 grid(a.gx * a.gy), block(256 / PPL);
-    if constexpr (CHK == 64 && GI == 4) {      // the default shape also exists without the colour / depth half
-        if (!a.write_base) {
-            if (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI, false>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI, false>), grid, block, lds, s, a);
+    if constexpr (CH <= 32 && PPL == 1 && CHK == 32) {
+        if (options().fwd_w4) {
+            hipLaunchKernelGGL((render_forward_mfma_kernel_w4<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
             return;
         }
     }
-    if (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI, true>), grid, block, lds, s, a);
+    if (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
+}
+template <int CH, int PPL, int CHK, int GI>
+void launch_one_mf2(const FwdArgs& a, hipStream_t s) {
+    // the two default shapes also exist without the colour / depth half (later channel windows of wide features)
+    if constexpr ((CHK == 64 && GI == 4) || (CHK == 32 && GI == 2 && PPL == 1)) {
+        if (!a.write_base) {
+            launch_shape<CH, PPL, CHK, GI, false>(a, s);
+            return;
+        }
+    }
+    launch_shape<CH, PPL, CHK, GI, true>(a, s);
 }
 template <int CH, int PPL>
 void launch_one_mf(const FwdArgs& a, hipStream_t s) {
@@ -546,7 +563,9 @@ void launch_one_mf(const FwdArgs& a, hipStream_t s) {
     if (v == 1) launch_one_mf2<CH, PPL, 32, 4>(a, s);
     else if (v == 2) launch_one_mf2<CH, PPL, 32, 2>(a, s);
     else if (v == 3) launch_one_mf2<CH, PPL, 64, 2>(a, s);
-    else launch_one_mf2<CH, PPL, 64, 4>(a, s);   // default: 64-instance chunks, 4-instance groups (measured best at c3)
+    else if (v == 4) launch_one_mf2<CH, PPL, 64, 4>(a, s);
+    else if (CH <= 32 && PPL == 1) launch_one_mf2<CH, PPL, 32, 2>(a, s);   // default for one quadrant per wave, see launch_shape
+    else launch_one_mf2<CH, PPL, 64, 4>(a, s);   // 64-instance chunks, 4-instance groups (best for two quadrants per wave / 64 channels)
 }
 
 template <int CH, int PPL>
@@ -585,7 +604,7 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
         } else if (a.nc <= 16) {
             if (ppl == 4) launch_one<16, 4>(a, s); else if (ppl == 2) launch_one<16, 2>(a, s); else launch_one<16, 1>(a, s);
         } else if (a.nc <= 32) {
-            if (mf) { if (ppl == 1) launch_one_mf<32, 1>(a, s); else launch_one_mf<32, 2>(a, s); }
+            if (mf) { if (ppl == 2) launch_one_mf<32, 2>(a, s); else launch_one_mf<32, 1>(a, s); }     // automatic: one quadrant per wave
             else if (ppl == 1) launch_one<32, 1>(a, s); else if (ppl == 4) launch_one<32, 4>(a, s); else launch_one<32, 2>(a, s);
         } else {
             if (mf) { if (ppl == 2) launch_one_mf<64, 2>(a, s); else launch_one_mf<64, 1>(a, s); }

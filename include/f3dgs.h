@@ -71,7 +71,7 @@ const char* f3dgs_last_error(void);
  *   "feature_mfma"   1 (default): feature contraction of the blend kernels on the matrix pipe (exact fp32)
  *   "profile"        1: per-stage HIP events, see f3dgs_profile_read; 2: only around the two blend kernels
  *   "sort_onesweep"  1 (default): single-pass radix scatter with decoupled look-back; 0: three-kernel passes
- *   "bwd_npix", "bwd_part_major", "bwd_strip", "bwd_half", "bwd_wave_cull", "fwd_ppl", "fwd_variant":
+ *   "bwd_npix", "bwd_part_major", "bwd_strip", "bwd_half", "bwd_wave_cull", "fwd_ppl", "fwd_variant", "fwd_w4":
  *                    kernel-shape tuning knobs (0 = automatic where applicable)
  * Unknown names return F3DGS_ERR_INVALID_ARGUMENT.
  */
