@@ -531,7 +531,8 @@ __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(
 }
 // Entry point by shape.  32 channels, one quadrant per wave, 32-instance chunks: 135 registers and 5.7 KB of LDS per wave -
 // squeezed into the four-waves-per-SIMD budget (128) it is the fastest shape at c3 (0.39 ms; 0.45 at three waves, 0.42-0.43
-// for two quadrants per wave with 64-instance chunks at three waves: 168 registers, 11.4 KB).
+// for two quadrants per wave with 64-instance chunks at three waves: 168 registers, 11.4 KB).  64 channels, same shape:
+// 150 registers and 9.7 KB, three waves per SIMD instead of two with 64-instance chunks (c4: 2.58 -> 2.23 ms).
 template <int CH, int PPL, int CHK, int GI, bool BASE>
 void launch_shape(const FwdArgs& a, hipStream_t s) {
     constexpr int NW = 4 / PPL;
@@ -543,7 +544,7 @@ void launch_shape(const FwdArgs& a, hipStream_t s) {
             return;
         }
     }
-    if (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
+    if (CH <= 32 || (PPL == 1 && CHK == 32)) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
 }
 template <int CH, int PPL, int CHK, int GI>
@@ -564,8 +565,8 @@ void launch_one_mf(const FwdArgs& a, hipStream_t s) {
     else if (v == 2) launch_one_mf2<CH, PPL, 32, 2>(a, s);
     else if (v == 3) launch_one_mf2<CH, PPL, 64, 2>(a, s);
     else if (v == 4) launch_one_mf2<CH, PPL, 64, 4>(a, s);
-    else if (CH <= 32 && PPL == 1) launch_one_mf2<CH, PPL, 32, 2>(a, s);   // default for one quadrant per wave, see launch_shape
-    else launch_one_mf2<CH, PPL, 64, 4>(a, s);   // 64-instance chunks, 4-instance groups (best for two quadrants per wave / 64 channels)
+    else if (PPL == 1) launch_one_mf2<CH, PPL, 32, 2>(a, s);   // default for one quadrant per wave, see launch_shape
+    else launch_one_mf2<CH, PPL, 64, 4>(a, s);   // 64-instance chunks, 4-instance groups (best for two quadrants per wave)
 }
 
 template <int CH, int PPL>
