@@ -149,7 +149,7 @@ constexpr int FLUSH_STRIDE = FLUSH_GROUP + 1; // odd: conflict-free lane-major w
 // pipe (exact-fp32 v_mfma_f32_32x32x2_f32) concurrently with the VALU work; dO is then kept row-major per
 // pixel with an odd row stride.  MF = false keeps it as float4 [c/4][pixel] for the VALU FMAs.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int CH, int NPIX, bool MF>
+template <int CH, int NPIX, bool MF, bool HALF = false>
 struct BwdLds {
     // Row stride (floats) of the MF image: unpadded, columns XOR-swizzled by the pixel index (staging writes and
     // matrix-pipe operand reads are both conflict-free).  Together with
@@ -162,7 +162,7 @@ struct BwdLds {
     float4 gf[MF ? 1 : (CH > 0 ? CH / 4 : 1)][MF ? 1 : NPIX];
     float gfm[MF ? NPIX * GS : 4];
     static constexpr int FS = MF ? 11 : FLUSH_STRIDE;   // MF: only the 10 geometric sums travel through LDS
-    float flush[64 * FS];
+    float flush[(HALF ? 32 : 64) * FS];        // one row per instance of a chunk
 };
 
 #ifdef F3DGS_DEV
@@ -200,7 +200,7 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
     constexpr int PARTS = 256 / NPIX;          // waves (workgroups) per tile
     constexpr int ROWS = NPIX / 16;            // pixel rows owned by this wave (NPIX = 256/128/64)
     constexpr int NV = NPIX >= 64 ? NPIX / 64 : 1;   // pixel-state registers per lane (NPIX = 32: lanes 32-63 idle here)
-    using Lds = BwdLds<CH, NPIX, MF>;
+    using Lds = BwdLds<CH, NPIX, MF, HALF>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds& L = *reinterpret_cast<Lds*>(smem);
     const int lane = threadIdx.x;
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
 
 template <int CH, int NPIX, bool MF>
 void launch_one(const BwdArgs& a, hipStream_t s) {
-    const size_t lds = sizeof(BwdLds<CH, NPIX, MF>);
+    const size_t lds = (NPIX == 64 && a.half) ? sizeof(BwdLds<CH, NPIX, MF, true>) : sizeof(BwdLds<CH, NPIX, MF, false>);
     const dim3 grid(a.gx * a.gy * (256 / NPIX));
     // later channel windows skip the geometric half of the work (default pixel-block size only: the other sizes are
     // experiment options and keep the one kernel, which tests write_base at the flush)
