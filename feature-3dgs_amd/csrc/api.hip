@@ -248,7 +248,7 @@ CountReadback& count_readback() {
 
 extern "C" {
 
-int f3dgs_version(void) { return 200; }
+int f3dgs_version(void) { return 210; }   // 2.1: + densify_gather, adam_step_rows, options bwd_half / fwd_w4, profile = 2
 
 int f3dgs_set_option(const char* name, int value) {
     if (!name) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null option name");
