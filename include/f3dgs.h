@@ -54,7 +54,7 @@ extern "C" {
  * resizeFunctional() of rasterize_points.cu:27-33. */
 typedef char* (*f3dgs_resize_fn)(void* ctx, size_t nbytes);
 
-/* Library / ABI version (major*10000 + minor*100 + patch). */
+/* Library / ABI version: major*10000 + minor*100 + patch (3.0.0 -> 30000). */
 int f3dgs_version(void);
 
 /* Thread-local message of the last error raised on this host thread. */
@@ -70,7 +70,8 @@ const char* f3dgs_last_error(void);
  *                    bounding-rectangle lists, bit-identical private state (used by the parity tests)
  *   "feature_mfma"   1 (default): feature contraction of the blend kernels on the matrix pipe (exact fp32)
  *   "profile"        1: per-stage HIP events, see f3dgs_profile_read; 2: only around the two blend kernels
- *   "sort_onesweep"  1 (default): single-pass radix scatter with decoupled look-back; 0: three-kernel passes
+ *   "sort_onesweep"  0 (default): three-kernel radix passes; 1: single-pass radix scatter with decoupled look-back
+ *                    (measured slower on MI355X, kept as a tested alternative)
  *   "bwd_npix", "bwd_part_major", "bwd_strip", "bwd_half", "bwd_wave_cull", "fwd_ppl", "fwd_variant", "fwd_w4":
  *                    kernel-shape tuning knobs (0 = automatic where applicable)
  * Unknown names return F3DGS_ERR_INVALID_ARGUMENT.

@@ -37,6 +37,12 @@ OUT = os.path.join(HERE, "_ref")
 HIPIFY = "/opt/rocm/bin/hipify-perl"
 HIPCC = "/opt/rocm/bin/hipcc"
 DEFAULT_CHANNELS = (3, 16, 32, 64, 128, 256)
+# A second flavour `_refC<n>s` of the same sources built with `-ffp-contract=off`: the product's preprocess kernel is
+# built without FMA contraction (so that it agrees bit-for-bit with the C++ oracle), the default flavour above with the
+# compiler's default contraction, as nvcc builds the reference.  Integer artefacts (radii, tile counts, num_rendered)
+# are asserted EXACTLY equal against the strict flavour at the full BASELINE sizes (tests/test_gpu_vs_ref.py); what
+# is left against the contracted flavour is then a documented property of the checker's build, not of the product.
+STRICT_CHANNELS = (16, 32, 128, 256)
 
 FILES = [
     "cuda_rasterizer/auxiliary.h", "cuda_rasterizer/backward.cu", "cuda_rasterizer/backward.h",
@@ -80,12 +86,12 @@ def _translate(text: str, channels: int, name: str) -> str:
     return text
 
 
-def module_path(channels: int) -> str:
-    return os.path.join(OUT, f"_refC{channels}" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+def module_path(channels: int, strict: bool = False) -> str:
+    return os.path.join(OUT, f"_refC{channels}" + ("s" if strict else "") + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 
-def build_one(channels: int, force: bool = False, verbose: bool = True, keep_src: bool = False) -> str:
-    target = module_path(channels)
+def build_one(channels: int, force: bool = False, verbose: bool = True, keep_src: bool = False, strict: bool = False) -> str:
+    target = module_path(channels, strict)
     srcs = [os.path.join(REF, f) for f in FILES]
     if not force and os.path.exists(target) and all(
             os.path.getmtime(s) <= os.path.getmtime(target) for s in srcs):   # (--force after editing this recipe)
@@ -94,7 +100,7 @@ def build_one(channels: int, force: bool = False, verbose: bool = True, keep_src
     import torch
     from torch.utils import cpp_extension as ce
 
-    sdir = os.path.join(OUT, f"src_C{channels}")
+    sdir = os.path.join(OUT, f"src_C{channels}" + ("s" if strict else ""))
     shutil.rmtree(sdir, ignore_errors=True)
     os.makedirs(os.path.join(sdir, "cuda_rasterizer"))
     for f in FILES:
@@ -108,12 +114,13 @@ def build_one(channels: int, force: bool = False, verbose: bool = True, keep_src
            + [pybind11.get_include(), sysconfig.get_paths()["include"], "/opt/rocm/include"])
     libdirs = ce.library_paths()
     abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
-    mod = f"_refC{channels}"
+    mod = f"_refC{channels}" + ("s" if strict else "")
     common = (["--offload-arch=gfx950", "-mcode-object-version=5", "-O3", "-std=c++17", "-fPIC", "-w",
                "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={abi}",
                f"-DTORCH_EXTENSION_NAME={mod}", "-DTORCH_API_INCLUDE_EXTENSION_H",
-               # reference build: nvcc default = FMA contraction on, as clang's HIP default (fast)
-               ] + [f"-I{p}" for p in inc])
+               # reference build: nvcc default = FMA contraction on, as clang's HIP default (fast);
+               # the strict flavour turns it off (see STRICT_CHANNELS)
+               ] + (["-ffp-contract=off"] if strict else []) + [f"-I{p}" for p in inc])
     objs = []
     units = ["cuda_rasterizer/forward.hip", "cuda_rasterizer/backward.hip", "cuda_rasterizer/rasterizer_impl.hip",
              "rasterize_points.hip", "ext.cpp"]
@@ -235,11 +242,18 @@ def build_knn(force: bool = False, keep_src: bool = False) -> str:
     return target
 
 
-def build_all(channels=DEFAULT_CHANNELS, force: bool = False, keep_src: bool = False) -> list:
+def build_all(channels=DEFAULT_CHANNELS, force: bool = False, keep_src: bool = False, strict_channels=STRICT_CHANNELS) -> list:
     if not os.path.isdir(REF):
         raise FileNotFoundError(f"{REF} not present (the GPU box only uses the prebuilt oracle/_ref modules)")
     os.makedirs(OUT, exist_ok=True)
-    return build_callers(force) + [build_knn(force, keep_src)] + [build_one(c, force, keep_src=keep_src) for c in channels]
+    import torch  # noqa: F401  (imported once, before the worker threads need it)
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [(c, False) for c in channels] + [(c, True) for c in strict_channels]
+    done = build_callers(force) + [build_knn(force, keep_src)]
+    # every flavour is five independent hipcc processes; a few flavours at a time keep all host cores busy
+    with ThreadPoolExecutor(max_workers=max(1, min(4, (os.cpu_count() or 2) // 2))) as ex:
+        done += list(ex.map(lambda j: build_one(j[0], force, keep_src=keep_src, strict=j[1]), jobs))
+    return done
 
 
 if __name__ == "__main__":

@@ -25,24 +25,28 @@ from util import ROOT
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
 
-def ref_path(C: int) -> str:
-    return os.path.join(REF_DIR, f"_refC{C}" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+def ref_path(C: int, strict: bool = False) -> str:
+    return os.path.join(REF_DIR, f"_refC{C}" + ("s" if strict else "") + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 
 _loaded = {}
 
 
-def load_ref(C: int):
-    """The reference's `_C` compiled with NUM_SEMANTIC_CHANNELS = C (config.h:16); skips when not built."""
-    if C in _loaded:
-        return _loaded[C]
-    p = ref_path(C)
+def load_ref(C: int, strict: bool = False):
+    """The reference's `_C` compiled with NUM_SEMANTIC_CHANNELS = C (config.h:16); skips when not built.
+    strict: the flavour built with `-ffp-contract=off` (oracle/build_ref.py: STRICT_CHANNELS) - the product's
+    preprocess is built that way too, so integer artefacts must agree EXACTLY with it."""
+    key = (C, strict)
+    if key in _loaded:
+        return _loaded[key]
+    p = ref_path(C, strict)
     if not os.path.exists(p):
         pytest.skip(f"{p} not built (run `python oracle/build_ref.py` where /root/reference exists)")
-    spec = importlib.util.spec_from_file_location(f"_refC{C}", p)
+    name = f"_refC{C}" + ("s" if strict else "")
+    spec = importlib.util.spec_from_file_location(name, p)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    _loaded[C] = mod
+    _loaded[key] = mod
     return mod
 
 
@@ -101,18 +105,18 @@ def raw_backward(mod, scene: dict, d: dict, fwd, dL_dcolor=None, dL_dfeature=Non
 
 
 # ---------------------------------------------------------------- the reference's private state -----
-def _carve(buf: torch.Tensor, fields):
+def _carve(buf: torch.Tensor, fields, want=None):
     """Replays `obtain()` (rasterizer_impl.h:25-30) over a reference state buffer; fields = [(name, dtype,
-    count)] in carve order; a dtype of None is an opaque byte run.  Returns {name: numpy array}."""
+    count)] in carve order; a dtype of None is an opaque byte run.  Returns {name: numpy array}; only the fields
+    named in `want` (default: all) are copied to the host (the full-size configs hold GBs of state)."""
     base = buf.data_ptr()
-    host = buf.cpu().numpy().view(np.uint8)
     p = base
     out = {}
     for name, dtype, count in fields:
         p = (p + 127) & ~127
         nbytes = count * (np.dtype(dtype).itemsize if dtype is not None else 1)
-        if dtype is not None and name is not None:
-            out[name] = host[p - base:p - base + nbytes].view(dtype).copy()
+        if dtype is not None and name is not None and (want is None or name in want):
+            out[name] = buf[p - base:p - base + nbytes].cpu().numpy().view(dtype).copy()
         p += nbytes
     return out
 
@@ -127,14 +131,14 @@ def ref_image_state(fwd, W: int, H: int) -> dict:
     return st
 
 
-def ref_geometry_state(fwd, P: int, C: int) -> dict:
+def ref_geometry_state(fwd, P: int, C: int, want=None) -> dict:
     """depths, clamped, means2D, cov3D, conic_opacity, rgb, (features), tiles_touched
     (rasterizer_impl.cu:154-172).  `tiles_touched` is NOT overwritten by the scan (it writes point_offsets);
     `internal_radii` is unused whenever the caller passes a radii tensor (rasterizer_impl.cu:236-239)."""
     return _carve(fwd[5], [("depths", np.float32, P), ("clamped", np.uint8, 3 * P), (None, np.int32, P),
                            ("means2D", np.float32, 2 * P), ("cov3D", np.float32, 6 * P),
                            ("conic_opacity", np.float32, 4 * P), ("rgb", np.float32, 3 * P),
-                           (None, np.float32, P * C), ("tiles_touched", np.uint32, P)])
+                           (None, np.float32, P * C), ("tiles_touched", np.uint32, P)], want)
 
 
 def ref_point_list(fwd) -> np.ndarray:
@@ -189,7 +193,22 @@ def flip_pixels(ref_img: dict, got_img: dict) -> np.ndarray:
 
 def grad_errors(got, want):
     """(normalised max error, worst element-wise excess) for `|got - want| <= 1e-3*|want| + 1e-5*max|want|`;
-    the second number is max(|err| / (1e-3*|want| + 1e-5*scale)): <= 1 means every element is inside."""
+    the second number is max(|err| / (1e-3*|want| + 1e-5*scale)): <= 1 means every element is inside.
+    Device tensors are compared where they live (fp64 on the GPU: the full-size configs hold 10^9 elements)."""
+    if isinstance(want, torch.Tensor):
+        want = want.detach().reshape(-1).double()
+        got = got.detach().reshape(-1).double()
+        if want.numel() == 0:
+            return 0.0, 0.0
+        scale = float(want.abs().max()) + 1e-30
+        mx, worst = 0.0, 0.0
+        step = 1 << 26                       # bounded temporaries
+        for i in range(0, want.numel(), step):
+            w, g = want[i:i + step], got[i:i + step]
+            err = (g - w).abs()
+            mx = max(mx, float(err.max()))
+            worst = max(worst, float((err / (1e-3 * w.abs() + 1e-5 * scale)).max()))
+        return mx / scale, worst
     want = np.asarray(want, np.float64).reshape(-1)
     got = np.asarray(got, np.float64).reshape(-1)
     if want.size == 0:

@@ -1,5 +1,6 @@
-"""Data-parallel step over the `nccl` backend (= RCCL) with the REAL op: two ranks share the one GPU of the test box
-(RCCL allows several ranks per device when asked to; if this build refuses, the test skips with RCCL's message).
+"""Data-parallel step over the `nccl` backend (= RCCL) with the REAL op: rank r runs on `cuda:(r % device_count)`, so
+on any box with two or more GPUs the two ranks are two devices talking over xGMI; on a one-GPU box both ranks land
+on cuda:0, RCCL refuses ("Duplicate GPU detected") and the test skips with RCCL's message.
 Each rank renders its own view; afterwards `leaf.grad` of every leaf must equal the sum of the two single-process
 gradients, with and without the in-backward overlap of the feature all-reduce (dp.FeatureGradOverlap)."""
 import os
@@ -50,10 +51,10 @@ def _worker(rank, world, port, out_dir):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     try:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         probe = torch.ones(4, device=dev)
         dist.all_reduce(probe)          # RCCL builds that refuse two ranks on one device fail here
         torch.cuda.synchronize()
@@ -80,7 +81,7 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_device_rccl(tmp_path):
+def test_two_ranks_rccl(tmp_path):
     world = 2
     os.environ.setdefault("NCCL_DEBUG", "WARN")
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
