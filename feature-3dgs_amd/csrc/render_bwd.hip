@@ -28,6 +28,7 @@
 // (the gradient tolerance of the path is 1e-3 relative).
 
 #include <cstdio>
+#include <vector>
 
 #include "render_common.h"
 
@@ -35,30 +36,6 @@ namespace f3dgs {
 
 namespace {
 
-struct BwdArgs {
-    const uint2* ranges;
-    const uint32_t* point_list;
-    const SplatRec* rec;
-    const float* bg;
-    const float* final_T;
-    const uint32_t* n_contrib;
-    const float* dL_dpix;
-    const float* dL_dfeat;
-    const float* dL_ddepth;
-    float* grec;         // P x GREC
-    float* dL_dfeature;  // P x C
-    int W, H, gx, gy;
-    int C, c0, nc;
-    int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
-    int part_major;  // workgroup -> (tile, part) order, see kernel
-    int strip;        // NPIX = 64: 16x4 pixel strips instead of 8x8 quadrants
-    int half;         // NPIX = 64: chunks of 32 instances, the two halves of the wave take different pixels
-    int no_wave_cull; // option bwd_wave_cull = 0: no wave-level footprint culling / compaction
-#ifdef F3DGS_DEV
-    int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs, bit3 phase timing
-    unsigned long long* dev_cycles;   // [0] staging, [1] window walk, [2] pixel trips, [3] flush, [4] waves
-#endif
-};
 
 // ---- paired DPP prefix scans --------------------------------------------------------------------------
 // Two independent inclusive scans over the 64 lanes run interleaved so that each DPP instruction's
@@ -716,7 +693,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
 #ifdef F3DGS_DEV
     a.dev = opt.dev;
     static unsigned long long* dev_cycles = nullptr;
-    if (!dev_cycles) (void)hipMalloc(&dev_cycles, 8 * sizeof(unsigned long long));
+    if (!dev_cycles) (void)hipMalloc(&dev_cycles, (size_t)8 * sizeof(unsigned long long) * 262144 * 4);
     a.dev_cycles = dev_cycles;
     if (a.dev & 8) (void)hipMemsetAsync(dev_cycles, 0, 8 * sizeof(unsigned long long), s);
     struct Report {     // prints the phase totals of this launch when it goes out of scope (synchronises: dev only)
@@ -735,6 +712,25 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     const int npix = opt.bwd_npix ? opt.bwd_npix : 64;
     a.part_major = opt.bwd_part_major;
     a.no_wave_cull = !opt.bwd_wave_cull;
+    if (opt.bwd_pl && opt.feature_mfma && !opt.bwd_npix) {      // pixel-lane formulation (render_bwd_pl.hip), the default
+        a.strip = 0; a.half = 0;
+        launch_render_backward_pl(a, C, s);
+#ifdef F3DGS_DEV
+        if (a.dev & 8) {
+            unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipStreamSynchronize(s);
+            const size_t nw = (size_t)a.gx * a.gy * 4;
+            std::vector<unsigned long long> all(nw * 8);
+            (void)hipMemcpy(all.data(), dev_cycles, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < nw; i++) for (int k = 0; k < 8; k++) h[k] += all[i * 8 + k];
+            const double w = (double)(h[7] ? h[7] : 1);
+            fprintf(stderr, "[f3dgs dev] pixel-lane backward, cycles per wave: staging %.0f  walk %.0f  phase1 %.0f  phase2 %.0f  flush %.0f | chunks/wave %.2f entries/wave %.1f (%llu waves); per chunk: phase1 %.0f phase2 %.0f flush %.0f\n",
+                    h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
+            report.on = false;
+        }
+#endif
+        return;
+    }
     a.strip = opt.bwd_strip;
     a.half = opt.bwd_half && !a.strip;
     const bool mf = opt.feature_mfma != 0;

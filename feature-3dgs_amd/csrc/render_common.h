@@ -75,6 +75,33 @@ __device__ __forceinline__ bool rect_hit(float mx, float my, float ca, float cb,
     return !(best > thresh * 1.001f);   // NaN keeps the splat; extra 0.1 % for the approximate log / rcp
 }
 
+// Arguments of the blend backward kernels (render_bwd.hip: instance-lane formulation; render_bwd_pl.hip: pixel-lane
+// formulation).
+struct BwdArgs {
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const SplatRec* rec;
+    const float* bg;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const float* dL_dpix;
+    const float* dL_dfeat;
+    const float* dL_ddepth;
+    float* grec;         // P x GREC
+    float* dL_dfeature;  // P x C
+    int W, H, gx, gy;
+    int C, c0, nc;
+    int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
+    int part_major;  // workgroup -> (tile, part) order, see kernel
+    int strip;        // NPIX = 64: 16x4 pixel strips instead of 8x8 quadrants
+    int half;         // NPIX = 64: chunks of 32 instances, the two halves of the wave take different pixels
+    int no_wave_cull; // option bwd_wave_cull = 0: no wave-level footprint culling / compaction
+#ifdef F3DGS_DEV
+    int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs, bit3 phase timing
+    unsigned long long* dev_cycles;   // [0] staging, [1] window walk, [2] pixel trips, [3] flush, [4] waves
+#endif
+};
+
 struct TileGeom {
     int tx, ty;        // tile coordinates
 };

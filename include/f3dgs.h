@@ -72,7 +72,7 @@ const char* f3dgs_last_error(void);
  *   "profile"        1: per-stage HIP events, see f3dgs_profile_read; 2: only around the two blend kernels
  *   "sort_onesweep"  0 (default): three-kernel radix passes; 1: single-pass radix scatter with decoupled look-back
  *                    (measured slower on MI355X, kept as a tested alternative)
- *   "bwd_npix", "bwd_part_major", "bwd_strip", "bwd_half", "bwd_wave_cull", "fwd_ppl", "fwd_variant", "fwd_w4":
+ *   "bwd_npix", "bwd_part_major", "bwd_strip", "bwd_half", "bwd_wave_cull", "bwd_pl", "fwd_ppl", "fwd_variant", "fwd_w4":
  *                    kernel-shape tuning knobs (0 = automatic where applicable)
  * Unknown names return F3DGS_ERR_INVALID_ARGUMENT.
  */

@@ -59,9 +59,15 @@ def _compare(scene, C_ref, pc=False, pv=False, flip_budget=None, check_state=Tru
     stats = {}
 
     # ---- integer artefacts
-    assert int(f_ref[0]) == int(f_prod[0]), f"num_rendered {int(f_prod[0])} vs reference {int(f_ref[0])}"
     r_ref, r_prod = f_ref[4].cpu().numpy(), f_prod[4].cpu().numpy()
     assert r_prod.dtype == r_ref.dtype and r_prod.shape == r_ref.shape
+    # num_rendered = sum of the 3-sigma rectangles' tile counts: equal whenever the radii are; a radius that differs by
+    # one (see below: only against the FMA-contracted flavour of the checker) moves its rectangle by at most one tile
+    # row and one tile column.  Against the strict flavour the count is asserted EXACTLY (strict_ints).
+    n_rad = int((r_ref != r_prod).sum())
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    assert abs(int(f_ref[0]) - int(f_prod[0])) <= n_rad * (gx + gy + 1), \
+        f"num_rendered {int(f_prod[0])} vs reference {int(f_ref[0])} with {n_rad} differing radii"
     if strict_ints:
         # same sources, no FMA contraction - as the product's preprocess: EXACT
         f_s = ru.raw_forward(ru.load_ref(C_ref, strict=True), scene, d_ref)
