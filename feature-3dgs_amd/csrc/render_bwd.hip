@@ -719,12 +719,12 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
         if (a.dev & 8) {
             unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             (void)hipStreamSynchronize(s);
-            const size_t nw = (size_t)a.gx * a.gy * 4;
+            const size_t nw = (size_t)a.gx * a.gy * 4;     // waves
             std::vector<unsigned long long> all(nw * 8);
             (void)hipMemcpy(all.data(), dev_cycles, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             for (size_t i = 0; i < nw; i++) for (int k = 0; k < 8; k++) h[k] += all[i * 8 + k];
             const double w = (double)(h[7] ? h[7] : 1);
-            fprintf(stderr, "[f3dgs dev] pixel-lane backward, cycles per wave: staging %.0f  walk %.0f  phase1 %.0f  phase2 %.0f  flush %.0f | chunks/wave %.2f entries/wave %.1f (%llu waves); per chunk: phase1 %.0f phase2 %.0f flush %.0f\n",
+            fprintf(stderr, "[f3dgs dev] pixel-lane backward, cycles per wave: staging %.0f  window %.0f  phase1 %.0f  phase2+merge %.0f  flush %.0f | chunks/wave %.2f entries/wave %.1f (%llu waves); per chunk: phase1 %.0f phase2 %.0f flush %.0f\n",
                     h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
             report.on = false;
         }

@@ -4,26 +4,34 @@
 // Q3, Q5, Q8 as in render_bwd.hip.
 //
 // The instance-lane kernel (render_bwd.hip) pays for the list-order dependence with two DPP prefix scans per pixel and
-// chunk and runs every per-(pixel, Gaussian) multiply-add on the vector pipe.  Here the two halves of the problem are
-// separated and each runs where it is cheap:
+// chunk, runs every per-(pixel, Gaussian) multiply-add on the vector pipe and flushes one partial sum per (8x8 quadrant,
+// Gaussian) with global atomics.  Here the work is cut differently: one 16x16 tile per WORKGROUP of four waves; the
+// tile's list is walked back to front in windows of 64 entries (splat records gathered ONCE per tile into LDS, a window
+// ahead) and processed in chunks of 16 consecutive entries, every chunk in two phases:
 //
-//   phase 1 (vector pipe, lane = PIXEL, one 8x8 quadrant per wave): the wave walks a chunk of 16 compacted list
-//     entries back to front, one entry at a time; transmittance T and the "colour behind" sum S are per-lane running
-//     scalars, so the recurrences are two multiply-adds - no scans.  Per entry and pixel it produces two numbers,
-//         w = alpha T_front            (blend weight:   every dL/d{colour, depth, feature} sum is  sum_px w  x  dL/dpixel)
-//         s = op G dL/dalpha           (every geometric sum is a moment  sum_px s x {1, x, y, x^2, xy, y^2}),
-//     and stores them in two 16 x 64 LDS tiles (pixel-permuted columns, see PlLds).
-//   phase 2 (matrix pipe): every per-Gaussian sum of the chunk is ONE contraction over the 64 pixels,
-//         [16 entries x 64 px] x [64 px x (C + 4 + 6)]  ->  exact-fp32 v_mfma_f32_16x16x4_f32,
-//     whose B operands (dL/dfeature, dL/dcolour, dL/ddepth of the wave's pixels and the pixel monomials) are loaded ONCE
-//     per wave into registers in operand layout - the dL/dfeature tile never touches LDS (this is what capped the
-//     instance-lane kernel at three waves per SIMD).  The A operands come back from the two LDS tiles with four
-//     conflict-free 16-byte reads each.
-//   flush: feature sums leave the accumulators as 64-byte runs (lane = channel) of coalesced atomics; the ten geometric
-//     sums are rebuilt from the moments about the block centre (dx = (mean - centre) - u) by 16 lanes.
+//   phase 1 (vector pipe, lane = PIXEL, wave = 8x8 QUADRANT): the wave takes its hits of the chunk (rect_hit against its
+//     quadrant, lane = entry, once per window) one after the other (NE at a time for instruction-level parallelism);
+//     transmittance T and the "colour behind" sum S are per-lane running scalars, so the recurrences are two
+//     multiply-adds - no scans.  Per entry and pixel it produces two numbers,
+//         w = alpha T_front            (every dL/d{colour, depth, feature} sum is  sum_px w  x  dL/dpixel)
+//         s = op G dL/dalpha           (every geometric sum is a moment  sum_px s x {1, u, v, u^2, uv, v^2}),
+//     stored in the quadrant's two 16 x 64 LDS tiles (pixel-permuted columns, see PlShared); rows of entries that miss the
+//     quadrant are zeroed.
+//   phase 2 (matrix pipe, wave = 16 output COLUMNS): every per-Gaussian sum of the chunk is ONE contraction over the 256
+//     pixels of the tile,  [16 entries x 256 px] x [256 px x (C + 4 + 6)]  ->  exact-fp32 v_mfma_f32_16x16x4_f32.  The
+//     four waves split the OUTPUT COLUMNS, not the pixels: wave 0 / 1 take feature channels 0-15 / 16-31, wave 2 the
+//     four colour / depth columns, wave 3 the six moment columns (later channel windows of a wide feature: sixteen
+//     channels per wave).  Each wave reads the A tiles of all four quadrants and keeps its B operand - its sixteen
+//     columns at all 256 pixels, 64 registers - resident for its whole life (the gradient images are staged once per tile
+//     through LDS with full-row requests).  A wave's accumulators therefore hold TILE-level sums: no partial sums are
+//     merged anywhere, and the tile leaves ONE coalesced atomic flush per (tile, entry) - 2.7x fewer global atomic
+//     requests than the per-quadrant flushes of the instance-lane kernel at config c3 - after the geometric sums are
+//     rebuilt from the moments about the tile centre (dx = (mean - centre) - u).
 //
-// Work per (entry, wave): ~28 vector instructions (instance-lane kernel: 63 per 64 pairs) and 4 matrix instructions
-// (128 matrix-pipe cycles at C = 32); the two pipes overlap across the waves of a SIMD.
+// Work per (entry, wave): ~35 vector instructions where the entry reaches the quadrant (instance-lane kernel: 63 per 64
+// pairs) and 4 matrix instructions (128 matrix-pipe cycles); the two pipes overlap across the workgroups of a CU.
+
+#include <cstdio>
 
 #include "render_common.h"
 
@@ -34,344 +42,434 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef F3DGS_DEV
-#define PL_DEV_SKIP(bit) (a.dev & (bit))     // 1: no atomics  2: no phase 1/2  4: no matrix instructions  16: no geometric atomics  32: no feature atomics
+#define PL_DEV_SKIP(bit) (a.dev & (bit))     // 1: no global atomics  2: no phase 1  4: no matrix instructions  16: no flush
 #define PL_PHASE_BEGIN() unsigned long long ph_t0_ = (a.dev & 8) ? __builtin_readcyclecounter() : 0ull; unsigned long long cyc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PL_PHASE_END(K) do { if (a.dev & 8) { const unsigned long long t1_ = __builtin_readcyclecounter(); cyc_[K] += t1_ - ph_t0_; ph_t0_ = t1_; } } while (0)
 #define PL_COUNT(K, N) do { if (a.dev & 8) cyc_[K] += (N); } while (0)
+#define PL_STAGE_MARK(K) do { if (a.dev & 32) PL_PHASE_END(K); } while (0)     // staging only (bit 32): finer phases
 #else
 #define PL_DEV_SKIP(bit) false
 #define PL_PHASE_BEGIN() do {} while (0)
 #define PL_PHASE_END(K) do {} while (0)
 #define PL_COUNT(K, N) do {} while (0)
+#define PL_STAGE_MARK(K) do {} while (0)
 #endif
 
 constexpr int PL_CAP = 16;         // list entries per chunk = rows of one 16x16x4 matrix instruction
-constexpr int PL_ROW = 68;         // dwords per pixel block row of the A tiles (16 entries x 4 px + one 4-dword skew slot)
+constexpr int PL_ROW = 68;         // dwords per pixel-block row of an A tile (16 entries x 4 px + one 4-dword skew slot)
+constexpr int PL_TILE = 16 * PL_ROW;
+constexpr int PL_WIN = 64;         // list entries per window
+constexpr int PL_FS = 68;          // dwords per entry of the flush tile: 32 (64) feature sums; 4 colour / depth sums + 4 x 6 moments
+constexpr int PL_SP = 260;         // dwords per plane of the staging image (16 x 16 pixels + 4: plane offset of 4 banks)
+constexpr int PL_STAGE_PLANES = 38;
 
-// One staged (compacted) list entry: three broadcast reads per entry in phase 1.
-struct PlEnt {
+// One staged list entry (shared by the four waves): three broadcast reads per entry in phase 1.
+struct PlRec {
     float4 q0;   // mean_x, mean_y, conic_a', conic_b'   (conic pre-scaled, see splat_power2)
-    float4 q1;   // conic_c', opacity, list position (bits), Gaussian index (bits)
-    float4 q2;   // red, green, blue, depth
+    float4 q1;   // conic_c', opacity, red, green
+    float4 q2;   // blue, depth, unused, Gaussian index (bits)
 };
 
-// A tiles: element (entry i, column c) with c = 16 u + 4 k + m - the pixel that matrix step t = 4 u + m contracts at
-// K index k - lives at dword (c >> 2) * 68 + (i + 1 - ((c >> 2) & 1)) * 4 + (c & 3): the 16 entries of one pixel block
-// are 16 bytes apart, so the operand read of lane (i, k) - one 16-byte read per u - meets the other lanes of its
-// 16-lane service group on sixteen different 4-bank groups (the one-slot skew between even and odd pixel blocks lines
-// the two k values of a group up), and the phase-1 stores (64 pixels of one entry) are at most 2-way conflicted (free).
-struct PlLds {
-    PlEnt ent[PL_CAP];
-    float wt[16 * PL_ROW];      // blend weights; reused as the 16 x 17 transpose tile of the geometric sums in the flush
-    float st[16 * PL_ROW];      // s = op G dL/dalpha
+// A tiles: element (row i, column c) of a quadrant's tile, with c = 16 u + 4 k + m - the pixel that matrix step
+// t = 4 u + m contracts at K index k - lives at dword (c >> 2) * 68 + (i + 1 - ((c >> 2) & 1)) * 4 + (c & 3): the 16 rows
+// of one pixel block are 16 bytes apart, so the operand read of lane (i, k) - one 16-byte read per u - meets the other
+// lanes of its 16-lane service group on sixteen different 4-bank groups (the one-slot skew between even and odd pixel
+// blocks lines the two k values of a group up), and the phase-1 stores (64 pixels of one row) are at most 2-way conflicted.
+struct PlShared {
+    float wt[4][PL_TILE];       // per quadrant: blend weights
+    float st[4][PL_TILE];       //               s = op G dL/dalpha
+    PlRec rec[2][PL_WIN];       // double-buffered: the last flush of window w reads it while window w - 1 is stored
+    float ftile[PL_CAP * PL_FS];   // the chunk's sums, entry-major, as they leave for global memory
+    uint32_t wave_max[4];
+    uint32_t touched[2];        // per chunk parity: rows that blended somewhere in the tile
+    uint32_t pad[10];
 };
+static_assert(sizeof(PlShared) * 3 <= 160 * 1024, "three workgroups per CU");
+static_assert(PL_STAGE_PLANES * PL_SP * 4 <= sizeof(PlShared), "staging image fits the aliased area");
 
-template <int NCB, bool GEO>
+// GEO = true:  first channel window (up to 32 channels) + the ten geometric sums; column blocks of the waves: feature
+//              channels 0-15, 16-31, colour/depth, moments.
+// GEO = false: a later channel window of up to 64 channels: sixteen per wave.
+template <bool GEO>
 __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    PlLds& L = *reinterpret_cast<PlLds*>(smem);
-    const int lane = threadIdx.x;
-    PL_PHASE_BEGIN();     // [0] staging  [1] walk  [2] phase 1  [3] phase 2  [4] flush  [5] chunks  [6] entries
+    PlShared& L = *reinterpret_cast<PlShared*>(smem);
+    float* const stage = reinterpret_cast<float*>(smem);      // staging image: aliases everything, used before the walk only
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: quadrant in phase 1, column block in phase 2
+    PL_PHASE_BEGIN();     // [0] staging  [1] window + barriers  [2] phase 1  [3] phase 2  [4] flush  [5] chunks  [6] entries
 
-    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t ntiles = gridDim.x / 4;
-    const uint32_t tile = a.part_major ? wg % ntiles : wg / 4;
-    const int part = a.part_major ? wg / ntiles : wg % 4;
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 rg = a.ranges[tile];
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
     const size_t HW = (size_t)a.W * a.H;
-    const int px0 = tx * TILE + (part & 1) * 8, py0 = ty * TILE + (part >> 1) * 8;
-
-    // ---- per-pixel state (lane = pixel (lane & 7, lane >> 3) of the quadrant) ---------------------------------
+    const int tx0 = tx * TILE, ty0 = ty * TILE;
+    const int qx = (q & 1) * 8, qy = (q >> 1) * 8;
     const int lx = lane & 7, ly = lane >> 3;
-    const int x = px0 + lx, y = py0 + ly;
-    const bool inside = x < a.W && y < a.H;
-    const size_t pid = inside ? (size_t)y * a.W + x : 0;      // outside the image: a valid address, masked below
-    uint32_t last = a.n_contrib[pid];
-    if (!inside) last = 0;
-    const uint32_t max_last = wave_max_u32(last);
-    auto load_ids = [&](int k0w) -> uint32_t {
-        const uint32_t pos = (uint32_t)(k0w + 63 - lane);
-        return (k0w >= 0 && pos < max_last) ? a.point_list[r_lo + pos] : 0u;
-    };
-    const int k_top = (int)((max_last + 63) / 64) * 64 - 64;
-    uint32_t ngid = load_ids(k_top), fgid = load_ids(k_top - 64);
-
-    float T = a.final_T[pid];
-    float dR = a.dL_dpix[pid], dG = a.dL_dpix[HW + pid], dB = a.dL_dpix[2 * HW + pid], dD = a.dL_ddepth[pid];
-    if (!inside) { T = 0.f; dR = dG = dB = dD = 0.f; }
-    float S = T * (a.bg[0] * dR + a.bg[1] * dG + a.bg[2] * dB);
-    const float pxf = (float)x, pyf = (float)y;
-
-    // ---- matrix-pipe B operands, resident for the life of the wave (lane = (column col, K index kk)) -------------
-    // step t contracts the four pixels (4 (t & 1) + kk, t >> 1), kk = 0..3: 16-byte runs of the planar gradient images
     const int col = lane & 15, kk = lane >> 4;
-    float Bf[NCB > 0 ? NCB : 1][16];
-    float Bgw[GEO ? 16 : 1], Bgs[GEO ? 16 : 1];
+
+    // ---- staging: every plane of the tile with full-row requests -> LDS [plane][16 rows][16 px]; then the per-pixel state
+    // (lane = pixel of quadrant q) and the wave's B operand (lane = (column col, K index kk)) are read out of it.
+    // B operand, resident for the life of the wave: Bop[qd][t] = column `col` of this wave's block at the pixel that step t
+    // of quadrant qd contracts at K index kk, i.e. pixel (4 (t & 1) + kk, t >> 1) of the quadrant.
+    float Bop[4][16];
+    uint32_t last = 0;
+    float T = 0.f, dR = 0.f, dG = 0.f, dB = 0.f, dD = 0.f;
     {
-        const int bx0 = px0 + kk;
-        const float* gsrc = col < 3 ? a.dL_dpix + (size_t)col * HW : a.dL_ddepth;
+        const bool vec = (a.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.dL_dfeat) | reinterpret_cast<uintptr_t>(a.dL_dpix) |
+                                              reinterpret_cast<uintptr_t>(a.dL_ddepth) | reinterpret_cast<uintptr_t>(a.final_T) |
+                                              reinterpret_cast<uintptr_t>(a.n_contrib)) & 15) == 0;
+        const int rounds = (GEO || a.nc <= 32) ? 1 : 2;
+        for (int rd = 0; rd < rounds; rd++) {
+            // planes of this round: 32 feature planes (channels 32 rd ..), then - first round only - the pixel planes:
+            // GEO: dL/dR, dL/dG, dL/dB, dL/ddepth, final_T, n_contrib;  otherwise: final_T, n_contrib
+            const int npix = rd == 0 ? (GEO ? 6 : 2) : 0;
+            if (rd > 0) __syncthreads();
+            // all requests of a thread first, then the LDS stores: one memory latency per round instead of one per plane
+            constexpr int NIT = (38 * 64 + 255) / 256;
+            float4 sv[NIT];
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int bx = bx0 + 4 * (t & 1), by = py0 + (t >> 1);
-            const bool in = bx < a.W && by < a.H;
-            const size_t pb = in ? (size_t)by * a.W + bx : 0;
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) {
-                const int ch = 16 * cb + col;
-                const float v = a.dL_dfeat[(size_t)(a.c0 + min(ch, a.nc - 1)) * HW + pb];
-                Bf[cb][t] = (in && ch < a.nc) ? v : 0.f;
+            for (int it = 0; it < NIT; it++) {
+                const int f = it * 256 + tid;
+                const int pl = f >> 6, row = (f >> 2) & 15, xq = f & 3;
+                const int y = ty0 + row, x = tx0 + 4 * xq;
+                const int ch = 32 * rd + pl;
+                const float* src;
+                bool on = y < a.H && f < (32 + npix) * 64;
+                if (pl < 32) {
+                    on = on && ch < a.nc;
+                    src = a.dL_dfeat + (size_t)(a.c0 + (on ? ch : 0)) * HW;
+                } else {
+                    const int pp = pl - 32 + (GEO ? 0 : 4);
+                    src = pp < 3 ? a.dL_dpix + (size_t)pp * HW : pp == 3 ? a.dL_ddepth : pp == 4 ? a.final_T : reinterpret_cast<const float*>(a.n_contrib);
+                }
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on && !PL_DEV_SKIP(64)) {
+                    const float* p = src + (size_t)y * a.W + x;
+                    if (vec) {
+                        if (x < a.W) v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (x + 0 < a.W) v.x = p[0];
+                        if (x + 1 < a.W) v.y = p[1];
+                        if (x + 2 < a.W) v.z = p[2];
+                        if (x + 3 < a.W) v.w = p[3];
+                    }
+                }
+                sv[it] = v;
             }
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int f = it * 256 + tid;
+                const int pl = f >> 6, row = (f >> 2) & 15, xq = f & 3;
+                if (f < (32 + npix) * 64) *reinterpret_cast<float4*>(&stage[pl * PL_SP + row * 16 + 4 * xq]) = sv[it];
+            }
+            PL_STAGE_MARK(0);
+            __syncthreads();
+            PL_STAGE_MARK(1);
+            if (rd == 0) {
+                const int sp = (qy + ly) * 16 + qx + lx;
+                constexpr int pb = 32 - (GEO ? 0 : 4);        // plane of dL/dR (GEO); final_T at pb + 4, n_contrib at pb + 5
+                last = __float_as_uint(stage[(pb + 5) * PL_SP + sp]);     // 0 outside the image (zero-filled)
+                T = stage[(pb + 4) * PL_SP + sp];
+                if constexpr (GEO) {
+                    dR = stage[(pb + 0) * PL_SP + sp]; dG = stage[(pb + 1) * PL_SP + sp]; dB = stage[(pb + 2) * PL_SP + sp];
+                    dD = stage[(pb + 3) * PL_SP + sp];
+                }
+            }
+            // which plane is this wave's column `col`?  (-1: a zero column)
+            int plane = -1;
+            bool mine = false;          // does this round hold this wave's block
             if constexpr (GEO) {
-                float v = 0.f;
-                if (col < 4) v = gsrc[pb];
-                Bgw[t] = (in && col < 4) ? v : 0.f;
-                // monomials of the pixel offset from the block centre, columns 4..9: 1, u, v, u^2, uv, v^2
-                const float uu = (float)(4 * (t & 1) + kk) - 3.5f, vv = (float)(t >> 1) - 3.5f;
-                Bgs[t] = col == 4 ? 1.f : col == 5 ? uu : col == 6 ? vv : col == 7 ? uu * uu : col == 8 ? uu * vv : col == 9 ? vv * vv : 0.f;
+                mine = true;
+                if (q < 2) plane = 16 * q + col;
+                else if (q == 2) plane = col < 4 ? 32 + col : -1;
+            } else {
+                mine = (q >> 1) == rd;
+                plane = 16 * (q & 1) + col;
+            }
+            if (GEO && q == 3) {
+                // the moment wave: monomials of the pixel offset from the QUADRANT centre (the moments of each quadrant are kept
+                // apart and re-centred on the splat mean one by one: |u|, |v| <= 3.5), columns 0..5: 1, u, v, u^2, uv, v^2 - the
+                // same operand for the four quadrants, evaluated as one polynomial with per-lane one-hot coefficients
+                const float k0c = col == 0 ? 1.f : 0.f, k1c = col == 1 ? 1.f : 0.f, k2c = col == 2 ? 1.f : 0.f;
+                const float k3c = col == 3 ? 1.f : 0.f, k4c = col == 4 ? 1.f : 0.f, k5c = col == 5 ? 1.f : 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const float uu = (float)(4 * (t & 1) + kk) - 3.5f, vv = (float)(t >> 1) - 3.5f;
+                    const float v = fmaf(fmaf(k3c, uu, fmaf(k4c, vv, k1c)), uu, fmaf(fmaf(k5c, vv, k2c), vv, k0c));
+#pragma unroll
+                    for (int qd = 0; qd < 4; qd++) Bop[qd][t] = v;
+                }
+            } else if (mine) {
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++)
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const int px = (qd & 1) * 8 + 4 * (t & 1) + kk, py = (qd >> 1) * 8 + (t >> 1);
+                        Bop[qd][t] = plane >= 0 ? stage[plane * PL_SP + py * 16 + px] : 0.f;
+                    }
             }
         }
     }
-    // LDS offsets (dwords): phase-1 store column of this lane's pixel, operand read base of this lane's (entry, K index)
+    PL_STAGE_MARK(2);
+    float S = T * (a.bg[0] * dR + a.bg[1] * dG + a.bg[2] * dB);
+    const float pxf = (float)(tx0 + qx + lx), pyf = (float)(ty0 + qy + ly);
+    const uint32_t my_max = wave_max_u32(last);
+    // does this wave hold a column block at all?
+    const bool active = (GEO && q >= 2) || 16 * q < a.nc;
+    const bool use_s = GEO && q == 3;
+    __syncthreads();                                // every read of the staging image is done: the area is re-used from here on
+    PL_STAGE_MARK(3);
+    if (lane == 0) L.wave_max[q] = my_max;
+    if (tid < 2) L.touched[tid] = 0;
+    __syncthreads();
+    PL_STAGE_MARK(4);
+    const uint32_t tile_max = max(max(L.wave_max[0], L.wave_max[1]), max(L.wave_max[2], L.wave_max[3]));
+    const int n_win = PL_DEV_SKIP(32) ? 0 : (int)((tile_max + PL_WIN - 1) / PL_WIN);
+
+    // LDS offsets (dwords): phase-1 store column of this lane's pixel, operand read base of this lane's (row, K index)
     const int ccol = 16 * (ly >> 1) + 4 * (lx & 3) + 2 * (ly & 1) + (lx >> 2);
     const int wofs = (ccol >> 2) * PL_ROW + (1 - ((ccol >> 2) & 1)) * 4 + (ccol & 3);
     const int rofs = kk * PL_ROW + (col + 1 - (kk & 1)) * 4;
-    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
-    const float cx0 = (float)px0 + 3.5f, cy0 = (float)py0 + 3.5f;
+    float* const my_wt = &L.wt[q][wofs];
+    constexpr int ST_OFS = 4 * PL_TILE;             // st[q] - wt[q], dwords
+    const float wx0 = (float)(tx0 + qx), wx1 = wx0 + 7.f, wy0 = (float)(ty0 + qy), wy1 = wy0 + 7.f;
+    if (!PL_DEV_SKIP(32)) PL_PHASE_END(0);
 
-    // ---- one chunk of n <= 16 staged entries (L.ent[0..n), back to front) -------------------------------------------
-    auto process = [&](const int n, const uint32_t pos_min) {
+    // ---- record loader (waves 0..2: one 16-byte third of every record; lane = entry, entry 0 = farthest back) -------
+    auto win_pos = [&](int w) -> uint32_t { return (uint32_t)(w * PL_WIN + PL_WIN - 1 - lane); };
+    auto load_id = [&](int w) -> uint32_t {
+        const uint32_t pos = win_pos(w);
+        return (w >= 0 && q < 3 && pos < tile_max) ? a.point_list[r_lo + pos] : 0u;
+    };
+    auto load_part = [&](int w, uint32_t gid) -> float4 {
+        const uint32_t pos = win_pos(w);
+        if (w >= 0 && q < 3 && pos < tile_max) return reinterpret_cast<const float4*>(a.rec + gid)[q];
+        return make_float4(0.f, 0.f, 0.f, 0.f);       // opacity 0: never a hit
+    };
+    uint32_t gid_cur = load_id(n_win - 1), gid_nxt = load_id(n_win - 2);
+    float4 part_cur = load_part(n_win - 1, gid_cur);
+    int parity = 0;
+
+    for (int w = n_win - 1; w >= 0; w--) {
+        // records of window w -> LDS; w - 1 / w - 2 in flight
+        PlRec* const rec = L.rec[w & 1];
+        if (q < 3) {
+            float4 v = part_cur;
+            if (q == 0) { v.z *= CONIC_SCALE_AC; v.w *= CONIC_SCALE_B; }
+            else if (q == 1) { v.x *= CONIC_SCALE_AC; }
+            else { v.w = __uint_as_float(gid_cur); }
+            reinterpret_cast<float4*>(&rec[lane])[q] = v;
+        }
+        gid_cur = gid_nxt;
+        part_cur = load_part(w - 1, gid_cur);
+        gid_nxt = load_id(w - 2);
+        __syncthreads();
         PL_PHASE_END(1);
-        PL_COUNT(5, 1); PL_COUNT(6, n);
-        __builtin_amdgcn_wave_barrier();
-        if (__ballot(last > pos_min) == 0) return;        // every pixel of the wave ended behind this chunk
-        if (PL_DEV_SKIP(2)) return;
-        // phase 1
-        uint32_t tm = 0;      // entries that blended somewhere in the wave
-#pragma unroll 2
-        for (int i = 0; i < n; i++) {
-            const float4 e0 = L.ent[i].q0, e1 = L.ent[i].q1;
-            const float dx = e0.x - pxf, dy = e0.y - pyf;
-            const float power2 = splat_power2(dx, dy, e0.z, e0.w, e1.x);
-            const float v = e1.y * __builtin_amdgcn_exp2f(power2);                  // op G, not yet clamped
-            const bool ok = (int)(__float_as_uint(e1.z) < last) & (int)!(power2 > 0.0f) & (int)!(v < ALPHA_MIN);
-            const float au = ok ? v : 0.f;          // exp2 may be inf where power > 0: selected away, never multiplied
-            const float al = fminf(ALPHA_MAX, au);
-            const float f = __builtin_amdgcn_rcpf(1.f - al);                        // exactly 1 for skipped pairs
-            const float Tb = T * f;                 // transmittance in front of this splat
-            const float w = al * Tb;
-            L.wt[wofs + 4 * i] = w;
-            if constexpr (GEO) {
-                const float4 e2 = L.ent[i].q2;
-                const float q = fmaf(e2.x, dR, fmaf(e2.y, dG, fmaf(e2.z, dB, e2.w * dD)));
-                const float dL_dalpha = fmaf(Tb, q, -(S * f));
-                S = fmaf(w, q, S);
-                L.st[wofs + 4 * i] = au * dL_dalpha;
-            }
-            T = Tb;
-            if (__ballot(ok)) tm |= 1u << i;
-        }
-        __builtin_amdgcn_wave_barrier();
-        PL_PHASE_END(2);
-        if (tm == 0) return;
 
-        // phase 2: all sums of the chunk on the matrix pipe
-        f32x4 accf[NCB > 0 ? NCB : 1], accw, accs;
+        const uint32_t k0 = (uint32_t)w * PL_WIN;
+        // entries of the window that exist: positions beyond the end of the list sit at the BACK (low entries) of the top window
+        const int n_have = (int)min((uint32_t)PL_WIN, tile_max - k0);
+        const int j_first = (PL_WIN - n_have) / PL_CAP;
+
+        for (int j = j_first; j < PL_WIN / PL_CAP; j++, parity ^= 1) {
+            PL_COUNT(5, 1);
+            // ---- phase 1: rows of the chunk = entries 16 j .. 16 j + 15 of the window.  Every entry is evaluated (an entry that
+            // misses the quadrant yields w = s = 0 at each of its pixels by itself): one straight-line block per chunk, records
+            // of the next pair in flight while a pair is computed.  A quadrant whose pixels all ended behind the chunk skips it.
+            const uint32_t pos_hi = k0 + (uint32_t)(PL_WIN - 1 - 16 * j);      // list position of row 0
+            uint32_t tm = 0;      // rows that blended somewhere in this quadrant; bit 16 + q: the quadrant's tiles are live
+            if (pos_hi - 15 < my_max && !PL_DEV_SKIP(2)) {
+                const PlRec* rc = &rec[16 * j];
+                float4 n0[2], n1[2];
+                float2 n2[2];
 #pragma unroll
-        for (int cb = 0; cb < (NCB > 0 ? NCB : 1); cb++) accf[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        accw = accs = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < 2; k++) {
+                    n0[k] = rc[k].q0; n1[k] = rc[k].q1;
+                    if constexpr (GEO) n2[k] = *reinterpret_cast<const float2*>(&rc[k].q2);
+                }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const float4 wa = *reinterpret_cast<const float4*>(&L.wt[rofs + u * 4 * PL_ROW]);
-            float4 sa = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (GEO) sa = *reinterpret_cast<const float4*>(&L.st[rofs + u * 4 * PL_ROW]);
-            const float wv[4] = {wa.x, wa.y, wa.z, wa.w}, sv[4] = {sa.x, sa.y, sa.z, sa.w};
-            if (PL_DEV_SKIP(4)) { accw[0] += wv[0] + wv[1] + wv[2] + wv[3] + sv[0] + sv[1] + sv[2] + sv[3]; continue; }
+                for (int p = 0; p < 8; p++) {
+                    float4 e0[2], e1[2];
+                    float2 e2[2];
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int t = 4 * u + m;
+                    for (int k = 0; k < 2; k++) { e0[k] = n0[k]; e1[k] = n1[k]; e2[k] = n2[k]; }
+                    if (p < 7) {
 #pragma unroll
-                for (int cb = 0; cb < NCB; cb++) {
-                    accf[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[m], Bf[cb][t], accf[cb], 0, 0, 0);
-                    if constexpr (GEO) {
-                        if (cb == 0) accw = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[m], Bgw[t], accw, 0, 0, 0);
-                        if (cb == NCB - 1) accs = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[m], Bgs[t], accs, 0, 0, 0);
+                        for (int k = 0; k < 2; k++) {
+                            n0[k] = rc[2 * p + 2 + k].q0; n1[k] = rc[2 * p + 2 + k].q1;
+                            if constexpr (GEO) n2[k] = *reinterpret_cast<const float2*>(&rc[2 * p + 2 + k].q2);
+                        }
+                    }
+                    PL_COUNT(6, 2);
+                    float au[2], al[2], f[2], qd[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const float dx = e0[k].x - pxf, dy = e0[k].y - pyf;
+                        const float power2 = splat_power2(dx, dy, e0[k].z, e0[k].w, e1[k].x);
+                        const float v = e1[k].y * __builtin_amdgcn_exp2f(power2);                  // op G, not yet clamped
+                        const bool ok = (int)(pos_hi - (uint32_t)(2 * p + k) < last) & (int)!(power2 > 0.0f) & (int)!(v < ALPHA_MIN);
+                        if (__ballot(ok)) tm |= 1u << (2 * p + k);
+                        au[k] = ok ? v : 0.f;          // exp2 may be inf where power > 0: selected away, never multiplied
+                        al[k] = fminf(ALPHA_MAX, au[k]);
+                        f[k] = __builtin_amdgcn_rcpf(1.f - al[k]);                                 // exactly 1 for skipped pairs
+                        if constexpr (GEO) qd[k] = fmaf(e1[k].z, dR, fmaf(e1[k].w, dG, fmaf(e2[k].x, dB, e2[k].y * dD)));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const float Tb = T * f[k];              // transmittance in front of this splat
+                        const float wv = al[k] * Tb;
+                        my_wt[4 * (2 * p + k)] = wv;
+                        if constexpr (GEO) {
+                            const float dL_dalpha = fmaf(Tb, qd[k], -(S * f[k]));
+                            S = fmaf(wv, qd[k], S);
+                            my_wt[4 * (2 * p + k) + ST_OFS] = au[k] * dL_dalpha;
+                        }
+                        T = Tb;
                     }
                 }
-                if constexpr (GEO && NCB == 0) {
-                    accw = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[m], Bgw[t], accw, 0, 0, 0);
-                    accs = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[m], Bgs[t], accs, 0, 0, 0);
-                }
+                tm |= 1u << (16 + q);
             }
-        }
+            if (tm && lane == 0) atomicOr(&L.touched[parity], tm);
+            PL_PHASE_END(2);
+            __syncthreads();                                                  // B_a: the A tiles of the chunk are complete
+            PL_PHASE_END(1);
 
-        PL_PHASE_END(3);
-        // flush.  D[i][j]: lane holds column j = lane & 15, register r holds row (entry) i = 4 (lane >> 4) + r.
-        uint32_t gidr[4];
+            // ---- phase 2: this wave's sixteen columns of every sum of the chunk
+            const uint32_t tt = L.touched[parity];
+            if (active && (tt & 0xFFFFu) != 0) {
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                const float* abase = (use_s ? &L.st[0][0] : &L.wt[0][0]) + rofs;
+                const int fs_row0 = (4 * kk) * PL_FS;
 #pragma unroll
-        for (int r = 0; r < 4; r++) gidr[r] = __float_as_uint(L.ent[4 * kk + r].q1.w);
-        if (PL_DEV_SKIP(1)) tm = 0;
-        if constexpr (NCB > 0) if (!PL_DEV_SKIP(32)) {
+                for (int qd = 0; qd < 4; qd++) {
+                    if ((tt >> (16 + qd)) & 1u) {              // the quadrant's tiles were written for this chunk
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (!((tm >> (4 * kk + r)) & 1u)) continue;
+                        for (int u = 0; u < 4; u++) {
+                            const float4 av = *reinterpret_cast<const float4*>(abase + qd * PL_TILE + u * 4 * PL_ROW);
+                            if (PL_DEV_SKIP(4)) { acc0[0] += av.x + av.y + av.z + av.w; continue; }
+                            // two accumulators alternate: no back-to-back dependent matrix instructions
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Bop[qd][4 * u + 0], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Bop[qd][4 * u + 1], acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Bop[qd][4 * u + 2], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Bop[qd][4 * u + 3], acc1, 0, 0, 0);
+                        }
+                    }
+                    if (use_s) {
+                        // the moment wave keeps the four quadrants apart (each is re-centred on the splat mean by itself)
+                        if (col < 6) {
 #pragma unroll
-                for (int cb = 0; cb < NCB; cb++) {
-                    const int ch = 16 * cb + col;
-                    if (ch < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gidr[r] * a.C + a.c0 + ch, accf[cb][r]);
+                            for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + 36 + 6 * qd + col] = acc0[r] + acc1[r];
+                        }
+                        acc0 = acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
-            }
-        }
-        if constexpr (GEO) {
-            __builtin_amdgcn_wave_barrier();       // the operand reads of L.wt are done: reuse it as the 16 x 17 transpose tile
+                // D[i][j]: lane holds column j = lane & 15, register r holds row (entry) i = 4 (lane >> 4) + r.
+                // Flush-tile slots: features at their channel; colour / depth sums at 32..35, the 4 x 6 moments at 36..59.
+                if (!use_s) {
+                    const int slot = (GEO && q == 2) ? 32 + col : 16 * q + col;
+                    if (!(GEO && q == 2) || col < 4) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) L.wt[(4 * kk + r) * 17 + col] = accw[r] + accs[r];      // disjoint columns
-            __builtin_amdgcn_wave_barrier();
-            float o[10];
-#pragma unroll
-            for (int k = 0; k < 10; k++) o[k] = 0.f;
-            if (lane < PL_CAP) {
-                const float* g = &L.wt[lane * 17];
-                const float4 e0 = L.ent[lane].q0, e1 = L.ent[lane].q1;
-                const float ax = e0.x - cx0, ay = e0.y - cy0;       // mean relative to the block centre: dx = ax - u
-                const float M0 = g[4], M1x = g[5], M1y = g[6], M2xx = g[7], M2xy = g[8], M2yy = g[9];
-                const float m1 = fmaf(ax, M0, -M1x), m2 = fmaf(ay, M0, -M1y);                  // sum s dx, sum s dy
-                const float sxx = fmaf(ax, fmaf(ax, M0, -2.f * M1x), M2xx);                    // sum s dx^2
-                const float sxy = fmaf(ax, fmaf(ay, M0, -M1y), fmaf(-ay, M1x, M2xy));          // sum s dx dy
-                const float syy = fmaf(ay, fmaf(ay, M0, -2.f * M1y), M2yy);                    // sum s dy^2
-                const float ca = e0.z * CONIC_UNSCALE_AC, cb = e0.w * CONIC_UNSCALE_B, cc = e1.x * CONIC_UNSCALE_AC;
-                // dG/ddelx = -G (a dx + b dy),  dG/da = -G dx^2 / 2, ...;  dL/dopacity = sum G dL/dalpha = M0 / op
-                o[0] = -ddelx_dx * fmaf(ca, m1, cb * m2);
-                o[1] = -ddely_dy * fmaf(cc, m2, cb * m1);
-                o[2] = -0.5f * sxx; o[3] = -0.5f * sxy; o[4] = -0.5f * syy;
-                o[5] = M0 * __builtin_amdgcn_rcpf(e1.y);     // only used where the entry blended somewhere => op > 0
-                o[6] = g[0]; o[7] = g[1]; o[8] = g[2]; o[9] = g[3];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < PL_CAP) {
-#pragma unroll
-                for (int k = 0; k < 10; k++) L.wt[lane * 17 + k] = o[k];
-            }
-            __builtin_amdgcn_wave_barrier();
-            // four entries per atomic instruction, ten consecutive floats of the gradient record each
-            if (a.write_base && !PL_DEV_SKIP(16)) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int e = 4 * r + kk;
-                    if (col < 10 && ((tm >> e) & 1u)) {
-                        const uint32_t gg = __float_as_uint(L.ent[e].q1.w);
-                        unsafeAtomicAdd(a.grec + (size_t)gg * GREC + col, L.wt[e * 17 + col]);
+                        for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + slot] = acc0[r] + acc1[r];
                     }
                 }
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-        PL_PHASE_END(4);
-    };
+            PL_PHASE_END(3);
+            __syncthreads();                                                  // B_b: tiles read, flush tile written
+            PL_PHASE_END(1);
 
-    // ---- walk the list back to front in windows of 64 positions; entries whose 1/255 footprint misses this wave's pixel
-    // block are dropped (rect_hit, exact-safe), the survivors are appended to the staged chunk ----------------------------
-    const float wx0 = (float)px0, wx1 = (float)(px0 + 7), wy0 = (float)py0, wy1 = (float)(py0 + 7);
-    int count = 0;
-    uint32_t cur_min = 0;
-    PL_PHASE_END(0);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    // three-stage software pipeline over the windows: while window k0 is tested / appended / processed, the splat records of
-    // window k0 - 64 and the list ids of window k0 - 128 are in flight
-    auto load_recs = [&](int k0w, uint32_t gid, float (&f)[10], bool& have) {
-        const uint32_t pos = (uint32_t)(k0w + 63 - lane);
-        have = k0w >= 0 && pos < max_last;
+            // ---- flush: wave q owns rows 4 q .. 4 q + 3 of the chunk
+            if ((tt & 0xFFFFu) != 0 && !PL_DEV_SKIP(16)) {
+                const uint32_t mine4 = (tt >> (4 * q)) & 0xFu;
+                if constexpr (GEO) {
+                    if (lane < 4 && ((mine4 >> lane) & 1u)) {
+                        float* g = &L.ftile[(4 * q + lane) * PL_FS + 32];
+                        const PlRec& rc = rec[16 * j + 4 * q + lane];
+                        const float4 r0 = rc.q0, r1 = rc.q1;
+                        const float c0 = g[0], c1 = g[1], c2 = g[2], c3 = g[3];
+                        float M0 = 0.f, m1 = 0.f, m2 = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f;
 #pragma unroll
-        for (int k = 0; k < 10; k++) f[k] = 0.f;
-        if (have) {
-            const SplatRec* rp = a.rec + gid;
-            const float4 q0 = rp->q0, q1 = rp->q1, q2 = rp->q2;
-            f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w; f[4] = q1.x; f[5] = q1.y;
-            f[6] = q1.z; f[7] = q1.w; f[8] = q2.x; f[9] = q2.y;
-        }
-    };
-    float nf[10];
-    bool nhave;
-    load_recs(k_top, ngid, nf, nhave);
-    for (int k0 = k_top;; k0 -= 64) {
-        const bool drain = k0 < 0;                      // one extra trip flushes the last, partially filled chunk
-        const uint32_t pos = (uint32_t)(k0 + 63 - lane);    // lane 0 = farthest back within the window
-        float f[10];
-#pragma unroll
-        for (int k = 0; k < 10; k++) f[k] = nf[k];
-        const uint32_t gid = ngid;
-        const bool have = nhave && !drain;
-        if (!drain) {
-            ngid = fgid;
-            load_recs(k0 - 64, ngid, nf, nhave);
-            fgid = load_ids(k0 - 128);
-        }
-        const bool hit = have && (a.no_wave_cull || rect_hit(f[0], f[1], f[2], f[3], f[4], f[5], wx0, wx1, wy0, wy1));
-        const unsigned long long hmask = __ballot(hit);
-        const int c2 = __popcll(hmask);
-        const int rank = __popcll(hmask & lt_mask);
-        int first = 0;
-        while (true) {
-            if (count == PL_CAP || (drain && count > 0)) {
-                process(count, cur_min);
-                count = 0;
+                        for (int qd = 0; qd < 4; qd++) {
+                            // mean relative to the quadrant centre: dx = ax - u
+                            const float ax = r0.x - (float)(tx0 + (qd & 1) * 8) - 3.5f, ay = r0.y - (float)(ty0 + (qd >> 1) * 8) - 3.5f;
+                            const float* mq = g + 4 + 6 * qd;
+                            const float N0 = mq[0], N1x = mq[1], N1y = mq[2], N2xx = mq[3], N2xy = mq[4], N2yy = mq[5];
+                            M0 += N0;
+                            m1 += fmaf(ax, N0, -N1x); m2 += fmaf(ay, N0, -N1y);                      // sum s dx, sum s dy
+                            sxx += fmaf(ax, fmaf(ax, N0, -2.f * N1x), N2xx);                         // sum s dx^2
+                            sxy += fmaf(ax, fmaf(ay, N0, -N1y), fmaf(-ay, N1x, N2xy));               // sum s dx dy
+                            syy += fmaf(ay, fmaf(ay, N0, -2.f * N1y), N2yy);                         // sum s dy^2
+                        }
+                        const float ca = r0.z * CONIC_UNSCALE_AC, cb = r0.w * CONIC_UNSCALE_B, cc = r1.x * CONIC_UNSCALE_AC;
+                        // dG/ddelx = -G (a dx + b dy),  dG/da = -G dx^2 / 2, ...;  dL/dopacity = sum G dL/dalpha = M0 / op
+                        g[0] = -(0.5f * a.W) * fmaf(ca, m1, cb * m2);
+                        g[1] = -(0.5f * a.H) * fmaf(cc, m2, cb * m1);
+                        g[2] = -0.5f * sxx; g[3] = -0.5f * sxy; g[4] = -0.5f * syy;
+                        g[5] = M0 * __builtin_amdgcn_rcpf(r1.y);
+                        g[6] = c0; g[7] = c1; g[8] = c2; g[9] = c3;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                uint32_t m = mine4;
+                while (m) {
+                    const int rr = 4 * q + __builtin_ctz(m);
+                    m &= m - 1;
+                    const uint32_t gg = __float_as_uint(rec[16 * j + rr].q2.w);
+                    if (!PL_DEV_SKIP(1)) {
+                        if constexpr (GEO) {
+                            const float v = L.ftile[rr * PL_FS + lane];
+                            if (lane < 32) {
+                                if (lane < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + lane, v);
+                            } else if (lane < 42) {
+                                unsafeAtomicAdd(a.grec + (size_t)gg * GREC + (lane - 32), v);
+                            }
+                        } else {
+                            const float v = L.ftile[rr * PL_FS + lane];
+                            if (lane < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + lane, v);
+                        }
+                    }
+                }
             }
-            if (first >= c2) break;
-            const int n = min(c2 - first, PL_CAP - count);
-            if (hit && rank >= first && rank < first + n) {
-                PlEnt en;
-                en.q0 = make_float4(f[0], f[1], f[2] * CONIC_SCALE_AC, f[3] * CONIC_SCALE_B);   // see splat_power2
-                en.q1 = make_float4(f[4] * CONIC_SCALE_AC, f[5], __uint_as_float(pos), __uint_as_float(gid));
-                en.q2 = make_float4(f[6], f[7], f[8], f[9]);
-                L.ent[count + rank - first] = en;
-            }
-            count += n;
-            first += n;
-            cur_min = (uint32_t)k0;      // every survivor of this window sits at a position >= k0
+            if (tt != 0 && q == 0 && lane == 0) L.touched[parity] = 0;     // next used two chunks from now, behind two barriers
+            PL_PHASE_END(4);
         }
-        if (drain) break;
     }
-    PL_PHASE_END(1);
 #ifdef F3DGS_DEV
     if ((a.dev & 8) && lane == 0) {
         cyc_[7] = 1;
-        for (int k = 0; k < 8; k++) a.dev_cycles[(size_t)blockIdx.x * 8 + k] = cyc_[k];     // private slots: summed on the host
+        for (int k = 0; k < 8; k++) a.dev_cycles[((size_t)blockIdx.x * 4 + q) * 8 + k] = cyc_[k];     // private slots: summed on the host
     }
 #endif
 }
 
-template <int NCB, bool GEO>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) render_backward_pl_kernel(BwdArgs a) {
-    render_backward_pl_body<NCB, GEO>(a);
+template <bool GEO>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) render_backward_pl_kernel(BwdArgs a) {
+    render_backward_pl_body<GEO>(a);
 }
 
-template <int NCB, bool GEO>
+template <bool GEO>
 void launch_pl(const BwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((render_backward_pl_kernel<NCB, GEO>), dim3(a.gx * a.gy * 4), dim3(64), sizeof(PlLds), s, a);
+#ifdef F3DGS_DEV
+    if (a.dev & 8) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_backward_pl_kernel<GEO>, 256, sizeof(PlShared));
+        fprintf(stderr, "[f3dgs dev] pixel-lane backward: %d workgroups per CU by the occupancy query, %zu bytes of LDS\n", nb, sizeof(PlShared));
+    }
+#endif
+    hipLaunchKernelGGL((render_backward_pl_kernel<GEO>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a);
 }
 
 }  // namespace
 
 // Channel windows: the first carries the geometric sums and up to 32 channels, later ones up to 64 channels.
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s) {
-    if (C == 0) {
-        a.c0 = 0; a.nc = 0; a.write_base = 1;
-        launch_pl<0, true>(a, s);
-        return;
-    }
-    for (int c0 = 0; c0 < C;) {
-        a.c0 = c0; a.write_base = (c0 == 0);
-        if (c0 == 0) {
-            a.nc = min(32, C);
-            if (a.nc <= 16) launch_pl<1, true>(a, s); else launch_pl<2, true>(a, s);
-        } else {
-            a.nc = min(64, C - c0);
-            if (a.nc <= 16) launch_pl<1, false>(a, s);
-            else if (a.nc <= 32) launch_pl<2, false>(a, s);
-            else launch_pl<4, false>(a, s);
-        }
-        c0 += a.nc;
+    a.c0 = 0; a.nc = min(32, C); a.write_base = 1;
+    launch_pl<true>(a, s);
+    for (int c0 = 32; c0 < C; c0 += 64) {
+        a.c0 = c0; a.nc = min(64, C - c0); a.write_base = 0;
+        launch_pl<false>(a, s);
     }
 }
 
