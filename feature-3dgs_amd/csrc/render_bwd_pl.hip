@@ -32,6 +32,7 @@
 // pairs) and 4 matrix instructions (128 matrix-pipe cycles); the two pipes overlap across the workgroups of a CU.
 
 #include <cstdio>
+#include <type_traits>
 
 #include "render_common.h"
 
@@ -40,6 +41,10 @@ namespace f3dgs {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access of the
+// wave - here the fire-and-forget atomics of the flush, microseconds under load - which nothing in the workgroup reads.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #ifdef F3DGS_DEV
 #define PL_DEV_SKIP(bit) (a.dev & (bit))     // 1: no global atomics  2: no phase 1  4: no matrix instructions  16: no flush
@@ -90,7 +95,8 @@ static_assert(PL_STAGE_PLANES * PL_SP * 4 <= sizeof(PlShared), "staging image fi
 // GEO = true:  first channel window (up to 32 channels) + the ten geometric sums; column blocks of the waves: feature
 //              channels 0-15, 16-31, colour/depth, moments.
 // GEO = false: a later channel window of up to 64 channels: sixteen per wave.
-template <bool GEO>
+// P1_NE / P1_PREF: entries per phase-1 group, records of the next group prefetched.
+template <bool GEO, int P1_NE, bool P1_PREF>
 __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     PlShared& L = *reinterpret_cast<PlShared*>(smem);
@@ -127,37 +133,45 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             // GEO: dL/dR, dL/dG, dL/dB, dL/ddepth, final_T, n_contrib;  otherwise: final_T, n_contrib
             const int npix = rd == 0 ? (GEO ? 6 : 2) : 0;
             if (rd > 0) __syncthreads();
-            // all requests of a thread first, then the LDS stores: one memory latency per round instead of one per plane
+            // all requests of a thread first (branch-free: a lane that has nothing to fetch reads a valid address and drops the
+            // value), then the LDS stores: one memory latency per round instead of one per plane
             constexpr int NIT = (38 * 64 + 255) / 256;
             float4 sv[NIT];
+            if (vec) {
 #pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int f = it * 256 + tid;
-                const int pl = f >> 6, row = (f >> 2) & 15, xq = f & 3;
-                const int y = ty0 + row, x = tx0 + 4 * xq;
-                const int ch = 32 * rd + pl;
-                const float* src;
-                bool on = y < a.H && f < (32 + npix) * 64;
-                if (pl < 32) {
-                    on = on && ch < a.nc;
-                    src = a.dL_dfeat + (size_t)(a.c0 + (on ? ch : 0)) * HW;
-                } else {
+                for (int it = 0; it < NIT; it++) {
+                    const int f = it * 256 + tid;
+                    const int pl = f >> 6, row = (f >> 2) & 15, xq = f & 3;
+                    const int y = ty0 + row, x = tx0 + 4 * xq;
+                    const int ch = 32 * rd + pl;
                     const int pp = pl - 32 + (GEO ? 0 : 4);
-                    src = pp < 3 ? a.dL_dpix + (size_t)pp * HW : pp == 3 ? a.dL_ddepth : pp == 4 ? a.final_T : reinterpret_cast<const float*>(a.n_contrib);
+                    const bool on = y < a.H && x < a.W && f < (32 + npix) * 64 && (pl >= 32 || ch < a.nc);
+                    const float* src = pl < 32 ? a.dL_dfeat + (size_t)(a.c0 + ch) * HW
+                                     : pp < 3 ? a.dL_dpix + (size_t)pp * HW : pp == 3 ? a.dL_ddepth : pp == 4 ? a.final_T : reinterpret_cast<const float*>(a.n_contrib);
+                    const float* p = on ? src + (size_t)y * a.W + x : a.final_T;
+                    const float4 raw = *reinterpret_cast<const float4*>(p);
+                    sv[it] = on ? raw : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (on && !PL_DEV_SKIP(64)) {
-                    const float* p = src + (size_t)y * a.W + x;
-                    if (vec) {
-                        if (x < a.W) v = *reinterpret_cast<const float4*>(p);
-                    } else {
+            } else {
+                for (int it = 0; it < NIT; it++) {          // images whose rows are not 16-byte aligned: element by element
+                    const int f = it * 256 + tid;
+                    const int pl = f >> 6, row = (f >> 2) & 15, xq = f & 3;
+                    const int y = ty0 + row, x = tx0 + 4 * xq;
+                    const int ch = 32 * rd + pl;
+                    const int pp = pl - 32 + (GEO ? 0 : 4);
+                    const bool on = y < a.H && f < (32 + npix) * 64 && (pl >= 32 || ch < a.nc);
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (on) {
+                        const float* src = pl < 32 ? a.dL_dfeat + (size_t)(a.c0 + ch) * HW
+                                         : pp < 3 ? a.dL_dpix + (size_t)pp * HW : pp == 3 ? a.dL_ddepth : pp == 4 ? a.final_T : reinterpret_cast<const float*>(a.n_contrib);
+                        const float* p = src + (size_t)y * a.W + x;
                         if (x + 0 < a.W) v.x = p[0];
                         if (x + 1 < a.W) v.y = p[1];
                         if (x + 2 < a.W) v.z = p[2];
                         if (x + 3 < a.W) v.w = p[3];
                     }
+                    sv[it] = v;
                 }
-                sv[it] = v;
             }
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
@@ -226,7 +240,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     if (tid < 2) L.touched[tid] = 0;
     __syncthreads();
     PL_STAGE_MARK(4);
-    const uint32_t tile_max = max(max(L.wave_max[0], L.wave_max[1]), max(L.wave_max[2], L.wave_max[3]));
+    const uint32_t tile_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)max(max(L.wave_max[0], L.wave_max[1]), max(L.wave_max[2], L.wave_max[3])));
     const int n_win = PL_DEV_SKIP(32) ? 0 : (int)((tile_max + PL_WIN - 1) / PL_WIN);
 
     // LDS offsets (dwords): phase-1 store column of this lane's pixel, operand read base of this lane's (row, K index)
@@ -253,20 +267,25 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     float4 part_cur = load_part(n_win - 1, gid_cur);
     int parity = 0;
 
-    for (int w = n_win - 1; w >= 0; w--) {
-        // records of window w -> LDS; w - 1 / w - 2 in flight
-        PlRec* const rec = L.rec[w & 1];
-        if (q < 3) {
+    // records of window w -> LDS buffer w & 1 (by the three loader waves), the next window's requests go out
+    auto store_window = [&](int w) {
+        if (q < 3 && w >= 0) {
             float4 v = part_cur;
             if (q == 0) { v.z *= CONIC_SCALE_AC; v.w *= CONIC_SCALE_B; }
             else if (q == 1) { v.x *= CONIC_SCALE_AC; }
             else { v.w = __uint_as_float(gid_cur); }
-            reinterpret_cast<float4*>(&rec[lane])[q] = v;
+            reinterpret_cast<float4*>(&L.rec[w & 1][lane])[q] = v;
         }
         gid_cur = gid_nxt;
         part_cur = load_part(w - 1, gid_cur);
         gid_nxt = load_id(w - 2);
-        __syncthreads();
+    };
+    store_window(n_win - 1);
+    lds_barrier();
+
+    for (int w = n_win - 1; w >= 0; w--) {
+        PlRec* const rec = L.rec[w & 1];
+        bool first_chunk = true;
         PL_PHASE_END(1);
 
         const uint32_t k0 = (uint32_t)w * PL_WIN;
@@ -283,62 +302,84 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             uint32_t tm = 0;      // rows that blended somewhere in this quadrant; bit 16 + q: the quadrant's tiles are live
             if (pos_hi - 15 < my_max && !PL_DEV_SKIP(2)) {
                 const PlRec* rc = &rec[16 * j];
-                float4 n0[2], n1[2];
-                float2 n2[2];
+                auto phase1 = [&](auto nec, auto prefc) {
+                    constexpr int NE = decltype(nec)::value;
+                    constexpr bool PREF = decltype(prefc)::value;
+                    float4 n0[NE], n1[NE];
+                    float2 n2[NE];
+                    if constexpr (PREF) {
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    n0[k] = rc[k].q0; n1[k] = rc[k].q1;
-                    if constexpr (GEO) n2[k] = *reinterpret_cast<const float2*>(&rc[k].q2);
-                }
-#pragma unroll
-                for (int p = 0; p < 8; p++) {
-                    float4 e0[2], e1[2];
-                    float2 e2[2];
-#pragma unroll
-                    for (int k = 0; k < 2; k++) { e0[k] = n0[k]; e1[k] = n1[k]; e2[k] = n2[k]; }
-                    if (p < 7) {
-#pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            n0[k] = rc[2 * p + 2 + k].q0; n1[k] = rc[2 * p + 2 + k].q1;
-                            if constexpr (GEO) n2[k] = *reinterpret_cast<const float2*>(&rc[2 * p + 2 + k].q2);
+                        for (int k = 0; k < NE; k++) {
+                            n0[k] = rc[k].q0; n1[k] = rc[k].q1;
+                            if constexpr (GEO) n2[k] = *reinterpret_cast<const float2*>(&rc[k].q2);
                         }
                     }
-                    PL_COUNT(6, 2);
-                    float au[2], al[2], f[2], qd[2];
 #pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const float dx = e0[k].x - pxf, dy = e0[k].y - pyf;
-                        const float power2 = splat_power2(dx, dy, e0[k].z, e0[k].w, e1[k].x);
-                        const float v = e1[k].y * __builtin_amdgcn_exp2f(power2);                  // op G, not yet clamped
-                        const bool ok = (int)(pos_hi - (uint32_t)(2 * p + k) < last) & (int)!(power2 > 0.0f) & (int)!(v < ALPHA_MIN);
-                        if (__ballot(ok)) tm |= 1u << (2 * p + k);
-                        au[k] = ok ? v : 0.f;          // exp2 may be inf where power > 0: selected away, never multiplied
-                        al[k] = fminf(ALPHA_MAX, au[k]);
-                        f[k] = __builtin_amdgcn_rcpf(1.f - al[k]);                                 // exactly 1 for skipped pairs
-                        if constexpr (GEO) qd[k] = fmaf(e1[k].z, dR, fmaf(e1[k].w, dG, fmaf(e2[k].x, dB, e2[k].y * dD)));
-                    }
+                    for (int p = 0; p < 16 / NE; p++) {
+                        float4 e0[NE], e1[NE];
+                        float2 e2[NE];
+                        if constexpr (PREF) {
 #pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const float Tb = T * f[k];              // transmittance in front of this splat
-                        const float wv = al[k] * Tb;
-                        my_wt[4 * (2 * p + k)] = wv;
-                        if constexpr (GEO) {
-                            const float dL_dalpha = fmaf(Tb, qd[k], -(S * f[k]));
-                            S = fmaf(wv, qd[k], S);
-                            my_wt[4 * (2 * p + k) + ST_OFS] = au[k] * dL_dalpha;
+                            for (int k = 0; k < NE; k++) { e0[k] = n0[k]; e1[k] = n1[k]; e2[k] = n2[k]; }
+                            if (p < 16 / NE - 1) {
+#pragma unroll
+                                for (int k = 0; k < NE; k++) {
+                                    n0[k] = rc[NE * (p + 1) + k].q0; n1[k] = rc[NE * (p + 1) + k].q1;
+                                    if constexpr (GEO) n2[k] = *reinterpret_cast<const float2*>(&rc[NE * (p + 1) + k].q2);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NE; k++) {
+                                e0[k] = rc[NE * p + k].q0; e1[k] = rc[NE * p + k].q1;
+                                if constexpr (GEO) e2[k] = *reinterpret_cast<const float2*>(&rc[NE * p + k].q2);
+                            }
                         }
-                        T = Tb;
+                        PL_COUNT(6, NE);
+                        float au[NE], al[NE], f[NE], qd[NE];
+#pragma unroll
+                        for (int k = 0; k < NE; k++) {
+                            const float dx = e0[k].x - pxf, dy = e0[k].y - pyf;
+                            const float power2 = splat_power2(dx, dy, e0[k].z, e0[k].w, e1[k].x);
+                            const float v = e1[k].y * __builtin_amdgcn_exp2f(power2);                  // op G, not yet clamped
+                            // the three tests as lane masks (scalar ANDs); the select takes the mask as it stands
+                            const unsigned long long okm = __ballot(pos_hi - (uint32_t)(NE * p + k) < last) & __ballot(!(power2 > 0.0f)) & __ballot(!(v < ALPHA_MIN));
+                            if (okm) tm |= 1u << (NE * p + k);
+                            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(au[k]) : "v"(v), "s"(okm));   // exp2 may be inf where power > 0: selected away, never multiplied
+                            al[k] = fminf(ALPHA_MAX, au[k]);
+                            f[k] = __builtin_amdgcn_rcpf(1.f - al[k]);                                 // exactly 1 for skipped pairs
+                            if constexpr (GEO) qd[k] = fmaf(e1[k].z, dR, fmaf(e1[k].w, dG, fmaf(e2[k].x, dB, e2[k].y * dD)));
+                        }
+#pragma unroll
+                        for (int k = 0; k < NE; k++) {
+                            const float Tb = T * f[k];              // transmittance in front of this splat
+                            const float wv = al[k] * Tb;
+                            my_wt[4 * (NE * p + k)] = wv;
+                            if constexpr (GEO) {
+                                const float dL_dalpha = fmaf(Tb, qd[k], -(S * f[k]));
+                                S = fmaf(wv, qd[k], S);
+                                my_wt[4 * (NE * p + k) + ST_OFS] = au[k] * dL_dalpha;
+                            }
+                            T = Tb;
+                        }
                     }
-                }
+                };
+                phase1(std::integral_constant<int, P1_NE>{}, std::integral_constant<bool, P1_PREF>{});
                 tm |= 1u << (16 + q);
             }
             if (tm && lane == 0) atomicOr(&L.touched[parity], tm);
             PL_PHASE_END(2);
-            __syncthreads();                                                  // B_a: the A tiles of the chunk are complete
+            lds_barrier();                                                  // B_a: the A tiles of the chunk are complete
+            if (first_chunk) {
+                // the other record buffer is free now (every wave has flushed the last chunk of window w + 1), and the loads of
+                // window w - 1 - requested a window ago - are older than any atomic still in flight: no wait on the flush traffic
+                store_window(w - 1);
+                first_chunk = false;
+            }
             PL_PHASE_END(1);
 
             // ---- phase 2: this wave's sixteen columns of every sum of the chunk
-            const uint32_t tt = L.touched[parity];
+            const uint32_t tt = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.touched[parity]);
             if (active && (tt & 0xFFFFu) != 0) {
                 f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
                 const float* abase = (use_s ? &L.st[0][0] : &L.wt[0][0]) + rofs;
@@ -377,57 +418,70 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 }
             }
             PL_PHASE_END(3);
-            __syncthreads();                                                  // B_b: tiles read, flush tile written
+            lds_barrier();                                                  // B_b: tiles read, flush tile written
             PL_PHASE_END(1);
 
             // ---- flush: wave q owns rows 4 q .. 4 q + 3 of the chunk
             if ((tt & 0xFFFFu) != 0 && !PL_DEV_SKIP(16)) {
-                const uint32_t mine4 = (tt >> (4 * q)) & 0xFu;
-                if constexpr (GEO) {
-                    if (lane < 4 && ((mine4 >> lane) & 1u)) {
-                        float* g = &L.ftile[(4 * q + lane) * PL_FS + 32];
-                        const PlRec& rc = rec[16 * j + 4 * q + lane];
-                        const float4 r0 = rc.q0, r1 = rc.q1;
-                        const float c0 = g[0], c1 = g[1], c2 = g[2], c3 = g[3];
-                        float M0 = 0.f, m1 = 0.f, m2 = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f;
-#pragma unroll
-                        for (int qd = 0; qd < 4; qd++) {
-                            // mean relative to the quadrant centre: dx = ax - u
-                            const float ax = r0.x - (float)(tx0 + (qd & 1) * 8) - 3.5f, ay = r0.y - (float)(ty0 + (qd >> 1) * 8) - 3.5f;
-                            const float* mq = g + 4 + 6 * qd;
-                            const float N0 = mq[0], N1x = mq[1], N1y = mq[2], N2xx = mq[3], N2xy = mq[4], N2yy = mq[5];
-                            M0 += N0;
-                            m1 += fmaf(ax, N0, -N1x); m2 += fmaf(ay, N0, -N1y);                      // sum s dx, sum s dy
-                            sxx += fmaf(ax, fmaf(ax, N0, -2.f * N1x), N2xx);                         // sum s dx^2
-                            sxy += fmaf(ax, fmaf(ay, N0, -N1y), fmaf(-ay, N1x, N2xy));               // sum s dx dy
-                            syy += fmaf(ay, fmaf(ay, N0, -2.f * N1y), N2yy);                         // sum s dy^2
+                const uint32_t m4 = (tt >> (4 * q)) & 0xFu;
+                float* const F = &L.ftile[(4 * q) * PL_FS];
+                const PlRec* const rq = &rec[16 * j + 4 * q];
+                if (m4 != 0) {
+                    if constexpr (GEO) {
+                        // sixteen lanes: (row, quadrant) - the quadrant's moments re-centred on the splat mean (dx = ax - u), then summed
+                        const int r = (lane >> 2) & 3, qd = lane & 3;
+                        float* row = F + r * PL_FS;
+                        const float4 i0 = rq[r].q0, i1 = rq[r].q1;
+                        const float ax = i0.x - (float)(tx0 + (qd & 1) * 8) - 3.5f, ay = i0.y - (float)(ty0 + (qd >> 1) * 8) - 3.5f;
+                        const float* mq = row + 36 + 6 * qd;
+                        const float N0 = mq[0], N1x = mq[1], N1y = mq[2], N2xx = mq[3], N2xy = mq[4], N2yy = mq[5];
+                        float M0 = N0;
+                        float m1 = fmaf(ax, N0, -N1x), m2 = fmaf(ay, N0, -N1y);                      // sum s dx, sum s dy
+                        float sxx = fmaf(ax, fmaf(ax, N0, -2.f * N1x), N2xx);                        // sum s dx^2
+                        float sxy = fmaf(ax, fmaf(ay, N0, -N1y), fmaf(-ay, N1x, N2xy));              // sum s dx dy
+                        float syy = fmaf(ay, fmaf(ay, N0, -2.f * N1y), N2yy);                        // sum s dy^2
+                        M0 += dpp_get<0xB1>(M0); m1 += dpp_get<0xB1>(m1); m2 += dpp_get<0xB1>(m2);
+                        sxx += dpp_get<0xB1>(sxx); sxy += dpp_get<0xB1>(sxy); syy += dpp_get<0xB1>(syy);
+                        M0 += dpp_get<0x4E>(M0); m1 += dpp_get<0x4E>(m1); m2 += dpp_get<0x4E>(m2);
+                        sxx += dpp_get<0x4E>(sxx); sxy += dpp_get<0x4E>(sxy); syy += dpp_get<0x4E>(syy);
+                        const float c0 = row[32], c1 = row[33], c2 = row[34], c3 = row[35];
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < 16 && qd == 0) {
+                            const float ca = i0.z * CONIC_UNSCALE_AC, cb = i0.w * CONIC_UNSCALE_B, cc = i1.x * CONIC_UNSCALE_AC;
+                            // dG/ddelx = -G (a dx + b dy),  dG/da = -G dx^2 / 2, ...;  dL/dopacity = sum G dL/dalpha = M0 / op
+                            float4 o0, o1;
+                            o0.x = -(0.5f * a.W) * fmaf(ca, m1, cb * m2);
+                            o0.y = -(0.5f * a.H) * fmaf(cc, m2, cb * m1);
+                            o0.z = -0.5f * sxx; o0.w = -0.5f * sxy;
+                            o1.x = -0.5f * syy;
+                            o1.y = M0 * __builtin_amdgcn_rcpf(fmaxf(i1.y, 1e-30f));
+                            o1.z = c0; o1.w = c1;
+                            *reinterpret_cast<float4*>(row + 32) = o0;
+                            *reinterpret_cast<float4*>(row + 36) = o1;
+                            *reinterpret_cast<float2*>(row + 40) = make_float2(c2, c3);
                         }
-                        const float ca = r0.z * CONIC_UNSCALE_AC, cb = r0.w * CONIC_UNSCALE_B, cc = r1.x * CONIC_UNSCALE_AC;
-                        // dG/ddelx = -G (a dx + b dy),  dG/da = -G dx^2 / 2, ...;  dL/dopacity = sum G dL/dalpha = M0 / op
-                        g[0] = -(0.5f * a.W) * fmaf(ca, m1, cb * m2);
-                        g[1] = -(0.5f * a.H) * fmaf(cc, m2, cb * m1);
-                        g[2] = -0.5f * sxx; g[3] = -0.5f * sxy; g[4] = -0.5f * syy;
-                        g[5] = M0 * __builtin_amdgcn_rcpf(r1.y);
-                        g[6] = c0; g[7] = c1; g[8] = c2; g[9] = c3;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                uint32_t m = mine4;
-                while (m) {
-                    const int rr = 4 * q + __builtin_ctz(m);
-                    m &= m - 1;
-                    const uint32_t gg = __float_as_uint(rec[16 * j + rr].q2.w);
-                    if (!PL_DEV_SKIP(1)) {
-                        if constexpr (GEO) {
-                            const float v = L.ftile[rr * PL_FS + lane];
-                            if (lane < 32) {
-                                if (lane < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + lane, v);
-                            } else if (lane < 42) {
-                                unsafeAtomicAdd(a.grec + (size_t)gg * GREC + (lane - 32), v);
+                        __builtin_amdgcn_wave_barrier();
+                        if (!PL_DEV_SKIP(1)) {
+                            // features: two rows per instruction, 32 channels each; gradient record: four rows per instruction
+                            const int rr = lane >> 5, ch = lane & 31;
+#pragma unroll
+                            for (int h = 0; h < 2; h++) {
+                                const int rw = 2 * h + rr;
+                                const float v = F[rw * PL_FS + ch];
+                                const uint32_t gg = __float_as_uint(rq[rw].q2.w);
+                                if (((m4 >> rw) & 1u) && ch < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + ch, v);
                             }
-                        } else {
-                            const float v = L.ftile[rr * PL_FS + lane];
-                            if (lane < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + lane, v);
+                            const int rw = lane >> 4, k16 = lane & 15;
+                            const float v = F[rw * PL_FS + 32 + min(k16, 9)];
+                            const uint32_t gg = __float_as_uint(rq[rw].q2.w);
+                            if (((m4 >> rw) & 1u) && k16 < 10) unsafeAtomicAdd(a.grec + (size_t)gg * GREC + k16, v);
+                        }
+                    } else if (!PL_DEV_SKIP(1)) {
+#pragma unroll
+                        for (int rw = 0; rw < 4; rw++) {
+                            const float v = F[rw * PL_FS + lane];
+                            const uint32_t gg = __float_as_uint(rq[rw].q2.w);
+                            if (((m4 >> rw) & 1u) && lane < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + lane, v);
                         }
                     }
                 }
@@ -444,9 +498,9 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 #endif
 }
 
-template <bool GEO>
+template <bool GEO, int P1_NE, bool P1_PREF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) render_backward_pl_kernel(BwdArgs a) {
-    render_backward_pl_body<GEO>(a);
+    render_backward_pl_body<GEO, P1_NE, P1_PREF>(a);
 }
 
 template <bool GEO>
@@ -454,11 +508,19 @@ void launch_pl(const BwdArgs& a, hipStream_t s) {
 #ifdef F3DGS_DEV
     if (a.dev & 8) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_backward_pl_kernel<GEO>, 256, sizeof(PlShared));
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_backward_pl_kernel<GEO, 2, true>, 256, sizeof(PlShared));
         fprintf(stderr, "[f3dgs dev] pixel-lane backward: %d workgroups per CU by the occupancy query, %zu bytes of LDS\n", nb, sizeof(PlShared));
     }
 #endif
-    hipLaunchKernelGGL((render_backward_pl_kernel<GEO>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a);
+#ifdef F3DGS_DEV
+    const int variant = (a.dev >> 8) & 7;
+    if (variant == 1) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 4, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
+    if (variant == 2) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 4, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
+    if (variant == 3) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 8, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
+    if (variant == 4) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 2, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
+    if (variant == 5) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
+#endif
+    hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 2, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a);
 }
 
 }  // namespace
