@@ -189,7 +189,7 @@ const OptionDesc kOptions[] = {
     {"bwd_half", "F3DGS_BWD_HALF", &Options::bwd_half, 1},
     {"fwd_w4", "F3DGS_FWD_W4", &Options::fwd_w4, 1},
     {"bwd_wave_cull", "F3DGS_BWD_WAVE_CULL", &Options::bwd_wave_cull, 1},
-    {"bwd_pl", "F3DGS_BWD_PL", &Options::bwd_pl, 0},
+    {"bwd_pl", "F3DGS_BWD_PL", &Options::bwd_pl, -1},
     {"fwd_ppl", "F3DGS_FWD_PPL", &Options::fwd_ppl, 0},
     {"fwd_variant", "F3DGS_FWD_VARIANT", &Options::fwd_variant, 0},
     {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},

@@ -168,7 +168,7 @@ struct Options {
     int bwd_half;        // blend backward: chunks of 32 instances against two pixel halves (64-pixel blocks only)
     int fwd_w4;          // blend forward, 32 channels, one quadrant per wave: four waves per SIMD (default 1)
     int bwd_wave_cull;   // blend backward: wave-level footprint culling (default 1)
-    int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe (needs feature_mfma)
+    int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 16; needs feature_mfma
     int fwd_ppl;         // quadrants per wave of the blend forward: 0 = automatic, 1/2/4
     int fwd_variant;     // blend forward chunk/group shape: 0 = default
     int sort_onesweep;   // 1: single-pass radix passes with decoupled look-back (measured slower on MI355X; default 0)

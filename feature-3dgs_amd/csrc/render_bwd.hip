@@ -712,7 +712,9 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     const int npix = opt.bwd_npix ? opt.bwd_npix : 64;
     a.part_major = opt.bwd_part_major;
     a.no_wave_cull = !opt.bwd_wave_cull;
-    if (opt.bwd_pl && opt.feature_mfma && !opt.bwd_npix) {      // pixel-lane formulation (render_bwd_pl.hip), the default
+    // pixel-lane formulation (render_bwd_pl.hip): option bwd_pl = 1 always, 0 never, -1 (default) from 17 channels on - with
+    // 16 or fewer one of its four matrix-pipe waves has no columns and the instance-lane kernel is a few per cent faster
+    if ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > 16)) && opt.feature_mfma && !opt.bwd_npix) {
         a.strip = 0; a.half = 0;
         launch_render_backward_pl(a, C, s);
 #ifdef F3DGS_DEV

@@ -287,8 +287,8 @@ def test_chunk_shapes_of_the_blend_backward_agree(C, option):
 
 @pytest.mark.parametrize("C", [0, 3, 16, 32, 48, 96, 200])
 def test_pixel_lane_and_instance_lane_backward_agree(C, option):
-    """Option bwd_pl (default 1: pixel-lane pass + all sums on the matrix pipe, render_bwd_pl.hip; 0: instance-lane kernel,
-    render_bwd.hip) changes only the order of the float sums: same gradients for no features, ragged channel counts, one
+    """Option bwd_pl (1: pixel-lane pass + all sums on the matrix pipe, render_bwd_pl.hip - the default from 17 channels on;
+    0: instance-lane kernel, render_bwd.hip) changes only the order of the float sums: same gradients for no features, ragged channel counts, one
     and several channel windows."""
     from synth import make_scene
     sc = make_scene(P=30000, C=C, width=333, height=208, seed=29)       # ragged image: masked pixels in edge tiles

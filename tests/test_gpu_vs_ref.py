@@ -287,8 +287,11 @@ def test_c4_eight_views_summed_gradients_vs_reference(record_property):
     for v in range(8):
         sc = dict(scene)
         sc.update(make_camera(scene["image_width"], scene["image_height"], yaw_deg=5.0 * v))
-        st, g_ref, g_prod = _compare(sc, sc["C"], check_state=False, self_noise=False, return_grads=True)
+        # threshold flips grow with the number of blending pairs: the worst of the eight views of this 2M-Gaussian scene has 75
+        # (c3, 1M Gaussians: 33); budget = twice that
+        st, g_ref, g_prod = _compare(sc, sc["C"], check_state=False, self_noise=False, return_grads=True, flip_budget=150)
         flips += st["flip_pixels"]
+        print(f"c4 view {v}: {st['flip_pixels']} flip pixels")
         for k in g_ref:
             tot_ref[k] = g_ref[k].double() if k not in tot_ref else tot_ref[k].add_(g_ref[k])
             tot_prod[k] = g_prod[k].double() if k not in tot_prod else tot_prod[k].add_(g_prod[k])
