@@ -150,14 +150,17 @@ def cpu_reference_path_c1(dev):
     best_n = min(sweep, key=sweep.get)
     cpu_ms = sweep[best_n]
     step, _ = make_step(sc, dev, pool=2)
-    for _ in range(5):
-        step(0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(50):
+    # the GPU has idled through the CPU legs above (tens of seconds: clocks down, caches cold) and c1 is launch-bound (~30
+    # launches and one 8-byte read-back per step): a short warm-up measured 1.9 ms per step on the driver's box against
+    # 0.23 ms for the same loop on a busy GPU - warm up for real, then time
+    for i in range(300):
         step(i)
     torch.cuda.synchronize()
-    gpu_ms = 1e3 * (time.perf_counter() - t0) / 50
+    t0 = time.perf_counter()
+    for i in range(200):
+        step(i)
+    torch.cuda.synchronize()
+    gpu_ms = 1e3 * (time.perf_counter() - t0) / 200
     mpix = sc["image_width"] * sc["image_height"] / 1e6
     model = ""
     try:
@@ -174,7 +177,7 @@ def cpu_reference_path_c1(dev):
             "note": "CPU: oracle/torch_oracle.py (restatement of the reference's algorithm; the reference has no CPU "
                     "rasterizer), median of up to 5 runs after 1 warm-up per thread count, best count reported; with "
                     "torch.set_num_threads(256) one step took 259 s on this host class (profiles/r02_notes.md). "
-                    "GPU: this library, mean of 50 steps"}
+                    "GPU: this library, mean of 200 steps after 300 warm-up steps (launch-bound: ~30 launches and one host read-back per step)"}
 
 
 def make_step(scene, dev, pool=4, dist=None, overlap=True):
@@ -217,6 +220,142 @@ def make_step(scene, dev, pool=4, dist=None, overlap=True):
     return step, leaves
 
 
+def config_label(P, W, H, C):
+    """'1M Gaussians @1080p, feat_dim=32' for the headline config, the same wording for the others."""
+    ps = f"{P // 1000000}M" if P % 1000000 == 0 else (f"{P // 1000}k" if P % 1000 == 0 else str(P))
+    res = {(1920, 1080): "@1080p", (3840, 2160): "@4K"}.get((W, H), f"@{W}x{H}")
+    return f"{ps} Gaussians {res}, feat_dim={C}"
+
+
+class _BenchModel:
+    """Duck-typed like the reference's GaussianModel (scene/gaussian_model.py) for densify.py: raw parameters (log scale,
+    logit opacity, SH split into dc / rest), the densification statistics and an optimizer with the reference's groups."""
+    percent_dense = 0.01
+
+    def __init__(self, scene, dev):
+        import torch
+        from fused_adam import FusedAdam
+        par = lambda x: torch.nn.Parameter(x.to(dev).contiguous().clone().requires_grad_(True))
+        self._xyz = par(scene["means3D"])
+        self._features_dc, self._features_rest = par(scene["shs"][:, :1]), par(scene["shs"][:, 1:])
+        self._scaling, self._rotation = par(torch.log(scene["scales"])), par(scene["rotations"])
+        op = scene["opacities"].clamp(1e-4, 1 - 1e-4)
+        self._opacity = par(torch.log(op / (1 - op)))
+        self._semantic_feature = par(scene["semantic_feature"])
+        P = self._xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros(P, 1, device=dev)
+        self.denom = torch.zeros(P, 1, device=dev)
+        self.max_radii2D = torch.zeros(P, device=dev)
+        groups = [{"params": [getattr(self, attr)], "lr": 1e-4, "name": name} for name, attr in (
+            ("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+            ("scaling", "_scaling"), ("rotation", "_rotation"), ("semantic_feature", "_semantic_feature"))]
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+
+    def leaves(self):
+        """What the reference's render() hands to the op (gaussian_renderer/__init__.py:196-236), as fresh leaves."""
+        import torch
+        with torch.no_grad():
+            d = dict(means3D=self._xyz.detach(), opacities=torch.sigmoid(self._opacity), scales=torch.exp(self._scaling),
+                     rotations=torch.nn.functional.normalize(self._rotation), shs=torch.cat((self._features_dc, self._features_rest), dim=1),
+                     semantic_feature=self._semantic_feature.detach())
+        d = {k: v.contiguous().clone().requires_grad_() for k, v in d.items()}
+        d["means2D"] = torch.zeros(self._xyz.shape[0], 3, device=self._xyz.device, requires_grad=True)
+        return d
+
+
+def densify_leg(args, dev):
+    """BASELINE.json config c5 as it is meant: 'densification on'.  Every --densify-every steps 5 % of the Gaussians are
+    re-sampled BETWEEN the timed iterations through densify.densify_and_prune (the reference's own selection rules on
+    prepared statistics: a random 5 % are cloned or split, another 5 % - opacity pushed under the threshold - are pruned),
+    so the point count P, the instance count N and every state buffer of the op change while it is being timed.
+    A step is timed by a HIP event pair around the op's forward + backward; the densification itself is reported beside it."""
+    import statistics
+
+    import torch
+
+    import densify
+    import diff_gaussian_rasterization as dgr
+    from synth import CONFIGS, make_scene
+    cfg_kw = dict(CONFIGS[args.config])
+    if args.feat_dim is not None:
+        cfg_kw["C"] = args.feat_dim
+    scene = make_scene(seed=0, **cfg_kw)
+    W, H, C = scene["image_width"], scene["image_height"], scene["C"]
+    t = lambda x: x.to(dev)
+    settings = dgr.GaussianRasterizationSettings(H, W, scene["tanfovx"], scene["tanfovy"], t(scene["bg"]), 1.0, t(scene["viewmatrix"]),
+                                                 t(scene["projmatrix"]), scene["sh_degree"], t(scene["campos"]), False, False)
+    rasterizer = dgr.GaussianRasterizer(settings)
+    model = _BenchModel(scene, dev)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    hw = float(W * H)
+    ups = [[t(torch.randn(3, H, W, generator=g) / hw), t(torch.randn(C, H, W, generator=g) / hw), t(torch.randn(1, H, W, generator=g) / hw)]
+           for _ in range(2)]
+    gd = torch.Generator(device=dev).manual_seed(99)
+    extent = 1.7          # percent_dense * extent = 0.017: the median of the largest axis of the recipe's scales -> clones and splits
+
+    def resample():
+        P = model._xyz.shape[0]
+        u = torch.rand(P, generator=gd, device=dev)
+        grow, drop = u < 0.05, u > 0.95
+        model.xyz_gradient_accum = torch.where(grow, 1.0, 0.0).reshape(P, 1)
+        model.denom = torch.ones(P, 1, device=dev)
+        with torch.no_grad():
+            model._opacity[drop] = -20.0            # sigmoid < min_opacity: pruned
+        return densify.densify_and_prune(model, 0.5, 0.005, extent, None)
+
+    n_list, p_list, step_ms, dens_ms, plans = [], [], [], [], []
+    leaves = model.leaves()
+    total = args.warmup + args.steps
+    torch.cuda.synchronize()
+    t_wall = None
+    for i in range(total):
+        if i == args.warmup:
+            torch.cuda.synchronize()
+            t_wall = time.perf_counter()
+        if i > 0 and i % args.densify_every == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            plan = resample()
+            leaves = model.leaves()
+            e1.record()
+            if i >= args.warmup:
+                plans.append(plan)
+                dens_ms.append((e0, e1))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        color, feat, radii, depth = rasterizer(**leaves)
+        torch.autograd.backward([color, feat, depth], ups[i % 2])
+        e1.record()
+        for v in leaves.values():
+            v.grad = None
+        if i >= args.warmup:
+            step_ms.append((e0, e1))
+            p_list.append(int(leaves["means3D"].shape[0]))
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_wall
+    step_ms = sorted(a.elapsed_time(b) for a, b in step_ms)
+    dens = [a.elapsed_time(b) for a, b in dens_ms]
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
+    mean_ms = sum(step_ms) / len(step_ms)
+    pool = getattr(model, "_row_pool", None) or getattr(model, "_f3dgs_pool", None)
+    out = {
+        "metric": f"rendered Mpix/s of rasterizer fwd+bwd with densification on, {config_label(scene['P'], W, H, C)} + depth",
+        "value": W * H / 1e6 / (mean_ms * 1e-3), "unit": "Mpix/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": mean_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {scene['P']} Gaussians at the start, {W}x{H}, SH degree {scene['sh_degree']}, feat_dim={C}, depth "
+                               f"gradients, 5 % of the Gaussians re-sampled every {args.densify_every} steps between the timed iterations",
+                   "P_min": min(p_list), "P_max": max(p_list), "densifications": len(plans),
+                   "last_plan": plans[-1] if plans else None},
+        "step_ms": {"mean": mean_ms, "median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "max": step_ms[-1], "n": len(step_ms),
+                    "source": "HIP event pair around the op's forward + backward of every timed step"},
+        "densification_ms": {"mean": (sum(dens) / len(dens)) if dens else None, "max": max(dens) if dens else None,
+                             "includes": "densify.densify_and_prune + the activations of the new leaves (outside the step)"},
+        "wall_ms_per_step_including_densification": 1e3 * wall / args.steps,
+        "row_pool_reallocations": getattr(pool, "reallocations", None),
+    }
+    print(json.dumps(out), flush=True)
+
+
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run and relay its output."""
     s = socket.socket()
@@ -238,6 +377,11 @@ def main():
     ap.add_argument("--comm-only", action="store_true", help="time only the gradient exchange of the config (N > 1)")
     ap.add_argument("--no-overlap", action="store_true", help="exchange all gradients after the backward pass")
     ap.add_argument("--feat-dim", type=int, default=None, help="override the config's feature dim (development)")
+    ap.add_argument("--valu", action="store_true",
+                    help="library option feature_mfma = 0: every blend kernel on the vector pipe only (the north-star-literal configuration)")
+    ap.add_argument("--densify-every", type=int, default=0,
+                    help="config c5 'densification on' (SURVEY.md 8d): every N steps 5 %% of the Gaussians are re-sampled through "
+                         "densify.densify_and_prune between the timed iterations (N and the state buffers change)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "0"))
@@ -269,6 +413,13 @@ def main():
     from diff_gaussian_rasterization import _C
     from synth import CONFIGS, make_scene
 
+    if args.valu:
+        _C.set_option("feature_mfma", 0)
+    if args.densify_every > 0:
+        if world != 1:
+            raise SystemExit("--densify-every is a single-GPU leg")
+        densify_leg(args, dev)
+        return
     cfg_kw = dict(CONFIGS[args.config])
     if args.feat_dim is not None:
         cfg_kw["C"] = args.feat_dim
@@ -277,7 +428,7 @@ def main():
     W, H = scene["image_width"], scene["image_height"]
     step, leaves = make_step(scene, dev, dist=dist, overlap=not args.no_overlap)
 
-    def timed(n_steps, per_step_events):
+    def timed(n_steps, per_step_events):       # (`step` is looked up at call time)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)] if per_step_events else None
         torch.cuda.synchronize()
         if dist is not None:
@@ -351,6 +502,35 @@ def main():
     prof = {name: (ms, calls) for name, ms, calls in _C.profile_read()}
     _C.set_option("profile", 0)
 
+    dp_breakdown = None
+    if dist is not None:
+        # the same K steps without the exchange, and the exchange alone on the gradients they left: what the scaling is made of
+        import dp
+        step_local, leaves_local = make_step(scene, dev, dist=None)
+        for i in range(3):
+            step_local(i)
+        _step = step
+        step = step_local
+        el_compute, _ = timed(args.steps, per_step_events=False)
+        step = _step
+        grads = {k: (leaves_local[k].grad if leaves_local[k].grad is not None else torch.zeros_like(leaves_local[k]))
+                 for k in ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")}
+        for _ in range(3):
+            dp.all_reduce_gaussian_grads(grads)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dp.all_reduce_gaussian_grads(grads)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        nbytes = sum(g.numel() * 4 for g in grads.values())
+        dp_breakdown = {"compute_only_ms": 1e3 * el_compute / args.steps, "comm_only_ms": 1e3 * float(tt.item()) / args.steps,
+                        "bytes_per_rank": nbytes, "comm_algbw_GBps": nbytes / (float(tt.item()) / args.steps) / 1e9,
+                        "note": "same K steps without the exchange (max over ranks), and the bucketed all-reduce alone; "
+                                "ms_per_step below their sum = overlap achieved"}
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         mpix = world * W * H / 1e6 / (elapsed / args.steps)
@@ -365,7 +545,7 @@ def main():
             dom_ms = stage_ms.get(kernel_stage[dom], float("nan"))
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
         profiled = None
-        for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
             f = os.path.join(ROOT, "profiles", name)
             if os.path.exists(f):
                 try:
@@ -375,31 +555,40 @@ def main():
                     break
                 except Exception:
                     pass
-        # VALU-issue fraction of the dominant kernel from the committed SQ counters (same caveat: a separate run)
-        sq_name = {"render_bwd": "render_backward_kernel", "render_fwd": "render_forward", "preprocess": "preprocess_kernel",
-                   "preprocess_bwd": "preprocess_backward_kernel"}[dom]
-        f = os.path.join(ROOT, "profiles", "r02_pmc_sq_counters.json")
-        if profiled is not None and os.path.exists(f):
+        # VALU-issue fraction of both blend kernels from the committed SQ counters (same caveat: a separate run)
+        sq_names = {"render_bwd": "render_backward", "render_fwd": "render_forward", "preprocess": "preprocess_kernel",
+                    "preprocess_bwd": "preprocess_backward_kernel"}
+        for sqf in ("r03_pmc_sq_counters.json", "r02_pmc_sq_counters.json"):
+            f = os.path.join(ROOT, "profiles", sqf)
+            if profiled is None or not os.path.exists(f):
+                continue
             try:
-                rows = [v for k, v in json.load(open(f)).items() if k.startswith(sq_name)]
-                if rows:
+                table = json.load(open(f))
+                for stage in dict.fromkeys((dom, "render_fwd", "render_bwd")):
+                    rows = [v for k, v in table.items() if k.startswith(sq_names[stage])]
+                    if not rows:
+                        continue
                     r = max(rows, key=lambda v: v.get("SQ_INSTS_VALU", 0))
                     # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MICROARCH.md); SQ_BUSY_CYCLES is summed over the 32
                     # shader engines, so /32 is the kernel's duration in shader cycles; 1024 SIMDs
-                    profiled["valu_issue"] = {
+                    profiled.setdefault("valu_issue", {})[stage] = {
                         "frac": 4.0 * r["SQ_ACTIVE_INST_VALU"] / (r["SQ_BUSY_CYCLES"] / 32.0 * 1024.0),
-                        "valu_instructions_per_launch": r["SQ_INSTS_VALU"], "mfma_instructions_per_launch": r["SQ_INSTS_MFMA"],
-                        "formula": "4 x SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs)",
-                        "source": "profiles/r02_pmc_sq_counters.json (rocprofv3 --pmc, a separate run of this config)"}
+                        "matrix_pipe_frac": r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (r["SQ_BUSY_CYCLES"] / 32.0 * 1024.0),
+                        "valu_instructions_per_launch": r["SQ_INSTS_VALU"], "mfma_instructions_per_launch": r["SQ_INSTS_MFMA"]}
+                profiled["valu_issue_source"] = (f"profiles/{sqf} (rocprofv3 --pmc, a separate run of this config); frac = 4 x "
+                                                 "SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs), matrix_pipe_frac = "
+                                                 "SQ_VALU_MFMA_BUSY_CYCLES / the same")
+                break
             except Exception:
                 pass
         per = sorted(per_step)
         pct = lambda q: per[min(len(per) - 1, int(q * len(per)))]
         out = {
-            "metric": "rendered Mpix/s of rasterizer fwd+bwd (train-step ms in ms_per_step), 1M Gaussians @1080p, feat_dim=32",
+            "metric": f"rendered Mpix/s of rasterizer fwd+bwd (train-step ms in ms_per_step), {config_label(P, W, H, C)}",
             "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "blend_kernels": "vector pipe only (option feature_mfma = 0)" if args.valu else "feature / gradient contractions on the matrix pipe (exact fp32)",
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {scene['sh_degree']}, feat_dim={C}, "
                                    f"one view per GPU (SURVEY.md 8d recipe, seed 0), fresh upstream gradients per step",
                        "P": P, "Pv": stats["Pv"], "N": stats["N"], "N_r": stats["N_r"],
@@ -420,6 +609,7 @@ def main():
             "roofline_whole_step": {"algorithmic_bytes": alg["total"],
                                     "achieved": alg["total"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                                     "frac": alg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "dp_breakdown": dp_breakdown,
             "stage_ms": stage_ms,
             "stage_ms_source": "auxiliary run of the same K steps with an event at every stage boundary (not the timed region)",
         }
