@@ -249,7 +249,7 @@ CountReadback& count_readback() {
 
 extern "C" {
 
-int f3dgs_version(void) { return 210; }   // 2.1: + densify_gather, adam_step_rows, options bwd_half / fwd_w4, profile = 2
+int f3dgs_version(void) { return 30000; }   // 3.0.0 (major * 10000 + minor * 100 + patch): + option bwd_pl (pixel-lane blend backward, render_bwd_pl.hip)
 
 int f3dgs_set_option(const char* name, int value) {
     if (!name) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null option name");

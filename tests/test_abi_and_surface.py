@@ -29,7 +29,8 @@ def test_c_abi_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/f3dgs.h but not exported"
     lib.f3dgs_version.restype = ctypes.c_int
-    assert lib.f3dgs_version() >= 100
+    v = lib.f3dgs_version()           # include/f3dgs.h: major * 10000 + minor * 100 + patch
+    assert v >= 30000 and v // 10000 == 3 and v % 100 < 100
     lib.f3dgs_backward_scratch_bytes.restype = ctypes.c_size_t
     assert lib.f3dgs_backward_scratch_bytes(1000, 32) >= 1000 * 40
 
