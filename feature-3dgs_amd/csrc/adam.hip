@@ -59,7 +59,79 @@ adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g, float*
     }
 }
 
+// ---- several tensors, one launch: block b belongs to the tensor whose block range contains it ------------------------------
+struct AdamEntry {
+    float* p; const float* g; float* m; float* v;
+    size_t n;
+    uint32_t block0;         // first workgroup of this tensor
+    uint32_t width;          // floats per row (row mask variant), 0: the mask does not apply to this tensor
+    float step_size, inv_sqrt_bc2;
+};
+struct AdamTable {
+    AdamEntry t[F3DGS_ADAM_MAX_TENSORS];
+    int count;
+};
+
+__global__ void __launch_bounds__(256)
+adam_multi_kernel(AdamTable tab, float b2, float omb1, float omb2, float eps, const uint8_t* __restrict__ row_mask) {
+    int k = 0;
+#pragma unroll 1
+    while (k + 1 < tab.count && blockIdx.x >= tab.t[k + 1].block0) k++;
+    const AdamEntry e = tab.t[k];
+    const size_t i4 = ((size_t)(blockIdx.x - e.block0) * 256 + threadIdx.x) * 4;
+    if (i4 >= e.n) return;
+    float* __restrict__ p = e.p; const float* __restrict__ g = e.g; float* __restrict__ m = e.m; float* __restrict__ v = e.v;
+    if (row_mask && e.width) {
+        const size_t last = (i4 + 4 <= e.n ? i4 + 4 : e.n) - 1;
+        const size_t r0 = i4 / e.width, r1 = last / e.width;
+        bool any = false;
+        for (size_t r = r0; r <= r1; r++) any = any || row_mask[r] != 0;
+        if (!any) return;
+        for (size_t i = i4; i <= last; i++) {
+            if (!row_mask[i / e.width]) continue;
+            adam_update(p[i], g[i], m[i], v[i], e.step_size, b2, omb1, omb2, e.inv_sqrt_bc2, eps);
+        }
+        return;
+    }
+    if (i4 + 4 <= e.n && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                           reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        float4 pp = *reinterpret_cast<float4*>(p + i4), mm = *reinterpret_cast<float4*>(m + i4), vv = *reinterpret_cast<float4*>(v + i4);
+        const float4 gg = *reinterpret_cast<const float4*>(g + i4);
+        float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) adam_update(pa[q], ga[q], ma[q], va[q], e.step_size, b2, omb1, omb2, e.inv_sqrt_bc2, eps);
+        *reinterpret_cast<float4*>(p + i4) = pp;
+        *reinterpret_cast<float4*>(m + i4) = mm;
+        *reinterpret_cast<float4*>(v + i4) = vv;
+        return;
+    }
+    for (size_t i = i4; i < e.n && i < i4 + 4; i++) adam_update(p[i], g[i], m[i], v[i], e.step_size, b2, omb1, omb2, e.inv_sqrt_bc2, eps);
+}
+
 }  // namespace
+
+void launch_adam_step_multi(int count, const f3dgs_adam_tensor* tensors, double b1, double b2, double eps, const uint8_t* row_mask,
+                            size_t rows, hipStream_t s) {
+    AdamTable tab;
+    tab.count = 0;
+    uint32_t blocks = 0;
+    for (int i = 0; i < count; i++) {
+        const f3dgs_adam_tensor& t = tensors[i];
+        if (t.n == 0) continue;
+        AdamEntry& e = tab.t[tab.count++];
+        e.p = t.param; e.g = t.grad; e.m = t.exp_avg; e.v = t.exp_avg_sq; e.n = t.n;
+        e.block0 = blocks;
+        e.width = (row_mask && rows && t.n % rows == 0) ? (uint32_t)(t.n / rows) : 0u;
+        // every derived constant is formed in double and rounded once, as in launch_adam_step
+        const double bc1 = 1.0 - pow(b1, (double)t.step), bc2 = 1.0 - pow(b2, (double)t.step);
+        e.step_size = (float)(t.lr / bc1);
+        e.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        blocks += (uint32_t)(((t.n + 3) / 4 + 255) / 256);
+    }
+    if (tab.count == 0) return;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, s, tab, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2),
+                       (float)eps, row_mask);
+}
 
 void launch_adam_step(size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps, int step,
                       const uint8_t* row_mask, size_t width, hipStream_t s) {

@@ -517,6 +517,26 @@ int f3dgs_adam_step_rows(size_t n, size_t width, const uint8_t* row_mask, float*
     return F3DGS_OK;
 }
 
+int f3dgs_adam_step_multi(int n_tensors, const f3dgs_adam_tensor* tensors, double beta1, double beta2, double eps,
+                          const uint8_t* row_mask, size_t rows, void* stream) {
+    if (n_tensors < 0 || n_tensors > F3DGS_ADAM_MAX_TENSORS) return fail(F3DGS_ERR_INVALID_ARGUMENT, "0 .. %d tensors per call", F3DGS_ADAM_MAX_TENSORS);
+    if (n_tensors == 0) return F3DGS_OK;
+    if (!tensors) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null table");
+    size_t blocks = 0;
+    for (int i = 0; i < n_tensors; i++) {
+        const f3dgs_adam_tensor& t = tensors[i];
+        if (t.n == 0) continue;
+        if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq) return fail(F3DGS_ERR_INVALID_ARGUMENT, "tensor %d: null pointer", i);
+        if (t.step < 1) return fail(F3DGS_ERR_INVALID_ARGUMENT, "tensor %d: step counts from 1", i);
+        blocks += ((t.n + 3) / 4 + 255) / 256;
+    }
+    if (blocks >= (1ull << 31)) return fail(F3DGS_ERR_UNSUPPORTED, "too large for one launch");
+    if (row_mask && rows == 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "row mask without a row count");
+    launch_adam_step_multi(n_tensors, tensors, beta1, beta2, eps, row_mask, rows, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return F3DGS_OK;
+}
+
 int f3dgs_densify_gather(size_t n_out, const int32_t* src_row, const uint8_t* kind, const int32_t* override_row, int n_tensors,
                          const f3dgs_densify_tensor* tensors, void* stream) {
     if (n_tensors < 0 || n_tensors > F3DGS_DENSIFY_MAX_TENSORS)

@@ -252,6 +252,40 @@ void AdamStep(torch::Tensor& param, const torch::Tensor& grad, torch::Tensor& ex
                  "adam_step");
 }
 
+// torch.optim.Adam's step over a list of tensors in one launch (include/f3dgs.h: f3dgs_adam_step_multi).
+void AdamStepMulti(std::vector<torch::Tensor> params, std::vector<torch::Tensor> grads, std::vector<torch::Tensor> exp_avgs,
+                   std::vector<torch::Tensor> exp_avg_sqs, std::vector<double> lrs, double beta1, double beta2, double eps,
+                   std::vector<int64_t> steps, const c10::optional<torch::Tensor>& row_mask) {
+    const size_t n = params.size();
+    TORCH_CHECK(n <= F3DGS_ADAM_MAX_TENSORS, "adam_step_multi: at most ", F3DGS_ADAM_MAX_TENSORS, " tensors per call");
+    TORCH_CHECK(grads.size() == n && exp_avgs.size() == n && exp_avg_sqs.size() == n && lrs.size() == n && steps.size() == n,
+                "adam_step_multi: list lengths differ");
+    if (n == 0) return;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(params[0].device());
+    std::vector<torch::Tensor> keep;       // contiguous copies of gradients stay alive until the launch is enqueued
+    f3dgs_adam_tensor tab[F3DGS_ADAM_MAX_TENSORS];
+    for (size_t i = 0; i < n; i++) {
+        TORCH_CHECK(params[i].is_cuda() && grads[i].is_cuda() && exp_avgs[i].is_cuda() && exp_avg_sqs[i].is_cuda(), "adam_step_multi: HIP tensors only");
+        TORCH_CHECK(params[i].scalar_type() == torch::kFloat32 && grads[i].scalar_type() == torch::kFloat32, "adam_step_multi: float32 only");
+        TORCH_CHECK(params[i].is_contiguous() && exp_avgs[i].is_contiguous() && exp_avg_sqs[i].is_contiguous(), "adam_step_multi: contiguous state");
+        TORCH_CHECK(grads[i].numel() == params[i].numel() && exp_avgs[i].numel() == params[i].numel() &&
+                    exp_avg_sqs[i].numel() == params[i].numel(), "adam_step_multi: size mismatch");
+        keep.push_back(grads[i].contiguous());
+        tab[i] = f3dgs_adam_tensor{params[i].data_ptr<float>(), keep.back().data_ptr<float>(), exp_avgs[i].data_ptr<float>(),
+                                   exp_avg_sqs[i].data_ptr<float>(), (size_t)params[i].numel(), lrs[i], (int)steps[i]};
+    }
+    const uint8_t* mask = nullptr;
+    size_t rows = 0;
+    torch::Tensor mk;
+    if (row_mask.has_value() && row_mask->defined()) {
+        TORCH_CHECK(row_mask->is_cuda(), "adam_step_multi: the mask must be a HIP tensor");
+        mk = row_mask->to(torch::kUInt8).contiguous();
+        mask = mk.data_ptr<uint8_t>();
+        rows = (size_t)mk.numel();
+    }
+    check_status(f3dgs_adam_step_multi((int)n, tab, beta1, beta2, eps, mask, rows, current_stream(params[0])), "adam_step_multi");
+}
+
 // One gather over all per-Gaussian tensors (densify.py builds the plan).  `modes[i]`: F3DGS_DENSIFY_*;
 // `overrides[i]` is the child-row array for mode OVERRIDE_CHILD (an empty tensor otherwise).
 void DensifyGather(const torch::Tensor& src_row, const torch::Tensor& kind, const torch::Tensor& override_row,
@@ -299,6 +333,8 @@ PYBIND11_MODULE(_C, m) {
     m.def("feature_l1", &FeatureL1);
     m.def("adam_step", &AdamStep, py::arg("param"), py::arg("grad"), py::arg("exp_avg"), py::arg("exp_avg_sq"), py::arg("lr"),
           py::arg("beta1"), py::arg("beta2"), py::arg("eps"), py::arg("step"), py::arg("row_mask") = py::none());
+    m.def("adam_step_multi", &AdamStepMulti, py::arg("params"), py::arg("grads"), py::arg("exp_avgs"), py::arg("exp_avg_sqs"), py::arg("lrs"),
+          py::arg("beta1"), py::arg("beta2"), py::arg("eps"), py::arg("steps"), py::arg("row_mask") = py::none());
     m.def("densify_gather", &DensifyGather);
     m.def("version", []() { return f3dgs_version(); });
     m.def("set_feature_grad_hook", [](py::object fn) { feature_grad_hook() = std::move(fn); },

@@ -241,6 +241,9 @@ hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, cons
 void launch_adam_step(size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps,
                       int step, const uint8_t* row_mask, size_t width, hipStream_t s);
 
+void launch_adam_step_multi(int count, const f3dgs_adam_tensor* tensors, double b1, double b2, double eps, const uint8_t* row_mask,
+                            size_t rows, hipStream_t s);
+
 // densify.hip
 using DensifyTensor = f3dgs_densify_tensor;
 constexpr int DENSIFY_MAX_TENSORS = F3DGS_DENSIFY_MAX_TENSORS;

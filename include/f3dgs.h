@@ -235,6 +235,25 @@ int f3dgs_adam_step_rows(size_t n, size_t width, const uint8_t* row_mask, float*
                          void* stream /* hipStream_t */);
 
 /*
+ * The same update over SEVERAL tensors in ONE launch (the reference steps the seven per-Gaussian tensors with torch's
+ * foreach kernels, scene/gaussian_model.py:163-178): a table of up to F3DGS_ADAM_MAX_TENSORS entries, each with its own
+ * learning rate and step count (torch keeps them per parameter); beta1 / beta2 / eps are shared.  `row_mask` (optional,
+ * `rows` bytes): the visibility-masked variant of f3dgs_adam_step_rows, applied to every tensor whose `n` is a multiple of `rows`.
+ */
+#define F3DGS_ADAM_MAX_TENSORS 16
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    size_t n;        /* elements */
+    double lr;
+    int step;        /* counts from 1 */
+} f3dgs_adam_tensor;
+int f3dgs_adam_step_multi(int n_tensors, const f3dgs_adam_tensor* tensors /* host array */, double beta1, double beta2, double eps,
+                          const uint8_t* row_mask, size_t rows, void* stream);
+
+/*
  * Row movement of one densification (scene/gaussian_model.py:300-431: densify_and_clone, densify_and_split,
  * prune_points and the optimizer-state edits of cat_tensors_to_optimizer / _prune_optimizer) as ONE gather over all
  * per-Gaussian tensors.  Output row j of every tensor comes from source row src_row[j]; kind[j] says how:

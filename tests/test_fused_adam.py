@@ -88,3 +88,26 @@ def test_visibility_masked_step_touches_only_visible_rows():
             sa, sb = a.state[grp_a["params"][0]], b.state[grp_b["params"][0]]
             for k in ("exp_avg", "exp_avg_sq"):
                 assert torch.equal(sa[k][vis], sb[k][vis]) and torch.equal(sb[k][~vis], st0[k][~vis]), (grp_a["name"], k)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_one_launch_and_per_tensor_paths_are_bit_identical(masked):
+    """FusedAdam(multi_tensor=True) - ONE launch over the seven tensors (f3dgs_adam_step_multi) - against the per-tensor entry
+    point (f3dgs_adam_step[_rows]): same element-wise arithmetic, so every parameter and moment must be equal bit for bit,
+    with and without the visibility mask extension."""
+    from fused_adam import FusedAdam
+    dev = "cuda:0"
+    ga, gb = _groups(dev, P=4099, C=32), _groups(dev, P=4099, C=32)
+    a, b = FusedAdam(ga, lr=0.0, eps=1e-15, multi_tensor=False), FusedAdam(gb, lr=0.0, eps=1e-15, multi_tensor=True)
+    gen = torch.Generator().manual_seed(5)
+    vis = (torch.rand(4099, generator=gen) < 0.6).to(dev) if masked else None
+    for it in range(4):
+        for grp_a, grp_b in zip(a.param_groups, b.param_groups):
+            grad = torch.randn(grp_a["params"][0].shape, generator=gen).to(dev) * 1e-2
+            grp_a["params"][0].grad, grp_b["params"][0].grad = grad.clone(), grad.clone()
+        a.step(visibility=vis); b.step(visibility=vis)
+    for grp_a, grp_b in zip(a.param_groups, b.param_groups):
+        pa, pb = grp_a["params"][0], grp_b["params"][0]
+        assert torch.equal(pa, pb), grp_a["name"]
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(a.state[pa][k], b.state[pb][k]), (grp_a["name"], k)
