@@ -500,6 +500,28 @@ int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float*
     return F3DGS_OK;
 }
 
+size_t f3dgs_feature_decode_scratch_bytes(int C, int Hg, int Wg, int has_decoder) {
+    if (C <= 0 || Hg <= 0 || Wg <= 0) return 0;
+    return feature_decode_scratch_bytes(C, Hg, Wg, has_decoder != 0);
+}
+
+int f3dgs_feature_decode(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
+                         const float* bias, void* out, int out_is_half, void* scratch, void* stream) {
+    if (C <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Hg <= 0 || Wg <= 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (!feature_map || !out) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
+    if ((weight == nullptr) != (bias == nullptr)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "weight and bias go together");
+    if (weight) {
+        if (!scratch) return fail(F3DGS_ERR_INVALID_ARGUMENT, "scratch is null");
+        if (!feature_l1_decoder_supported(C))
+            return fail(F3DGS_ERR_UNSUPPORTED, "decoder input width %d: supported are 32, 64, 128", C);
+    } else if (Cout != C) {
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "without a decoder the output has C = %d channels, got %d", C, Cout);
+    }
+    HIP_TRY(launch_feature_decode(C, H, W, Cout, Hg, Wg, feature_map, weight, bias, out, out_is_half != 0,
+                                  static_cast<char*>(scratch), static_cast<hipStream_t>(stream)));
+    return F3DGS_OK;
+}
+
 int f3dgs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
                     double beta2, double eps, int step, void* stream) {
     return f3dgs_adam_step_rows(n, 1, nullptr, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, stream);

@@ -227,6 +227,32 @@ FeatureL1(const torch::Tensor& feature_map, const torch::Tensor& gt, const torch
     return std::make_tuple(loss, d_fm, d_w, d_b);
 }
 
+// forward-only resize -> 1x1 decoder (include/f3dgs.h: f3dgs_feature_decode); returns the (Cout, Hg, Wg) map, fp32 or fp16
+torch::Tensor FeatureDecode(const torch::Tensor& feature_map, int64_t Hg, int64_t Wg, const torch::Tensor& weight,
+                            const torch::Tensor& bias, bool half) {
+    TORCH_CHECK(feature_map.is_cuda(), "feature_decode: tensors must live on a HIP device (no CPU path)");
+    TORCH_CHECK(feature_map.dim() == 3, "feature_decode: feature_map (C,H,W) expected");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(feature_map.device());
+    auto fm = dev_f32(feature_map, "feature_map");
+    const bool dec = weight.numel() > 0;
+    torch::Tensor w = weight, b = bias;
+    const int C = fm.size(0), H = fm.size(1), W = fm.size(2);
+    int Cout = C;
+    if (dec) {
+        w = dev_f32(weight, "weight");
+        b = dev_f32(bias, "bias");
+        TORCH_CHECK(w.dim() == 2 && w.size(1) == C && b.numel() == w.size(0), "feature_decode: weight (Cout,C) / bias (Cout) do not match feature_map");
+        Cout = w.size(0);
+    }
+    torch::Tensor out = torch::empty({Cout, Hg, Wg}, fm.options().dtype(half ? torch::kFloat16 : torch::kFloat32));
+    torch::Tensor scratch = torch::empty({(long long)f3dgs_feature_decode_scratch_bytes(C, (int)Hg, (int)Wg, dec ? 1 : 0)}, fm.options().dtype(torch::kByte));
+    const int rc = f3dgs_feature_decode(C, H, W, Cout, (int)Hg, (int)Wg, fm.data_ptr<float>(), dec ? w.data_ptr<float>() : nullptr,
+                                        dec ? b.data_ptr<float>() : nullptr, out.data_ptr(), half ? 1 : 0,
+                                        dec ? scratch.data_ptr() : nullptr, current_stream(fm));
+    check_status(rc, "feature_decode");
+    return out;
+}
+
 void AdamStep(torch::Tensor& param, const torch::Tensor& grad, torch::Tensor& exp_avg, torch::Tensor& exp_avg_sq, double lr,
               double beta1, double beta2, double eps, int64_t step, const c10::optional<torch::Tensor>& row_mask) {
     TORCH_CHECK(param.is_cuda() && grad.is_cuda() && exp_avg.is_cuda() && exp_avg_sq.is_cuda(), "adam_step: HIP tensors only");
@@ -331,6 +357,7 @@ PYBIND11_MODULE(_C, m) {
     m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
     m.def("mark_visible", &markVisible);
     m.def("feature_l1", &FeatureL1);
+    m.def("feature_decode", &FeatureDecode);
     m.def("adam_step", &AdamStep, py::arg("param"), py::arg("grad"), py::arg("exp_avg"), py::arg("exp_avg_sq"), py::arg("lr"),
           py::arg("beta1"), py::arg("beta2"), py::arg("eps"), py::arg("step"), py::arg("row_mask") = py::none());
     m.def("adam_step_multi", &AdamStepMulti, py::arg("params"), py::arg("grads"), py::arg("exp_avgs"), py::arg("exp_avg_sqs"), py::arg("lrs"),

@@ -237,6 +237,10 @@ hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, cons
                              const float* bias, const float* gt, float* loss, float* d_feature_map, float* d_weight,
                              float* d_bias, char* scratch, hipStream_t s);
 
+size_t feature_decode_scratch_bytes(int C, int Hg, int Wg, bool decoder);
+hipError_t launch_feature_decode(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
+                                 const float* bias, void* out, bool half, char* scratch, hipStream_t s);
+
 // adam.hip
 void launch_adam_step(size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps,
                       int step, const uint8_t* row_mask, size_t width, hipStream_t s);

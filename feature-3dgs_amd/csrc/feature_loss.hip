@@ -18,6 +18,8 @@
 // The decoder is the one dense contraction next to the rasterizer (v_mfma_f32_32x32x2_f32: exact fp32, A/B one
 // value per lane, A[i = l&31][k = l>>5], B[k = l>>5][n = l&31], D column l&31, rows (r&3)+8(r>>2)+4(l>>5)).
 
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace f3dgs {
@@ -236,6 +238,104 @@ fl_decoder_kernel(int N, int Np, int Cout, const float* __restrict__ X, const fl
     if (lane == 0) L.red[w] = loss;
     __syncthreads();
     if (threadIdx.x == 0) loss_partial[blockIdx.x] = (L.red[0] + L.red[1] + L.red[2] + L.red[3]) * inv_n;
+}
+
+// ---- forward-only decode (inference side, render.py:169-171): phase A of the kernel above, the decoded map written out ----
+// y^T[co][px] = W[co][:] . X[px][:] + b[co]; a lane holds column px and rows co(r, h): 32 consecutive pixels per half-wave
+// and row -> 128-byte (fp32) or 64-byte (fp16) runs of the (Cout, Hg, Wg) output.
+template <int C, bool HALF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+fl_decode_kernel(int N, int Cout, const float* __restrict__ X, const float* __restrict__ Wd, const float* __restrict__ bias,
+                 void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GemmLds<C>& L = *reinterpret_cast<GemmLds<C>*>(smem);
+    constexpr int HC = C / 2;
+    constexpr int LPT = (32 * C / 4) / 256;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int p = blockIdx.x * 128 + 32 * w + li;
+    const bool p_ok = p < N;
+    float xr[HC];
+    {
+        const float4* src = reinterpret_cast<const float4*>(X + (size_t)(p_ok ? p : 0) * C + h * HC);
+#pragma unroll
+        for (int k = 0; k < HC / 4; k++) {
+            const float4 v = src[k];
+            xr[4 * k] = v.x; xr[4 * k + 1] = v.y; xr[4 * k + 2] = v.z; xr[4 * k + 3] = v.w;
+        }
+    }
+    auto load_tile = [&](int co0, float4 (&v)[LPT]) {
+#pragma unroll
+        for (int k = 0; k < LPT; k++) {
+            const int e = (threadIdx.x + 256 * k) * 4, r = e / C, c = e - r * C;
+            v[k] = co0 + r < Cout ? *reinterpret_cast<const float4*>(Wd + (size_t)(co0 + r) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf, const float4 (&v)[LPT]) {
+#pragma unroll
+        for (int k = 0; k < LPT; k++) {
+            const int e = (threadIdx.x + 256 * k) * 4, r = e / C, c = e - r * C;
+            *reinterpret_cast<float4*>(&L.Ws[buf][r][c]) = v[k];
+        }
+    };
+    float4 wnext[LPT];
+    load_tile(0, wnext);
+    store_tile(0, wnext);
+    __syncthreads();
+    const int ntiles = (Cout + 31) / 32;
+    for (int t = 0; t < ntiles; t++) {
+        const int co0 = 32 * t, buf = t & 1;
+        if (t + 1 < ntiles) load_tile(co0 + 32, wnext);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + mfma_row(r, h);
+            acc[r] = co < Cout ? bias[co] : 0.f;
+        }
+        const float* wrow = &L.Ws[buf][li][h * HC];
+#pragma unroll
+        for (int s4 = 0; s4 < HC / 4; s4++) {
+            const float4 a = *reinterpret_cast<const float4*>(wrow + 4 * s4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xr[4 * s4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xr[4 * s4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xr[4 * s4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xr[4 * s4 + 3], acc, 0, 0, 0);
+            if ((s4 & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + mfma_row(r, h);
+            if (p_ok && co < Cout) {
+                if constexpr (HALF) reinterpret_cast<__half*>(out)[(size_t)co * N + p] = __float2half_rn(acc[r]);
+                else reinterpret_cast<float*>(out)[(size_t)co * N + p] = acc[r];
+            }
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1, wnext);
+        __syncthreads();
+    }
+}
+
+// resize only (no decoder): pixel-major X -> (C, Hg, Wg), optionally fp16.  grid (ceil(N / 64), ceil(C / 32))
+template <bool HALF>
+__global__ void __launch_bounds__(256)
+fl_resize_out_kernel(ResizeGeom g, int C, const float* __restrict__ fm, void* __restrict__ out) {
+    const int N = g.Hg * g.Wg;
+    const int p = blockIdx.x * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;
+    if (p >= N) return;
+    const int yo = p / g.Wg, xo = p - yo * g.Wg;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    taps(yo, g.sy, g.H, y0, y1, ly0, ly1);
+    taps(xo, g.sx, g.W, x0, x1, lx0, lx1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = blockIdx.y * 32 + cg * 8 + k;
+        if (c >= C) continue;
+        const float* pl = fm + (size_t)c * g.H * g.W;
+        const float v = ly0 * (lx0 * pl[y0 * g.W + x0] + lx1 * pl[y0 * g.W + x1]) + ly1 * (lx0 * pl[y1 * g.W + x0] + lx1 * pl[y1 * g.W + x1]);
+        if constexpr (HALF) reinterpret_cast<__half*>(out)[(size_t)c * N + p] = __float2half_rn(v);
+        else reinterpret_cast<float*>(out)[(size_t)c * N + p] = v;
+    }
 }
 
 // ---- K3: dW = g_y^T X, db = sum g_y over a range of pixel tiles; grid (ceil(Cout / 128), splits) ------------------
@@ -496,6 +596,43 @@ size_t feature_l1_scratch_bytes(int C, int Cout, int Hg, int Wg, bool decoder) {
 }
 
 bool feature_l1_decoder_supported(int C) { return C == 32 || C == 64 || C == 128; }
+
+size_t feature_decode_scratch_bytes(int C, int Hg, int Wg, bool decoder) {
+    return decoder ? (((size_t)Hg * Wg * C * sizeof(float) + ALIGN - 1) & ~(ALIGN - 1)) : 0;
+}
+
+template <int C>
+static hipError_t run_decode(int N, int Cout, const float* X, const float* Wd, const float* bias, void* out, bool half, hipStream_t s) {
+    const size_t lds = sizeof(GemmLds<C>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fl_decode_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fl_decode_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (half) hipLaunchKernelGGL((fl_decode_kernel<C, true>), dim3((N + 127) / 128), dim3(256), lds, s, N, Cout, X, Wd, bias, out);
+    else hipLaunchKernelGGL((fl_decode_kernel<C, false>), dim3((N + 127) / 128), dim3(256), lds, s, N, Cout, X, Wd, bias, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_feature_decode(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
+                                 const float* bias, void* out, bool half, char* scratch, hipStream_t s) {
+    const int N = Hg * Wg;
+    ResizeGeom g;
+    g.H = H; g.W = W; g.Hg = Hg; g.Wg = Wg;
+    g.sy = Hg > 1 ? (float)(H - 1) / (float)(Hg - 1) : 0.f;
+    g.sx = Wg > 1 ? (float)(W - 1) / (float)(Wg - 1) : 0.f;
+    const dim3 grid1((N + 63) / 64, (C + 31) / 32);
+    if (!weight) {
+        if (half) hipLaunchKernelGGL(fl_resize_out_kernel<true>, grid1, dim3(256), 0, s, g, C, feature_map, out);
+        else hipLaunchKernelGGL(fl_resize_out_kernel<false>, grid1, dim3(256), 0, s, g, C, feature_map, out);
+        return hipGetLastError();
+    }
+    float* X = reinterpret_cast<float*>(scratch);
+    hipLaunchKernelGGL(fl_resize_kernel, grid1, dim3(256), 0, s, g, C, feature_map, X, nullptr, 0.f, nullptr);
+    if (C == 32) return run_decode<32>(N, Cout, X, weight, bias, out, half, s);
+    if (C == 64) return run_decode<64>(N, Cout, X, weight, bias, out, half, s);
+    if (C == 128) return run_decode<128>(N, Cout, X, weight, bias, out, half, s);
+    return hipErrorInvalidValue;
+}
 
 hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
                              const float* bias, const float* gt, float* loss, float* d_feature_map, float* d_weight,

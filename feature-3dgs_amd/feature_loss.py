@@ -50,3 +50,20 @@ def fused_feature_l1(feature_map: torch.Tensor, gt_feature_map: torch.Tensor, we
     w2 = weight.reshape(weight.shape[0], -1)
     return _FusedFeatureL1.apply(feature_map, gt_feature_map, w2, bias if bias is not None else torch.zeros(
         weight.shape[0], device=weight.device, dtype=weight.dtype))
+
+
+@torch.no_grad()
+def fused_feature_decode(feature_map: torch.Tensor, size, weight: Optional[torch.Tensor] = None,
+                         bias: Optional[torch.Tensor] = None, half: bool = False) -> torch.Tensor:
+    """Forward only (the inference side of the same ops, render.py:169-171 / :137-139 / :294-296):
+
+        feature_map = F.interpolate(feature_map.unsqueeze(0), size=size, mode='bilinear', align_corners=True).squeeze(0)
+        if speedup: feature_map = cnn_decoder(feature_map)
+
+    as one call; `half=True` returns fp16 as render.py stores the maps (`.half()`, :179).  Returns (Cout, Hg, Wg)."""
+    e = torch.Tensor([])
+    if weight is None:
+        return _C.feature_decode(feature_map, int(size[0]), int(size[1]), e, e, bool(half))
+    w2 = weight.reshape(weight.shape[0], -1)
+    b = bias if bias is not None else torch.zeros(weight.shape[0], device=weight.device, dtype=weight.dtype)
+    return _C.feature_decode(feature_map, int(size[0]), int(size[1]), w2, b, bool(half))

@@ -218,6 +218,16 @@ int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float*
                      float* d_bias, void* scratch, void* stream /* hipStream_t */);
 
 /*
+ * Forward-only counterpart (the inference side, render.py:169-171, :137-139, :294-296): the rendered feature map (C,H,W)
+ * is resized (bilinear, align_corners=True) to (Hg,Wg) and - if weight / bias are given - decoded by the 1x1 conv into
+ * `out` (Cout,Hg,Wg), fp32 or (out_is_half != 0) IEEE fp16 as render.py stores it.  Without a decoder Cout must equal C.
+ * With a decoder C must be 32, 64 or 128.  `scratch`: f3dgs_feature_decode_scratch_bytes(...) bytes (0 without a decoder).
+ */
+size_t f3dgs_feature_decode_scratch_bytes(int C, int Hg, int Wg, int has_decoder);
+int f3dgs_feature_decode(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
+                         const float* bias, void* out, int out_is_half, void* scratch, void* stream);
+
+/*
  * One torch.optim.Adam step (no weight decay, no amsgrad: the reference's configuration,
  * scene/gaussian_model.py:163-178) over one tensor of n floats, in place; `step` is the 1-based step count of that
  * tensor.  param / grad / exp_avg / exp_avg_sq are device pointers.

@@ -83,3 +83,27 @@ def test_fused_feature_l1_rejects_what_it_cannot_do():
         fused_feature_l1(torch.zeros(8, 8, 8, device=dev), torch.zeros(16, 4, 4, device=dev))
     with pytest.raises(Exception):           # CPU tensors: no silent fallback
         fused_feature_l1(torch.zeros(8, 8, 8), torch.zeros(8, 4, 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,H,W,Cout,Hg,Wg,decoder", CASES)
+@pytest.mark.parametrize("half", [False, True])
+def test_fused_feature_decode_matches_reference_ops(C, H, W, Cout, Hg, Wg, decoder, half):
+    """Forward only (render.py:169-171): F.interpolate(bilinear, align_corners=True) -> cnn_decoder, against the same two
+    PyTorch ops in fp64; fp32 output to 1e-5 of the map's scale, fp16 output (render.py:179 stores halves) to one half-ulp
+    of the fp64 value on top of that."""
+    import torch.nn.functional as F
+    from feature_loss import fused_feature_decode
+    fm, _gt, w, b = _case(C, H, W, Cout, Hg, Wg, decoder, 11)
+    x = F.interpolate(fm.double().unsqueeze(0), size=(Hg, Wg), mode="bilinear", align_corners=True).squeeze(0)
+    if decoder:
+        x = F.conv2d(x.unsqueeze(0), w.double().reshape(Cout, C, 1, 1), b.double()).squeeze(0)
+    dev = "cuda:0"
+    got = fused_feature_decode(fm.to(dev), (Hg, Wg), w.to(dev) if decoder else None, b.to(dev) if decoder else None, half=half)
+    assert got.shape == (Cout if decoder else C, Hg, Wg) and got.dtype == (torch.float16 if half else torch.float32)
+    scale = float(x.abs().max())
+    err = (got.double().cpu() - x).abs()
+    if half:
+        assert float((err - x.abs() * 2.0 ** -11).max()) <= 2e-5 * scale + 2.0 ** -25      # round-to-nearest half + subnormal step
+    else:
+        assert float(err.max()) <= 1e-5 * scale
