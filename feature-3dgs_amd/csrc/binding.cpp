@@ -18,6 +18,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
+#include <exception>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -64,10 +65,31 @@ py::object& feature_grad_hook() {
     static py::object* hook = new py::object(py::none());   // leaked on purpose: no destructor after interpreter exit
     return *hook;
 }
+// A Python exception must not unwind through the extern "C" frame of f3dgs_backward: it is parked here and rethrown by the
+// binding once the C call has returned and the callback registration has been cleared.
+std::exception_ptr& pending_hook_error() {
+    thread_local std::exception_ptr e;
+    return e;
+}
 void feature_ready_trampoline(void* ctx, void* /*stream*/) {
     py::object& hook = feature_grad_hook();
-    if (!hook.is_none()) hook(*static_cast<torch::Tensor*>(ctx));
+    if (hook.is_none() || pending_hook_error()) return;
+    try {
+        hook(*static_cast<torch::Tensor*>(ctx));
+    } catch (...) {
+        pending_hook_error() = std::current_exception();
+    }
 }
+// clears the thread-local callback registration on every way out of the backward binding
+struct FeatureCallbackGuard {
+    bool armed;
+    explicit FeatureCallbackGuard(bool on, void* ctx) : armed(on) {
+        if (armed) f3dgs_set_feature_grad_ready_callback(feature_ready_trampoline, ctx);
+    }
+    ~FeatureCallbackGuard() {
+        if (armed) f3dgs_set_feature_grad_ready_callback(nullptr, nullptr);
+    }
+};
 
 void* current_stream(const torch::Tensor& ref) {
     return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(ref.device().index()).stream();
@@ -166,8 +188,11 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     auto rad = radii.contiguous();
 
     const bool notify = !feature_grad_hook().is_none() && P > 0 && C > 0;
-    if (notify) f3dgs_set_feature_grad_ready_callback(feature_ready_trampoline, &dL_dsemantic_feature);
-    const int rc = f3dgs_backward(
+    pending_hook_error() = nullptr;
+    int rc;
+    {
+    FeatureCallbackGuard guard_cb(notify, &dL_dsemantic_feature);
+    rc = f3dgs_backward(
         P, degree, M, C, R, fptr(bg), W, H, fptr(m3), fptr(shs), fptr(col), fptr(sf), fptr(sc), scale_modifier, fptr(rot),
         fptr(cov), fptr(vm), fptr(pm), fptr(cp), tan_fovx, tan_fovy, P ? rad.data_ptr<int>() : nullptr,
         reinterpret_cast<const char*>(geomBuffer.data_ptr()), reinterpret_cast<const char*>(binningBuffer.data_ptr()),
@@ -178,7 +203,12 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
         (P && M) ? dL_dsh.data_ptr<float>() : nullptr, P ? dL_dscales.data_ptr<float>() : nullptr,
         P ? dL_drotations.data_ptr<float>() : nullptr, nullptr, P ? scratch.data_ptr() : nullptr, debug ? 1 : 0,
         current_stream(means3D));
-    if (notify) f3dgs_set_feature_grad_ready_callback(nullptr, nullptr);
+    }
+    if (pending_hook_error()) {
+        std::exception_ptr e = pending_hook_error();
+        pending_hook_error() = nullptr;
+        std::rethrow_exception(e);
+    }
     check_status(rc, "rasterize_gaussians_backward");
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dsemantic_feature, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
                            dL_dscales, dL_drotations);

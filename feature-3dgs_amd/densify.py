@@ -115,7 +115,12 @@ def _apply_plan(model, pool: RowPool, src_row: torch.Tensor, kind: torch.Tensor,
         t = tensor.detach()
         t = t if t.is_contiguous() else t.contiguous()
         out = pool.out(key, n_out, t)
-        srcs.append(t); dsts.append(out); modes.append(mode); ovs.append(override if override is not None else empty)
+        # a tensor without columns (sh_degree = 0: `_features_rest` is (P, 0, 3)) or without source rows has nothing to move:
+        # it only gets its correctly shaped (n_out, ...) view; the gather table holds the others
+        if t.numel() > 0 and t.shape[0] > 0 and out[:1].numel() > 0:
+            srcs.append(t); dsts.append(out); modes.append(mode); ovs.append(override if override is not None else empty)
+        elif n_out and out[:1].numel() > 0:
+            out[:n_out].zero_()
         return out
 
     for name, attr in GROUPS:
@@ -136,7 +141,7 @@ def _apply_plan(model, pool: RowPool, src_row: torch.Tensor, kind: torch.Tensor,
             if t.dtype != torch.float32:
                 raise TypeError(f"{attr}: float32 expected, got {t.dtype}")
             stat_out[attr] = (add(attr, t.reshape(t.shape[0], -1), _COPY), t.shape[1:])
-    if n_out:
+    if n_out and srcs:
         _C.densify_gather(src_row, kind, override_row, srcs, dsts, ovs, modes)
 
     for name, attr, p, out_p, st, out_m, out_v in placed:
@@ -227,3 +232,32 @@ def densify_and_prune(model, max_grad: float, min_opacity: float, extent: float,
     n_out = int(src_row.numel())
     return {"cloned": int(clone_src.numel()), "split": int(sel.numel()),
             "pruned": int(src2.numel() - sel.numel() + child_src.numel() - n_out), "points": n_out}
+
+
+@torch.no_grad()
+def compact(model) -> None:
+    """After a densification every parameter, Adam moment and statistic is a VIEW `buffer[:n]` of a capacity-sized RowPool
+    buffer (that is what keeps the shapes stable).  Two consequences the reference's fresh exact-size tensors do not have:
+    `torch.save(model.capture())` / `optimizer.state_dict()` serialise the whole underlying storage (~1.5x, with stale rows),
+    and a tensor held across TWO densifications is overwritten when its buffer is reused.  `compact(model)` replaces every
+    one of them by an exact-size clone (same values, optimizer state re-keyed) - call it before capturing a checkpoint, or
+    before handing tensors to code that keeps them."""
+    opt = getattr(model, "optimizer", None)
+    group_of = {g["name"]: g for g in opt.param_groups} if opt is not None else {}
+    for name, attr in GROUPS:
+        p = getattr(model, attr)
+        new_p = nn.Parameter(p.detach().clone().requires_grad_(True))
+        g = group_of.get(name)
+        if g is not None:
+            st = opt.state.pop(g["params"][0], None)
+            g["params"][0] = new_p
+            if st is not None:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k in st:
+                        st[k] = st[k].clone()
+                opt.state[new_p] = st
+        setattr(model, attr, new_p)
+    for attr in ("xyz_gradient_accum", "denom", "max_radii2D"):
+        t = getattr(model, attr, None)
+        if isinstance(t, torch.Tensor):
+            setattr(model, attr, t.clone())

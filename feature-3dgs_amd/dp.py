@@ -29,6 +29,8 @@ Backends: "nccl" (= RCCL on ROCm) on GPUs; "gloo" for the CPU tests.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, Iterable, List, Optional, Sequence
 
 import torch
@@ -93,6 +95,9 @@ class GradBuckets:
             grads[k].copy_(self.buckets[b][o:o + n].view(shp))
 
 
+_DEBUG = os.environ.get("F3DGS_DP_DEBUG", "0") not in ("", "0")     # cross-rank agreement checks (extra collectives)
+
+
 def _check(grads: Dict[str, torch.Tensor]) -> List[str]:
     keys = []
     for k, v in grads.items():
@@ -122,9 +127,12 @@ def all_reduce_gaussian_grads(grads: Dict[str, torch.Tensor], group=None, bucket
         return grads
     skip = set(skip)
     keys = [k for k in _check(grads) if k not in skip]
-    big = [k for k in keys if grads[k].numel() * 4 >= direct_bytes and grads[k].is_contiguous()]
+    # which tensors go alone and which share the bucket is decided by SHAPE only: every rank must issue the same collectives
+    # in the same order (a rank-local property such as contiguity must not change the schedule)
+    big = [k for k in keys if grads[k].numel() * 4 >= direct_bytes]
     small = [k for k in keys if k not in big]
-    works = [dist.all_reduce(grads[k], op=dist.ReduceOp.SUM, group=group, async_op=True) for k in big]
+    staged = {k: grads[k].contiguous() for k in big if not grads[k].is_contiguous()}
+    works = [dist.all_reduce(staged.get(k, grads[k]), op=dist.ReduceOp.SUM, group=group, async_op=True) for k in big]
     if small:
         if buckets is None:
             buckets = GradBuckets({k: grads[k].shape for k in small}, grads[small[0]].device, bucket_bytes)
@@ -132,6 +140,8 @@ def all_reduce_gaussian_grads(grads: Dict[str, torch.Tensor], group=None, bucket
         works += buckets.all_reduce(group, async_op=True)
     for w in works:
         w.wait()
+    for k, t in staged.items():
+        grads[k].copy_(t)
     if small:
         buckets.unpack_into(grads)
     return grads
@@ -280,12 +290,36 @@ def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.
     for v in leaves.values():
         v.grad = None
     view_ids = list(view_ids)
+
+    def all_grads():
+        # the SAME key list on every rank: a leaf this rank's view did not reach (no gradient) contributes zeros - the
+        # collective schedule is derived from the leaves, never from which gradients happen to exist locally
+        if _active(group):
+            for v in leaves.values():
+                if v.grad is None:
+                    v.grad = torch.zeros_like(v)
+        return {k: v.grad for k, v in leaves.items() if v.grad is not None}
+
     if overlap and len(view_ids) == 1 and _active(group):
         with FeatureGradOverlap(group) as ov:
             render_and_backward(view_ids[0])
-            grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
-            return all_reduce_gaussian_grads(grads, group=group, buckets=buckets, skip=ov.reduced((feature_key,)))
+            grads = all_grads()
+            feat = leaves.get(feature_key)
+            if feat is None or feat.numel() == 0:
+                return all_reduce_gaussian_grads(grads, group=group, buckets=buckets)
+            # exactly ONE all-reduce of the feature gradient per rank and step: started inside the backward pass where the
+            # hook fired; a rank whose backward pass did not reach the op (or produced no feature gradient) issues the
+            # matching one here, so that its peers' collective is not left without a partner
+            if not ov.reduced((feature_key,)):
+                dist.all_reduce(grads[feature_key], op=dist.ReduceOp.SUM, group=group)
+            if _DEBUG:
+                fired = torch.tensor([float(bool(ov.reduced((feature_key,))))], device=grads[feature_key].device)
+                lo = fired.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+                dist.all_reduce(fired, op=dist.ReduceOp.MAX, group=group)
+                if float(lo) != float(fired):
+                    raise RuntimeError("dp_step: the feature-gradient hook fired on some ranks only (F3DGS_DP_DEBUG)")
+            return all_reduce_gaussian_grads(grads, group=group, buckets=buckets, skip=(feature_key,))
     for vid in view_ids:
         render_and_backward(vid)
-    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
-    return all_reduce_gaussian_grads(grads, group=group, buckets=buckets)
+    return all_reduce_gaussian_grads(all_grads(), group=group, buckets=buckets)

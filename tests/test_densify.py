@@ -226,6 +226,59 @@ def test_buffers_keep_their_shape_between_densifications():
     assert ptr0 in {b.untyped_storage().data_ptr() for b in pool._bufs["_xyz"]}
 
 
+def test_sh_degree_zero_model_densifies_and_prunes():
+    """A model without higher SH bands keeps `_features_rest` as (P, 0, 3): the reference's mask / cat code handles the empty
+    columns; here such a tensor (and its Adam moments) stays out of the gather table and only gets its (n, 0, 3) shape
+    (ADVICE r2)."""
+    import densify
+    from fused_adam import FusedAdam
+    tensors, stats = _tensors(3000, 8, seed=4)
+    tensors["_features_rest"] = tensors["_features_rest"][:, :0].contiguous()
+    m = _model(None, tensors, stats, FusedAdam)
+    assert m._features_rest.shape == (3000, 0, 3)
+    plan = densify.densify_and_prune(m, 0.0002, 0.005, 5.0, 20)
+    n = plan["points"]
+    assert n > 0 and m._features_rest.shape == (n, 0, 3) and m._xyz.shape == (n, 3)
+    st = m.optimizer.state[m._features_rest]
+    assert st["exp_avg"].shape == (n, 0, 3) and st["exp_avg_sq"].shape == (n, 0, 3)
+    densify.prune_points(m, torch.arange(n, device="cuda:0") % 3 == 0)
+    assert m._features_rest.shape[0] == m._xyz.shape[0] == n - (n + 2) // 3
+    for _, a in GROUPS:
+        p = getattr(m, a)
+        p.grad = torch.randn_like(p) * 0.01
+    m.optimizer.step()
+    assert torch.isfinite(m._xyz).all()
+
+
+def test_compact_gives_exact_size_storage_for_checkpoints(tmp_path):
+    """After a densification the tensors are views of capacity-sized pool buffers: torch.save would write the whole storage.
+    densify.compact(model) replaces them by exact-size clones with the optimizer state re-keyed."""
+    import os
+    import densify
+    from fused_adam import FusedAdam
+    tensors, stats = _tensors(6000, 8, seed=9)
+    m = _model(None, tensors, stats, FusedAdam)
+    densify.densify_and_prune(m, 0.0002, 0.005, 5.0, 20, pool=densify.RowPool(growth=2.0))
+    n = m._xyz.shape[0]
+    assert m._xyz.untyped_storage().nbytes() > 1.5 * n * 3 * 4          # a view of a larger buffer
+    before = {a: getattr(m, a).detach().clone() for _, a in GROUPS}
+    mom = {a: m.optimizer.state[getattr(m, a)]["exp_avg"].clone() for _, a in GROUPS}
+    densify.compact(m)
+    for _, a in GROUPS:
+        p = getattr(m, a)
+        assert torch.equal(p, before[a]) and p.untyped_storage().nbytes() == p.numel() * 4
+        st = m.optimizer.state[p]
+        assert torch.equal(st["exp_avg"], mom[a]) and st["exp_avg"].untyped_storage().nbytes() == p.numel() * 4
+    f = tmp_path / "ckpt.pt"
+    torch.save({a: getattr(m, a) for _, a in GROUPS}, f)
+    exact = sum(getattr(m, a).numel() * 4 for _, a in GROUPS)
+    assert os.path.getsize(f) < 1.05 * exact + 65536
+    for _, a in GROUPS:           # and the optimizer still steps the new parameters
+        p = getattr(m, a)
+        p.grad = torch.randn_like(p) * 0.01
+    m.optimizer.step()
+
+
 def test_c_abi_rejects_bad_plans():
     import ctypes
     import os

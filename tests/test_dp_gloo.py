@@ -135,3 +135,46 @@ def test_world_size_one_is_a_no_op():
     assert dp.all_reduce_gaussian_grads(g) is g
     s = dp.reduce_scatter_gaussian_grads({"a": g["a"]})
     assert s["a"] is g["a"] and dp.shard_range(10, 0, 1) == (0, 10)
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    """Rank 1's step leaves one leaf without a gradient and hands in a NON-contiguous large gradient: the ranks must still
+    issue the same collectives (the schedule follows the leaves' shapes, not what exists locally)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "feature-3dgs_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dp
+    leaves = {"a": torch.zeros(50, 3, requires_grad=True), "big": torch.zeros(64, 40, requires_grad=True),
+              "c": torch.zeros(50, 1, requires_grad=True)}
+
+    def render_and_backward(_vid):
+        leaves["a"].grad = torch.full((50, 3), float(rank + 1))
+        base = torch.arange(40 * 64, dtype=torch.float32).reshape(40, 64) * (rank + 1)
+        leaves["big"].grad = base.t() if rank == 1 else base.t().contiguous()      # rank 1: a transposed view
+        if rank == 0:
+            leaves["c"].grad = torch.ones(50, 1)                                   # rank 1: no gradient for "c"
+
+    dp.dp_step(render_and_backward, leaves, [rank])
+    # the same through the explicit call with a tiny `direct_bytes`, so that "big" travels alone
+    g = {k: v.grad.clone() for k, v in leaves.items()}
+    g["big"] = g["big"].t().contiguous().t() if rank == 0 else g["big"]
+    dp.all_reduce_gaussian_grads(g, direct_bytes=1024)
+    np.savez(os.path.join(out_dir, f"u{rank}.npz"), a=leaves["a"].grad.numpy(), big=leaves["big"].grad.numpy(), c=leaves["c"].grad.numpy(),
+             big2=np.ascontiguousarray(g["big"].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_schedule_does_not_depend_on_local_gradients(tmp_path):
+    world = 2
+    mp.spawn(_uneven_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    base = np.arange(40 * 64, dtype=np.float32).reshape(40, 64).T
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"u{rank}.npz"))
+        assert np.allclose(got["a"], 3.0)
+        assert np.allclose(got["big"], 3.0 * base)
+        assert np.allclose(got["c"], 1.0)                   # rank 1 contributed zeros instead of skipping the collective
+        assert np.allclose(got["big2"], 2.0 * 3.0 * base)   # every rank holds the first SUM: reduced again = x world
