@@ -15,7 +15,7 @@ import os
 import sys
 from collections import defaultdict
 
-HEAVY = {"render_bwd": "render_backward_kernel", "render_fwd": "render_forward", "preprocess": "preprocess_kernel",
+HEAVY = {"render_bwd": "render_backward", "render_fwd": "render_forward", "preprocess": "preprocess_kernel",
          "preprocess_bwd": "preprocess_backward_kernel"}
 
 

@@ -1,12 +1,17 @@
 #!/bin/bash
 # GPU box: collect everything that goes under profiles/ for one round (run through gpurun; output in gpurun_out/<tag>).
 #   tools/round_profiles.sh r02
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 # 1. bench lines: c3 full (driver contract), the other BASELINE configs single-GPU
 timeout 300 python bench.py > $OUT/${TAG}_bench_c3.json 2> $OUT/bench_c3.err
 for c in c1 c2 c4 c5; do timeout 200 python bench.py --config $c --no-cpu-baseline --steps 20 --warmup 5 > $OUT/${TAG}_bench_$c.json 2> $OUT/bench_$c.err; done
+# 1b. the north-star-literal configuration (no matrix pipe anywhere) and config c5 with densification on
+timeout 200 python bench.py --no-cpu-baseline --valu > $OUT/${TAG}_bench_c3_valu.json 2> $OUT/bench_c3_valu.err
+timeout 300 python bench.py --config c5 --densify-every 5 --steps 40 --warmup 10 > $OUT/${TAG}_bench_c5_densify.json 2> $OUT/bench_c5_densify.err
+timeout 200 python tools/adam_bench.py > $OUT/${TAG}_adam.txt 2>&1
+timeout 200 python tools/adam_bench.py 5000000 128 >> $OUT/${TAG}_adam.txt 2>&1
 # 2. kernel trace of the SAME command as the bench (rocprofv3 --kernel-trace --stats)
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python $ROOT/bench.py --no-cpu-baseline > $OUT/kt_bench.json 2> $OUT/kt.err
