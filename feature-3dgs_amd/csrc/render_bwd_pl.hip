@@ -46,6 +46,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // wave - here the fire-and-forget atomics of the flush, microseconds under load - which nothing in the workgroup reads.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The lane index, recomputed where it is asked for: values derived from it inside a loop are rebuilt per iteration (two
+// instructions) instead of living in registers across the whole walk - the B operand needs the room.
+__device__ __forceinline__ int fresh_lane() {
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
+
 #ifdef F3DGS_DEV
 #define PL_DEV_SKIP(bit) (a.dev & (bit))     // 1: no global atomics  2: no phase 1  4: no matrix instructions  16: no flush
 #define PL_PHASE_BEGIN() unsigned long long ph_t0_ = (a.dev & 8) ? __builtin_readcyclecounter() : 0ull; unsigned long long cyc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -61,10 +69,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #endif
 
 constexpr int PL_CAP = 16;         // list entries per chunk = rows of one 16x16x4 matrix instruction
-constexpr int PL_ROW = 68;         // dwords per pixel-block row of an A tile (16 entries x 4 px + one 4-dword skew slot)
+constexpr int PL_ROW = 64;         // dwords per pixel-block row of an A tile (16 entries x 4 px, XOR-swizzled)
 constexpr int PL_TILE = 16 * PL_ROW;
 constexpr int PL_WIN = 64;         // list entries per window
-constexpr int PL_FS = 68;          // dwords per entry of the flush tile: 32 (64) feature sums; 4 colour / depth sums + 4 x 6 moments
+constexpr int PL_FS = 68;          // dwords per entry of the flush tile: 32 (64) feature sums; 4 colour / depth sums + 4 x 6 moments; 8 of splat data
 constexpr int PL_SP = 260;         // dwords per plane of the staging image (16 x 16 pixels + 4: plane offset of 4 banks)
 constexpr int PL_STAGE_PLANES = 38;
 
@@ -76,20 +84,21 @@ struct PlRec {
 };
 
 // A tiles: element (row i, column c) of a quadrant's tile, with c = 16 u + 4 k + m - the pixel that matrix step
-// t = 4 u + m contracts at K index k - lives at dword (c >> 2) * 68 + (i + 1 - ((c >> 2) & 1)) * 4 + (c & 3): the 16 rows
-// of one pixel block are 16 bytes apart, so the operand read of lane (i, k) - one 16-byte read per u - meets the other
-// lanes of its 16-lane service group on sixteen different 4-bank groups (the one-slot skew between even and odd pixel
-// blocks lines the two k values of a group up), and the phase-1 stores (64 pixels of one row) are at most 2-way conflicted.
+// t = 4 u + m contracts at K index k - lives in pixel block b = c >> 2 at dword 64 b + 4 (i ^ (b & 7)) + (c & 3): the 16
+// rows of a pixel block are 16 bytes apart and rotated by an XOR with the block index, so that the operand read of lane
+// (i, k) - one 16-byte read per u - meets the other lanes of its 16-lane service group ({0-3, 12-15, 20-27}, ...) on sixteen
+// different 4-bank groups, and the phase-1 stores (the 64 pixels of one row: sixteen blocks) are 2-way conflicted at most.
+// The XOR touches address bits 4..6 only: a row's address is (lane base) ^ (16 row), one instruction per entry.
 struct PlShared {
     float wt[4][PL_TILE];       // per quadrant: blend weights
     float st[4][PL_TILE];       //               s = op G dL/dalpha
-    PlRec rec[2][PL_WIN];       // double-buffered: the last flush of window w reads it while window w - 1 is stored
-    float ftile[PL_CAP * PL_FS];   // the chunk's sums, entry-major, as they leave for global memory
+    PlRec rec[PL_WIN];          // one window of records: read by phase 1 only (the flush has its own copy in the flush tile)
+    float ftile[PL_CAP * PL_FS];   // the chunk's sums, entry-major, as they leave for global memory; slots 60..67: splat data
     uint32_t wave_max[4];
     uint32_t touched[2];        // per chunk parity: rows that blended somewhere in the tile
-    uint32_t pad[10];
+    uint32_t pad[2];
 };
-static_assert(sizeof(PlShared) * 3 <= 160 * 1024, "three workgroups per CU");
+static_assert(sizeof(PlShared) * 4 <= 160 * 1024, "four workgroups per CU");
 static_assert(PL_STAGE_PLANES * PL_SP * 4 <= sizeof(PlShared), "staging image fits the aliased area");
 
 // GEO = true:  first channel window (up to 32 channels) + the ten geometric sums; column blocks of the waves: feature
@@ -245,9 +254,8 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 
     // LDS offsets (dwords): phase-1 store column of this lane's pixel, operand read base of this lane's (row, K index)
     const int ccol = 16 * (ly >> 1) + 4 * (lx & 3) + 2 * (ly & 1) + (lx >> 2);
-    const int wofs = (ccol >> 2) * PL_ROW + (1 - ((ccol >> 2) & 1)) * 4 + (ccol & 3);
-    const int rofs = kk * PL_ROW + (col + 1 - (kk & 1)) * 4;
-    float* const my_wt = &L.wt[q][wofs];
+    const uint32_t wofs_b = (uint32_t)(((ccol >> 2) * PL_ROW + ((ccol >> 2) & 7) * 4 + (ccol & 3)) * 4);     // bytes, row 0
+    char* const my_wt = reinterpret_cast<char*>(&L.wt[q][0]);
     constexpr int ST_OFS = 4 * PL_TILE;             // st[q] - wt[q], dwords
     const float wx0 = (float)(tx0 + qx), wx1 = wx0 + 7.f, wy0 = (float)(ty0 + qy), wy1 = wy0 + 7.f;
     if (!PL_DEV_SKIP(32)) PL_PHASE_END(0);
@@ -267,14 +275,14 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     float4 part_cur = load_part(n_win - 1, gid_cur);
     int parity = 0;
 
-    // records of window w -> LDS buffer w & 1 (by the three loader waves), the next window's requests go out
+    // records of window w -> LDS (by the three loader waves), the next window's requests go out
     auto store_window = [&](int w) {
         if (q < 3 && w >= 0) {
             float4 v = part_cur;
             if (q == 0) { v.z *= CONIC_SCALE_AC; v.w *= CONIC_SCALE_B; }
             else if (q == 1) { v.x *= CONIC_SCALE_AC; }
             else { v.w = __uint_as_float(gid_cur); }
-            reinterpret_cast<float4*>(&L.rec[w & 1][lane])[q] = v;
+            reinterpret_cast<float4*>(&L.rec[lane])[q] = v;
         }
         gid_cur = gid_nxt;
         part_cur = load_part(w - 1, gid_cur);
@@ -284,8 +292,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     lds_barrier();
 
     for (int w = n_win - 1; w >= 0; w--) {
-        PlRec* const rec = L.rec[w & 1];
-        bool first_chunk = true;
+        PlRec* const rec = L.rec;
         PL_PHASE_END(1);
 
         const uint32_t k0 = (uint32_t)w * PL_WIN;
@@ -300,6 +307,19 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             // of the next pair in flight while a pair is computed.  A quadrant whose pixels all ended behind the chunk skips it.
             const uint32_t pos_hi = k0 + (uint32_t)(PL_WIN - 1 - 16 * j);      // list position of row 0
             uint32_t tm = 0;      // rows that blended somewhere in this quadrant; bit 16 + q: the quadrant's tiles are live
+            if (lane < 4) {
+                // what the flush of this wave's four rows needs of their splats, kept beside the sums: the record window may
+                // be replaced while the chunk is flushed
+                const PlRec& rr = rec[16 * j + 4 * q + lane];
+                float* const info = &L.ftile[(4 * q + lane) * PL_FS];
+                if constexpr (GEO) {
+                    const float4 i0 = rr.q0, i1 = rr.q1;
+                    *reinterpret_cast<float4*>(info + 60) = i0;
+                    *reinterpret_cast<float4*>(info + 64) = make_float4(i1.x, i1.y, rr.q2.w, 0.f);
+                } else {
+                    info[64] = rr.q2.w;
+                }
+            }
             if (pos_hi - 15 < my_max && !PL_DEV_SKIP(2)) {
                 const PlRec* rc = &rec[16 * j];
                 auto phase1 = [&](auto nec, auto prefc) {
@@ -354,11 +374,12 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                         for (int k = 0; k < NE; k++) {
                             const float Tb = T * f[k];              // transmittance in front of this splat
                             const float wv = al[k] * Tb;
-                            my_wt[4 * (NE * p + k)] = wv;
+                            float* const wp = reinterpret_cast<float*>(my_wt + (wofs_b ^ (uint32_t)(16 * (NE * p + k))));
+                            wp[0] = wv;
                             if constexpr (GEO) {
                                 const float dL_dalpha = fmaf(Tb, qd[k], -(S * f[k]));
                                 S = fmaf(wv, qd[k], S);
-                                my_wt[4 * (NE * p + k) + ST_OFS] = au[k] * dL_dalpha;
+                                wp[ST_OFS] = au[k] * dL_dalpha;
                             }
                             T = Tb;
                         }
@@ -370,11 +391,10 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             if (tm && lane == 0) atomicOr(&L.touched[parity], tm);
             PL_PHASE_END(2);
             lds_barrier();                                                  // B_a: the A tiles of the chunk are complete
-            if (first_chunk) {
-                // the other record buffer is free now (every wave has flushed the last chunk of window w + 1), and the loads of
-                // window w - 1 - requested a window ago - are older than any atomic still in flight: no wait on the flush traffic
+            if (j == PL_WIN / PL_CAP - 1) {
+                // phase 1 of the window's last chunk is done everywhere: the record buffer is free.  The loads of window w - 1 -
+                // requested a window ago - are older than any atomic still in flight: no wait on the flush traffic
                 store_window(w - 1);
-                first_chunk = false;
             }
             PL_PHASE_END(1);
 
@@ -382,14 +402,17 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             const uint32_t tt = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.touched[parity]);
             if (active && (tt & 0xFFFFu) != 0) {
                 f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-                const float* abase = (use_s ? &L.st[0][0] : &L.wt[0][0]) + rofs;
+                const float* abase = (use_s ? &L.st[0][0] : &L.wt[0][0]);
+                const int lane2 = fresh_lane();
+                const int col = lane2 & 15, kk = lane2 >> 4;
+                const int rofs0 = kk * PL_ROW + (col ^ kk) * 4, rofs1 = rofs0 ^ 16;                          // even / odd u
                 const int fs_row0 = (4 * kk) * PL_FS;
 #pragma unroll
                 for (int qd = 0; qd < 4; qd++) {
                     if ((tt >> (16 + qd)) & 1u) {              // the quadrant's tiles were written for this chunk
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
-                            const float4 av = *reinterpret_cast<const float4*>(abase + qd * PL_TILE + u * 4 * PL_ROW);
+                            const float4 av = *reinterpret_cast<const float4*>(abase + ((u & 1) ? rofs1 : rofs0) + qd * PL_TILE + u * 4 * PL_ROW);
                             if (PL_DEV_SKIP(4)) { acc0[0] += av.x + av.y + av.z + av.w; continue; }
                             // two accumulators alternate: no back-to-back dependent matrix instructions
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Bop[qd][4 * u + 0], acc0, 0, 0, 0);
@@ -425,13 +448,15 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             if ((tt & 0xFFFFu) != 0 && !PL_DEV_SKIP(16)) {
                 const uint32_t m4 = (tt >> (4 * q)) & 0xFu;
                 float* const F = &L.ftile[(4 * q) * PL_FS];
-                const PlRec* const rq = &rec[16 * j + 4 * q];
+                constexpr int GID_SLOT = GEO ? 66 : 64;
+                const int lane = fresh_lane();
                 if (m4 != 0) {
                     if constexpr (GEO) {
                         // sixteen lanes: (row, quadrant) - the quadrant's moments re-centred on the splat mean (dx = ax - u), then summed
                         const int r = (lane >> 2) & 3, qd = lane & 3;
                         float* row = F + r * PL_FS;
-                        const float4 i0 = rq[r].q0, i1 = rq[r].q1;
+                        const float4 i0 = *reinterpret_cast<const float4*>(row + 60);
+                        const float2 i1 = *reinterpret_cast<const float2*>(row + 64);            // conic c', opacity
                         const float ax = i0.x - (float)(tx0 + (qd & 1) * 8) - 3.5f, ay = i0.y - (float)(ty0 + (qd >> 1) * 8) - 3.5f;
                         const float* mq = row + 36 + 6 * qd;
                         const float N0 = mq[0], N1x = mq[1], N1y = mq[2], N2xx = mq[3], N2xy = mq[4], N2yy = mq[5];
@@ -468,19 +493,19 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                             for (int h = 0; h < 2; h++) {
                                 const int rw = 2 * h + rr;
                                 const float v = F[rw * PL_FS + ch];
-                                const uint32_t gg = __float_as_uint(rq[rw].q2.w);
+                                const uint32_t gg = __float_as_uint(F[rw * PL_FS + GID_SLOT]);
                                 if (((m4 >> rw) & 1u) && ch < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + ch, v);
                             }
                             const int rw = lane >> 4, k16 = lane & 15;
                             const float v = F[rw * PL_FS + 32 + min(k16, 9)];
-                            const uint32_t gg = __float_as_uint(rq[rw].q2.w);
+                            const uint32_t gg = __float_as_uint(F[rw * PL_FS + GID_SLOT]);
                             if (((m4 >> rw) & 1u) && k16 < 10) unsafeAtomicAdd(a.grec + (size_t)gg * GREC + k16, v);
                         }
                     } else if (!PL_DEV_SKIP(1)) {
 #pragma unroll
                         for (int rw = 0; rw < 4; rw++) {
                             const float v = F[rw * PL_FS + lane];
-                            const uint32_t gg = __float_as_uint(rq[rw].q2.w);
+                            const uint32_t gg = __float_as_uint(F[rw * PL_FS + GID_SLOT]);
                             if (((m4 >> rw) & 1u) && lane < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + lane, v);
                         }
                     }
@@ -499,7 +524,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 }
 
 template <bool GEO, int P1_NE, bool P1_PREF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) render_backward_pl_kernel(BwdArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel(BwdArgs a) {
     render_backward_pl_body<GEO, P1_NE, P1_PREF>(a);
 }
 
@@ -508,19 +533,16 @@ void launch_pl(const BwdArgs& a, hipStream_t s) {
 #ifdef F3DGS_DEV
     if (a.dev & 8) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_backward_pl_kernel<GEO, 2, true>, 256, sizeof(PlShared));
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_backward_pl_kernel<GEO, 1, true>, 256, sizeof(PlShared));
         fprintf(stderr, "[f3dgs dev] pixel-lane backward: %d workgroups per CU by the occupancy query, %zu bytes of LDS\n", nb, sizeof(PlShared));
     }
 #endif
 #ifdef F3DGS_DEV
     const int variant = (a.dev >> 8) & 7;
-    if (variant == 1) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 4, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
-    if (variant == 2) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 4, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
-    if (variant == 3) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 8, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
-    if (variant == 4) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 2, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
-    if (variant == 5) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
+    if (variant == 4) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
+    if (variant == 5) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 2, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
 #endif
-    hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 2, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a);
+    hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a);
 }
 
 }  // namespace
