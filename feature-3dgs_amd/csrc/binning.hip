@@ -163,21 +163,33 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 
     const size_t wbase = (size_t)blockIdx.x * CHUNK + (size_t)w * (ITEMS * 64);
     uint32_t key[ITEMS];
+    uint32_t val[REORDER ? ITEMS : 1];
     uint32_t rank[ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // every request of the chunk goes out first (the values are only needed by the LDS reorder: their latency hides
+    // behind the ranking)
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const size_t i = wbase + (size_t)k * 64 + lane;
+        key[k] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+        if constexpr (REORDER) val[k] = (vals_in && i < n) ? vals_in[i] : (uint32_t)i;
+    }
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const size_t i = wbase + (size_t)k * 64 + lane;
         const bool valid = i < n;
-        key[k] = valid ? keys_in[i] : 0xFFFFFFFFu;
         const uint32_t d = (key[k] >> shift) & (BINS - 1);
-        unsigned long long peers = __ballot(valid);
+        const unsigned long long vm = __ballot(valid);
+        uint32_t p_lo = (uint32_t)vm, p_hi = (uint32_t)(vm >> 32);
 #pragma unroll
         for (int b = 0; b < BITS; b++) {
-            const bool bit = (d >> b) & 1;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
+            // x: all ones where the lane's digit has bit b; a peer's bit equals it: peers &= ~(ballot ^ x) = ~ballot ^ x
+            const uint32_t x = 0u - ((d >> b) & 1u);
+            const unsigned long long nm = ~__ballot(x != 0u);
+            p_lo &= (uint32_t)nm ^ x;
+            p_hi &= (uint32_t)(nm >> 32) ^ x;
         }
+        const unsigned long long peers = ((unsigned long long)p_hi << 32) | p_lo;
         const uint32_t before = __popcll(peers & lt_mask);
         const uint32_t old = vcnt[w * BINS + d];
         if (valid && before == 0) vcnt[w * BINS + d] = old + (uint32_t)__popcll(peers);
@@ -222,7 +234,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
                 const uint32_t d = (key[k] >> shift) & (BINS - 1);
                 const uint32_t lp = cnt[w][d] + rank[k];
                 skey[lp] = key[k];
-                sval[lp] = vals_in ? vals_in[i] : (uint32_t)i;
+                if constexpr (REORDER) sval[lp] = val[k];
             }
         }
         __syncthreads();

@@ -257,8 +257,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     const uint32_t wofs_b = (uint32_t)(((ccol >> 2) * PL_ROW + ((ccol >> 2) & 7) * 4 + (ccol & 3)) * 4);     // bytes, row 0
     char* const my_wt = reinterpret_cast<char*>(&L.wt[q][0]);
     constexpr int ST_OFS = 4 * PL_TILE;             // st[q] - wt[q], dwords
-    const float wx0 = (float)(tx0 + qx), wx1 = wx0 + 7.f, wy0 = (float)(ty0 + qy), wy1 = wy0 + 7.f;
-    if (!PL_DEV_SKIP(32)) PL_PHASE_END(0);
+        if (!PL_DEV_SKIP(32)) PL_PHASE_END(0);
 
     // ---- record loader (waves 0..2: one 16-byte third of every record; lane = entry, entry 0 = farthest back) -------
     auto win_pos = [&](int w) -> uint32_t { return (uint32_t)(w * PL_WIN + PL_WIN - 1 - lane); };

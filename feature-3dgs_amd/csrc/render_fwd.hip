@@ -46,7 +46,14 @@ struct FwdArgs {
     int C;        // total feature channels (row stride of feat)
     int c0, nc;   // channel window handled by this launch
     int write_base;  // 1: also write colour / depth / final_T / n_contrib
+    int dev;         // development builds: work-skipping bits (128: no feature gathers  256: no matrix instructions  512: no alpha evaluation skip)
 };
+
+#ifdef F3DGS_DEV
+#define FW_DEV_SKIP(bit) (a.dev & (bit))
+#else
+#define FW_DEV_SKIP(bit) false
+#endif
 
 template <int CH, int PPL>
 __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
@@ -363,7 +370,8 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
         // and no data register is involved; one wait before the blend.
         constexpr int CHV = CH / 4;
         const bool vec_ok = (a.C & 3) == 0 && (a.c0 & 3) == 0;
-        if (vec_ok && a.nc == CH) {
+        if (FW_DEV_SKIP(128)) {
+        } else if (vec_ok && a.nc == CH) {
             using lds_ptr = __attribute__((address_space(3))) void*;
             using gbl_ptr = const __attribute__((address_space(1))) void*;
 #pragma unroll
@@ -401,6 +409,7 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
             float2 g1[GI];
             uint32_t pos_e[GI];
             bool live_e[GI];
+            float Bv[NP][NB];
 #pragma unroll
             for (int e = 0; e < GI; e++) {
                 live_e[e] = j + e < cnt;
@@ -410,6 +419,15 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                 const float4 tail = *reinterpret_cast<const float4*>(&ck.ent[je].co_c);
                 g1[e] = make_float2(tail.x, tail.y);
                 pos_e[e] = __float_as_uint(tail.z);
+            }
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                // B rows: instance j+2k for lanes 0-31, j+2k+1 for lanes 32-63 (a missing instance has w = 0 and
+                // re-reads row j so that stale LDS contents can never inject a NaN)
+                const int e0 = 2 * k;
+                const int rsel = (lane >> 5) ? (live_e[e0 + 1] ? j + e0 + 1 : j) : (live_e[e0] ? j + e0 : j);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) Bv[k][nb] = ck.feat[rsel * CH + (lane & 31) + 32 * nb];
             }
             // a quadrant whose 64 pixels are all saturated is skipped as a whole (wave-uniform branch)
             bool slot_live[PPL];
@@ -452,14 +470,10 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                     any_blend = any_blend || ok;
                 }
             }
-            if (__any(any_blend)) {
+            if (__any(any_blend) && !FW_DEV_SKIP(256)) {
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
-                    // B rows: instance j+2k for lanes 0-31, j+2k+1 for lanes 32-63 (a missing instance has w = 0 and
-                    // re-reads row j so that stale LDS contents can never inject a NaN)
                     const int e0 = 2 * k;
-                    const int rsel = (lane >> 5) ? (live_e[e0 + 1] ? j + e0 + 1 : j) : (live_e[e0] ? j + e0 : j);
-                    const int brow = rsel * CH + (lane & 31);
 #pragma unroll
                     for (int p = 0; p < PPL; p++) {
                         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[e0][p]),
@@ -467,9 +481,8 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                         const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) {
-                            const float Bv = ck.feat[brow + 32 * nb];
-                            acc[p][0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv, acc[p][0][nb], 0, 0, 0);
-                            acc[p][1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv, acc[p][1][nb], 0, 0, 0);
+                            acc[p][0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv[k][nb], acc[p][0][nb], 0, 0, 0);
+                            acc[p][1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv[k][nb], acc[p][1][nb], 0, 0, 0);
                         }
                     }
                 }
@@ -588,6 +601,11 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     a.final_T = final_T; a.n_contrib = n_contrib; a.out_color = out_color; a.out_feat = out_feat;
     a.out_depth = out_depth;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
+#ifdef F3DGS_DEV
+    a.dev = options().dev;
+#else
+    a.dev = 0;
+#endif
     const int ppl = options().fwd_ppl;
     const bool mf = options().feature_mfma != 0;
     if (C == 0) {
