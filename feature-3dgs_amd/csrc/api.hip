@@ -364,8 +364,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
 
     // instance offsets in depth order (three-kernel flavour only; the single-pass emit scans on the fly)
     if (!onesweep)
-        launch_exclusive_scan(geom.tiles_touched, order, geom.offsets, nullptr, (size_t)P, geom.scan_tmp, nullptr, 0,
-                              nullptr, s);
+        launch_offset_sums(geom.tiles_touched, order, (size_t)P, geom.scan_tmp, geom.scan_sub, s);
     HIP_TRY(hipEventSynchronize(rb.done));
     // [0] instances in our lists, [1] the reference's bounding-rectangle count
     const uint32_t counts[2] = {rb.host[0], rb.host[1]};
@@ -393,10 +392,11 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
         if ((rc = check_debug(debug, s, "tile sort"))) return rc;
         tm.mark("tile_sort");
     } else {
-        // all-ones = "no entry yet" for both halves of the encoded ranges (see BinState::ranges_enc)
-        HIP_TRY(hipMemsetAsync(bin.ranges_enc, 0xFF, tiles * sizeof(uint2), s));
-        if (N > 0) {
-            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, s);
+        if (N == 0) {
+            // all-ones = "no entry yet" for both halves of the encoded ranges (see BinState::ranges_enc)
+            HIP_TRY(hipMemsetAsync(bin.ranges_enc, 0xFF, tiles * sizeof(uint2), s));
+        } else {
+            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, bin.ranges_enc, s);   // presets the ranges too
             if ((rc = check_debug(debug, s, "emit"))) return rc;
             tm.mark("emit");
             // the final pass also records the tile ranges
@@ -614,7 +614,6 @@ int f3dgs_debug_read(const char* what, int P, int C, int R, int width, int heigh
     else if (w == "tiles_touched") { src = geom.tiles_touched; bytes = (size_t)P * 4; }
     else if (w == "depth_key") { src = geom.depth_key; bytes = (size_t)P * 4; }
     else if (w == "order") { src = geom.val_a; bytes = (size_t)P * 4; }
-    else if (w == "offsets") { src = geom.offsets; bytes = (size_t)P * 4; }
     else if (w == "counters") { src = geom.counters; bytes = 16 * 4; }
     else if (w == "point_list") { src = bin.point_list; bytes = (size_t)n_list * 4; }
     else if (w == "tile_sorted") { src = bin.tile_sorted; bytes = (size_t)n_list * 4; }

@@ -23,17 +23,31 @@ namespace f3dgs {
 
 namespace {
 
-// ---------------- generic exclusive scan (reduce / spine / apply) ------------------------------------
+// ---------------- list offsets in depth order: two-level sums (reduce / spine) -----------------------
+// Two levels are kept: the sum of every run of 64 consecutive items (`sub`, 64 per workgroup chunk - one run is what
+// one wave of the emit kernel owns) and the chunk totals, which the spine kernel turns into chunk offsets.  The emit
+// kernel rebuilds its offsets from the two (one 256-byte read + a wave scan), so no per-item offset array is written
+// or read and there is no third scan launch.
 __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* __restrict__ in,
                                                           const uint32_t* __restrict__ gather, size_t n,
-                                                          uint32_t* __restrict__ block_sums) {
+                                                          uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sub) {
     __shared__ uint32_t sh[8];
     const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
-    uint32_t acc = 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const size_t i = base + (size_t)k * 256 + threadIdx.x;
-        if (i < n) acc += gather ? in[gather[i]] : in[i];
+        v[k] = i < n ? (gather ? in[gather[i]] : in[i]) : 0u;
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        uint32_t r = v[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) r += (uint32_t)__shfl_xor((int)r, d, 64);
+        if (lane == 0) sub[(size_t)blockIdx.x * 64 + 4 * k + w] = r;       // items base + 256 k + 64 w .. + 63
+        acc += v[k];
     }
     uint32_t tot;
     block_excl_scan_256(acc, sh, &tot);
@@ -62,30 +76,6 @@ __global__ void __launch_bounds__(256) scan_spine_kernel(uint32_t* __restrict__ 
         carry += tot;
     }
     if (threadIdx.x == 0 && total) *total = carry;
-}
-
-__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* __restrict__ in,
-                                                         const uint32_t* __restrict__ gather, size_t n,
-                                                         const uint32_t* __restrict__ block_sums,
-                                                         uint32_t* __restrict__ out) {
-    __shared__ uint32_t sh[8];
-    // thread t owns 16 consecutive items so the running order is preserved
-    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * 16;
-    uint32_t v[16];
-    uint32_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const size_t i = base + k;
-        v[k] = i < n ? (gather ? in[gather[i]] : in[i]) : 0;
-        acc += v[k];
-    }
-    uint32_t ex = block_excl_scan_256(acc, sh, nullptr) + block_sums[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const size_t i = base + k;
-        if (i < n) out[i] = ex;
-        ex += v[k];
-    }
 }
 
 // ---------------- radix sort pass -------------------------------------------------------------------
@@ -426,13 +416,13 @@ __global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ dst, s
 
 }  // namespace
 
-void launch_exclusive_scan(const uint32_t* in, const uint32_t* gather, uint32_t* out, uint32_t* total, size_t n,
-                           uint32_t* tmp, const uint32_t* extra, size_t n_extra, uint32_t* extra_total, hipStream_t s) {
+void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, uint32_t* chunk_offsets, uint32_t* sub,
+                        hipStream_t s) {
     const size_t nb = scan_blocks(n);
     if (nb == 0) return;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, in, gather, n, tmp);
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, s, tmp, nb, total, extra, n_extra, extra_total);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, in, gather, n, tmp, out);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, in, gather, n, chunk_offsets, sub);
+    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, s, chunk_offsets, nb, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                       (size_t)0, (uint32_t*)nullptr);
 }
 
 // ITEMS = keys per thread: 8 for the depth sort (2048-key workgroups: P = 1M gives 489 workgroups, about two per CU;

@@ -67,9 +67,9 @@ struct GeomState {
     uint32_t* key_b;
     uint32_t* val_a;
     uint32_t* val_b;
-    uint32_t* offsets;        // P   exclusive scan of tiles_touched in depth order
     uint32_t* hist;           // RADIX_BINS * sort_blocks(P) + RADIX_BINS
-    uint32_t* scan_tmp;       // scan_blocks(P) + 8
+    uint32_t* scan_tmp;       // scan_blocks(P) + 8      list offset of every chunk of SCAN_CHUNK Gaussians in depth order
+    uint32_t* scan_sub;       // 64 x scan_blocks(P)     list entries of every run of 64 Gaussians in depth order
     uint32_t* ref_partial;    // per preprocess workgroup: bounding-rectangle tile counts, then list-entry counts
     uint32_t* counters;       // 16 words: [0] = instances in the (culled) lists, [1] = reference num_rendered
     // -- control words of the single-pass sorts (lookback.h).  depth_hist is zeroed by preprocess_kernel (it is
@@ -93,9 +93,9 @@ struct GeomState {
         g.key_b = c.take<uint32_t>(P);
         g.val_a = c.take<uint32_t>(P);
         g.val_b = c.take<uint32_t>(P);
-        g.offsets = c.take<uint32_t>(P);
         g.hist = c.take<uint32_t>(DEPTH_RADIX_BINS * sort_blocks(P) + DEPTH_RADIX_BINS);
         g.scan_tmp = c.take<uint32_t>(scan_blocks(P) + 8);
+        g.scan_sub = c.take<uint32_t>(64 * scan_blocks(P));
         g.ref_partial = c.take<uint32_t>(2 * ((P + 255) / 256) + 2);
         g.counters = c.take<uint32_t>(16);
         g.depth_hist = c.take<uint32_t>(4 * 256);
@@ -205,18 +205,19 @@ void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D
                                 hipStream_t s);
 
 // binning.hip
-// Exclusive scan of in[gather[i]] (or in[i]); *total receives the grand total.  If `extra` is given its
-// `n_extra` values are summed into *extra_total by the spine kernel (rides along for free).
-void launch_exclusive_scan(const uint32_t* in, const uint32_t* gather, uint32_t* out, uint32_t* total, size_t n,
-                           uint32_t* tmp, const uint32_t* extra, size_t n_extra, uint32_t* extra_total, hipStream_t s);
+// Two-level sums of in[gather[i]] (or in[i]) for the emit kernel: chunk_offsets[c] = exclusive prefix of the chunks of
+// SCAN_CHUNK items, sub[64 c + r] = sum of run r (64 items) of chunk c.
+void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, uint32_t* chunk_offsets, uint32_t* sub,
+                        hipStream_t s);
 // Stable LSD radix sort of (key,val) u32 pairs on key bits [0, nbits).  Result lands in (key_out,val_out);
 // (key_in,val_in) and the *_tmp buffers are clobbered.  key_out/val_out may alias the tmp or in buffers
 // only as arranged by the caller through the pass parity (see binning.hip).
 // `ranges_enc` (optional): the final pass records every tile's [min, max + 1) output positions (BinState::ranges_enc)
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
                              uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s);
+// also presets `ranges_enc` (all-ones = "no entry yet") for the final tile-sort pass
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
-                           uint32_t* inst_tile, uint32_t* inst_id, hipStream_t s);
+                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, hipStream_t s);
 // single-pass flavour (option sort_onesweep): offsets by decoupled look-back inside the emit kernel, which also
 // produces the tile digit histograms, presets `ranges` for the final sort pass and zero-fills b.tile_status
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,

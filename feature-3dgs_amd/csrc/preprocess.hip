@@ -363,23 +363,32 @@ __global__ void __launch_bounds__(256) count_totals_kernel(const uint32_t* __res
 // 0.061 ms for 42 MB at c3).  Waves whose range exceeds the LDS slice (a few huge splats) store directly.
 constexpr int EMIT_CAP = 1024;      // list entries per wave in LDS (8 KB)
 __global__ void __launch_bounds__(256)
-emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                      const uint32_t* __restrict__ tiles_touched, const SplatRec* __restrict__ rec, int gx, int gy,
-                      int cull, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_id) {
+emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_offsets,
+                      const uint32_t* __restrict__ sub, const uint32_t* __restrict__ tiles_touched,
+                      const SplatRec* __restrict__ rec, int gx, int gy, int cull, uint32_t* __restrict__ inst_tile,
+                      uint32_t* __restrict__ inst_id, uint2* __restrict__ ranges_enc) {
     __shared__ uint32_t s_tile[4][EMIT_CAP];
     __shared__ uint32_t s_id[4][EMIT_CAP];
+    // all-ones = "no entry yet" for both halves of the encoded tile ranges (BinState::ranges_enc; the final sort pass,
+    // two launches further on, lowers them with atomicMin)
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (uint32_t)(gx * gy); t += gridDim.x * 256)
+        ranges_enc[t] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool valid = i < P;
     const uint32_t g = valid ? order[i] : 0u;
     const uint32_t cnt = valid ? tiles_touched[g] : 0u;
-    const uint32_t off0 = valid ? offsets[i] : 0u;
-    // the wave's range of the list: [offset of its first Gaussian, end of its last one)
-    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)off0);    // lane 0 of a launched wave is always < P
-    uint32_t end = valid ? off0 + cnt : 0u;
+    // the wave's range of the list starts at: offset of its chunk of SCAN_CHUNK Gaussians + the runs of 64 in front of its
+    // own inside the chunk (binning.hip: scan_reduce_kernel); a lane's run starts behind the lanes in front of it
+    const uint32_t first = (uint32_t)(blockIdx.x * 256 + 64 * w);              // the wave's first Gaussian (depth order)
+    const uint32_t chunk = first / SCAN_CHUNK, run = (first % SCAN_CHUNK) / 64;
+    uint32_t before = (uint32_t)lane < run ? sub[(size_t)chunk * 64 + lane] : 0u;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) end = max(end, (uint32_t)__shfl_xor((int)end, d, 64));
-    const uint32_t total = end - base;
+    for (int d = 32; d >= 1; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
+    const uint32_t base = chunk_offsets[chunk] + before;
+    const uint32_t inc = wave_incl_scan(cnt, lane);
+    const uint32_t off0 = base + inc - cnt;
+    const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
     const bool staged = total <= (uint32_t)EMIT_CAP;          // wave-uniform
     if (cnt != 0) {
         uint32_t off = off0;
@@ -783,9 +792,9 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
 }
 
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
-                           uint32_t* inst_tile, uint32_t* inst_id, hipStream_t s) {
-    hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.offsets,
-                       g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id);
+                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, hipStream_t s) {
+    hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.scan_tmp, g.scan_sub,
+                       g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc);
 }
 
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,
