@@ -343,7 +343,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // K1: projection, culling, SH colour, tile counts
     const int cull = tile_cull_enabled();
     launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, vp, radii,
-                      geom, cull, !onesweep, s);
+                      geom, cull, s);
     if ((rc = check_debug(debug, s, "preprocess"))) return rc;
     tm.mark("preprocess");
     if (onesweep) launch_sort_prologue(geom, (size_t)P, s);   // digit histograms of the depth keys + both instance totals
@@ -352,12 +352,17 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // trip hides behind ~0.1 ms of GPU work instead of idling the device.
     CountReadback& rb = count_readback();
     if (!rb.host || !rb.done) return fail(F3DGS_ERR_ALLOC, "pinned read-back buffer / event creation failed");
-    HIP_TRY(hipMemcpyAsync(rb.host, geom.counters, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(rb.done, s));
+    if (onesweep) {
+        HIP_TRY(hipMemcpyAsync(rb.host, geom.counters, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(rb.done, s));
+    }
 
-    // depth sort of the Gaussians (ids start in index order -> ties keep ascending id)
+    // depth sort of the Gaussians (ids start in index order -> ties keep ascending id).  Three-kernel flavour: its
+    // first kernel adds up the totals and stores them into the pinned host words itself (no totals / copy launches);
+    // rb.done is recorded right behind that kernel.
+    const TotalsJob tj = {geom.ref_partial, (P + 255) / 256, geom.counters, rb.host, rb.done};
     if (onesweep) launch_depth_sort_onesweep(geom, (size_t)P, s);
-    else launch_depth_sort(geom.depth_key, geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, geom.hist, s);
+    else HIP_TRY(launch_depth_sort(geom.depth_key, geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, geom.hist, &tj, s));
     if ((rc = check_debug(debug, s, "depth sort"))) return rc;
     tm.mark("depth_sort");
     const uint32_t* order = geom.val_a;

@@ -83,13 +83,38 @@ __global__ void __launch_bounds__(256) scan_spine_kernel(uint32_t* __restrict__ 
 // consecutive items (lane = item within the step).  BITS = digit width (8 for tile ids, 11 for the 32-bit
 // depth keys: 3 passes instead of 4).  vals_in == nullptr means "value = item index" (first pass of the
 // depth sort: saves an iota kernel and a key copy).
+// `tj` (first pass of the depth sort only): workgroup 0 also adds up the per-workgroup instance counts of
+// preprocess_kernel - both totals are known right after that kernel - and stores them to the device counters and
+// straight into the host's pinned read-back words: no totals launch and no copy launch in front of the sort.
 template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
                                                                   int shift, uint32_t nb,
-                                                                  uint32_t* __restrict__ hist) {
+                                                                  uint32_t* __restrict__ hist, TotalsJob tj) {
     constexpr int BINS = 1 << BITS;
     constexpr int CHUNK = SORT_THREADS * ITEMS;
     __shared__ uint32_t h[BINS];
+    if (tj.partial && blockIdx.x == 0) {
+        __shared__ uint32_t shc[2][SORT_THREADS / 64];
+        uint32_t v = 0, u = 0;
+        for (int i = threadIdx.x; i < tj.n_partial; i += SORT_THREADS) { v += tj.partial[i]; u += tj.partial[tj.n_partial + i]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            v += (uint32_t)__shfl_xor((int)v, d, 64);
+            u += (uint32_t)__shfl_xor((int)u, d, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { shc[0][threadIdx.x >> 6] = v; shc[1][threadIdx.x >> 6] = u; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t ref = 0, own = 0;
+            for (int k = 0; k < SORT_THREADS / 64; k++) { ref += shc[0][k]; own += shc[1][k]; }
+            tj.counters[0] = own; tj.counters[1] = ref;      // [0] entries of our lists, [1] the reference's count
+            if (tj.host) {
+                __hip_atomic_store(&tj.host[0], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&tj.host[1], ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+            }
+        }
+    }
     for (int d = threadIdx.x; d < BINS; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * CHUNK;
@@ -429,13 +454,16 @@ void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, ui
 // with 16 there are fewer workgroups than CUs and every pass is one latency chain: 0.116 -> 0.097 ms at c3), 16 for
 // the tile sort (twice the instances, and the LDS reorder pays more on longer runs: 0.119 vs 0.128 ms with 8).
 template <int BITS, int ITEMS>
-static void radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n, int shift,
-                       uint32_t* hist, hipStream_t s, uint2* ranges_enc = nullptr) {
+static hipError_t radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n, int shift,
+                             uint32_t* hist, hipStream_t s, uint2* ranges_enc = nullptr, const TotalsJob* tj = nullptr) {
+    hipError_t rc = hipSuccess;
     constexpr int BINS = 1 << BITS;
     static_assert(ITEMS >= SORT_ITEMS, "the histogram buffers are sized for SORT_ITEMS keys per thread");
     const uint32_t nb = (uint32_t)((n + SORT_THREADS * ITEMS - 1) / (SORT_THREADS * ITEMS));
     uint32_t* totals = hist + (size_t)BINS * nb;
-    hipLaunchKernelGGL((radix_hist_kernel<BITS, ITEMS>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, n, shift, nb, hist);
+    hipLaunchKernelGGL((radix_hist_kernel<BITS, ITEMS>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, n, shift, nb, hist,
+                       tj ? *tj : TotalsJob{nullptr, 0, nullptr, nullptr});
+    if (tj && tj->ready) rc = hipEventRecord(tj->ready, s);        // the totals are final behind this launch
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(BINS), dim3(256), 0, s, hist, nb, totals);
     if (ranges_enc && BITS <= 8)
         hipLaunchKernelGGL((radix_scatter_kernel<BITS, ITEMS, true, true>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko, vo, n,
@@ -443,6 +471,7 @@ static void radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uin
     else
         hipLaunchKernelGGL((radix_scatter_kernel<BITS, ITEMS, (BITS <= 8), false>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko,
                            vo, n, shift, nb, hist, totals, (uint2*)nullptr);
+    return rc;
 }
 
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
@@ -456,29 +485,30 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
         uint32_t* vi = in_a ? val_a : val_b;
         uint32_t* ko = in_a ? key_b : key_a;
         uint32_t* vo = in_a ? val_b : val_a;
-        radix_pass<RADIX_BITS, 16>(ki, vi, ko, vo, n, p * RADIX_BITS, hist, s, p == passes - 1 ? ranges_enc : nullptr);
+        (void)radix_pass<RADIX_BITS, 16>(ki, vi, ko, vo, n, p * RADIX_BITS, hist, s, p == passes - 1 ? ranges_enc : nullptr);
         in_a = !in_a;
     }
 }
 
 // Depth sort of the Gaussians: 32-bit keys in `keys` (read-only), values = indices.  Three passes of 11/11/10
 // bits; the sorted ids end in val_a (and the sorted keys in key_a).
-void launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
-                       uint32_t* hist, hipStream_t s) {
-    if (n == 0) return;
+hipError_t launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
+                             uint32_t* hist, const TotalsJob* tj, hipStream_t s) {
+    if (n == 0) return hipSuccess;
     if (n > 200000) {
         // large P: four 8-bit passes are faster than three 11-bit ones (measured at 1M: 0.105 vs 0.148 ms);
         // small P is launch-bound and prefers fewer passes.  Result must end in (key_a, val_a): A <- keys, then
         // A -> B -> A -> ... needs an odd number of remaining hops, so the first pass writes into B.
-        radix_pass<RADIX_BITS, SORT_ITEMS>(keys, nullptr, key_b, val_b, n, 0, hist, s);
-        radix_pass<RADIX_BITS, SORT_ITEMS>(key_b, val_b, key_a, val_a, n, 8, hist, s);
-        radix_pass<RADIX_BITS, SORT_ITEMS>(key_a, val_a, key_b, val_b, n, 16, hist, s);
-        radix_pass<RADIX_BITS, SORT_ITEMS>(key_b, val_b, key_a, val_a, n, 24, hist, s);
-        return;
+        const hipError_t rc = radix_pass<RADIX_BITS, SORT_ITEMS>(keys, nullptr, key_b, val_b, n, 0, hist, s, nullptr, tj);
+        (void)radix_pass<RADIX_BITS, SORT_ITEMS>(key_b, val_b, key_a, val_a, n, 8, hist, s);
+        (void)radix_pass<RADIX_BITS, SORT_ITEMS>(key_a, val_a, key_b, val_b, n, 16, hist, s);
+        (void)radix_pass<RADIX_BITS, SORT_ITEMS>(key_b, val_b, key_a, val_a, n, 24, hist, s);
+        return rc;
     }
-    radix_pass<DEPTH_RADIX_BITS, SORT_ITEMS>(keys, nullptr, key_a, val_a, n, 0, hist, s);
-    radix_pass<DEPTH_RADIX_BITS, SORT_ITEMS>(key_a, val_a, key_b, val_b, n, DEPTH_RADIX_BITS, hist, s);
-    radix_pass<DEPTH_RADIX_BITS, SORT_ITEMS>(key_b, val_b, key_a, val_a, n, 2 * DEPTH_RADIX_BITS, hist, s);
+    const hipError_t rc = radix_pass<DEPTH_RADIX_BITS, SORT_ITEMS>(keys, nullptr, key_a, val_a, n, 0, hist, s, nullptr, tj);
+    (void)radix_pass<DEPTH_RADIX_BITS, SORT_ITEMS>(key_a, val_a, key_b, val_b, n, DEPTH_RADIX_BITS, hist, s);
+    (void)radix_pass<DEPTH_RADIX_BITS, SORT_ITEMS>(key_b, val_b, key_a, val_a, n, 2 * DEPTH_RADIX_BITS, hist, s);
+    return rc;
 }
 
 
@@ -537,7 +567,7 @@ void launch_radix_sort_keys_to_order(const uint32_t* keys, uint32_t* key_a, uint
     for (int p = 0; p < passes; p++) {
         uint32_t* ko = to_a ? key_a : key_b;
         uint32_t* vo = to_a ? val_a : val_b;
-        radix_pass<RADIX_BITS, SORT_ITEMS>(ki, vi, ko, vo, n, p * RADIX_BITS, hist, s);
+        (void)radix_pass<RADIX_BITS, SORT_ITEMS>(ki, vi, ko, vo, n, p * RADIX_BITS, hist, s);
         ki = ko; vi = vo;
         to_a = !to_a;
     }

@@ -195,8 +195,7 @@ struct ViewParams {
 void launch_mark_visible(int P, const float* means3D, const float* view_dev, uint8_t* present, hipStream_t s);
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
-                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull,
-                       bool totals_kernel, hipStream_t s);
+                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull, hipStream_t s);
 void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D, const int* radii, const float* shs,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
                                 const ViewParams& vp, const GeomState& g, const float* grec, float* dL_dmean2D,
@@ -225,8 +224,17 @@ void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32
 void launch_sort_prologue(const GeomState& g, size_t P, hipStream_t s);
 void launch_depth_sort_onesweep(const GeomState& g, size_t n, hipStream_t s);
 void launch_tile_sort_onesweep(const GeomState& g, const BinState& b, size_t n, int passes, uint2* ranges, hipStream_t s);
-void launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
-                       uint32_t* hist, hipStream_t s);
+// `tj` (optional): the first kernel of the sort also produces the two instance totals from the per-workgroup partials of
+// preprocess_kernel - device counters and the host's pinned words - and `ready` is recorded right behind it.
+struct TotalsJob {
+    const uint32_t* partial;   // GeomState::ref_partial
+    int n_partial;
+    uint32_t* counters;        // GeomState::counters
+    uint32_t* host;            // pinned, device-visible (may be null)
+    hipEvent_t ready;          // host side only
+};
+hipError_t launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
+                             uint32_t* hist, const TotalsJob* tj, hipStream_t s);
 void launch_iota(uint32_t* dst, size_t n, hipStream_t s);
 void launch_radix_sort_keys_to_order(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b,
                                      size_t n, int nbits, uint32_t* hist, hipStream_t s);

@@ -315,10 +315,10 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         if (out_radius == 0) clamped[i] = 0;
     }
     // the reference's num_rendered = sum of bounding-rectangle tile counts (rasterizer_impl.cu:279-283)
-    // Same-address atomics serialise at ~12 ns each on MI355X, so every workgroup writes ONE partial sum and
-    // the scan's spine kernel adds the partials up.
-    // The same goes for the length of our own (culled) instance lists: both totals are known right after this
-    // kernel, long before the host needs them (api.hip reads them back while the depth sort runs).
+    // Same-address atomics serialise at ~12 ns each on MI355X, so every workgroup writes ONE partial sum; the first
+    // kernel of the depth sort adds the partials up (binning.hip: TotalsJob) and stores the totals into the host's
+    // pinned words.  The same goes for the length of our own (culled) instance lists: both totals are known right
+    // after this kernel, long before the host needs them (it waits for them while the depth sort runs).
     __shared__ uint32_t wsum[2][4];
     uint32_t v = bbox_tiles, u = out_tiles;
 #pragma unroll
@@ -334,25 +334,6 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
             ref_partial[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
             ref_partial[nbp + blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
         }
-    }
-}
-
-// counters[0] = instances in our lists, counters[1] = the reference's bounding-rectangle count
-__global__ void __launch_bounds__(256) count_totals_kernel(const uint32_t* __restrict__ partial, int nb,
-                                                           uint32_t* __restrict__ counters) {
-    __shared__ uint32_t sh[2][4];
-    uint32_t v = 0, u = 0;
-    for (int i = threadIdx.x; i < nb; i += 256) { v += partial[i]; u += partial[nb + i]; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        v += (uint32_t)__shfl_xor((int)v, d, 64);
-        u += (uint32_t)__shfl_xor((int)u, d, 64);
-    }
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = v; sh[1][threadIdx.x >> 6] = u; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        counters[1] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-        counters[0] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
     }
 }
 
@@ -779,16 +760,12 @@ void launch_mark_visible(int P, const float* means3D, const float* view_dev, uin
 
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
-                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull,
-                       bool totals_kernel, hipStream_t s) {
+                       const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull, hipStream_t s) {
     // at least 4 workgroups so that the depth_hist zero-fill above is complete even for tiny P
     const int grid = max(4, (P + 255) / 256);
     hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, P, D, M, means3D, scales, rotations,
                        opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped, g.tiles_touched,
                        g.depth_key, cull, g.ref_partial, g.depth_hist);
-    // (the single-pass sort computes the totals in its prologue kernel instead)
-    if (totals_kernel)
-        hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(256), 0, s, g.ref_partial, (P + 255) / 256, g.counters);
 }
 
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
