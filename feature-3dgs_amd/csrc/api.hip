@@ -5,6 +5,7 @@
 // 198-342, 347-461).  Everything is enqueued on the caller's stream; the only host synchronisation is
 // the 4-byte read-back of num_rendered (same place as rasterizer_impl.cu:283).
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,9 @@ namespace {
 thread_local std::string g_err;
 thread_local f3dgs_stage_fn g_feature_ready_fn = nullptr;
 thread_local void* g_feature_ready_ctx = nullptr;
+thread_local f3dgs_rows_fn g_rows_ready_fn = nullptr;
+thread_local void* g_rows_ready_ctx = nullptr;
+thread_local int g_rows_ready_chunks = 1;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -278,6 +282,12 @@ void f3dgs_set_feature_grad_ready_callback(f3dgs_stage_fn fn, void* ctx) {
     g_feature_ready_ctx = ctx;
 }
 
+void f3dgs_set_grad_rows_ready_callback(f3dgs_rows_fn fn, void* ctx, int chunks) {
+    g_rows_ready_fn = fn;
+    g_rows_ready_ctx = ctx;
+    g_rows_ready_chunks = chunks > 0 ? chunks : 1;
+}
+
 int f3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                        uint8_t* present, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -471,10 +481,24 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     if ((rc = check_debug(debug, s, "render backward"))) return rc;
     tm.mark("render_bwd");
     if (g_feature_ready_fn) g_feature_ready_fn(g_feature_ready_ctx, stream);   // dL_dsemantic_feature is final on `s` here
-    launch_preprocess_backward(P, D, M, C, means3D, radii, shs, scales, rotations, cov3D_precomp, vp, geom, grec,
-                               dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
-                               (M > 0 && shs) ? dL_dsh : nullptr, scales ? dL_dscale : nullptr,
-                               scales ? dL_drot : nullptr, dL_dz, s);
+    // The per-Gaussian stage, in `chunks` launches over consecutive row ranges when a rows-ready callback asks for it:
+    // behind launch k every per-Gaussian gradient of rows [r0, r1) is final on `s` (the kernel is row-parallel), so a
+    // data-parallel caller can start reducing them - the SH gradient is 3/4 of the non-feature message - while the
+    // later chunks still run.
+    {
+        const int align = preprocess_backward_row_align();
+        int chunks = g_rows_ready_fn ? std::max(1, g_rows_ready_chunks) : 1;
+        int per = (int)(((long long)P + chunks - 1) / chunks);
+        per = std::max(align, (per + align - 1) / align * align);
+        for (int r0 = 0; r0 < P; r0 += per) {
+            const int r1 = std::min(P, r0 + per);
+            launch_preprocess_backward(P, D, M, C, means3D, radii, shs, scales, rotations, cov3D_precomp, vp, geom, grec,
+                                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                                       (M > 0 && shs) ? dL_dsh : nullptr, scales ? dL_dscale : nullptr,
+                                       scales ? dL_drot : nullptr, dL_dz, r0, r1, s);
+            if (g_rows_ready_fn) g_rows_ready_fn(g_rows_ready_ctx, stream, r0, r1);
+        }
+    }
     if ((rc = check_debug(debug, s, "preprocess backward"))) return rc;
     tm.mark("preprocess_bwd");
     HIP_TRY(hipGetLastError());

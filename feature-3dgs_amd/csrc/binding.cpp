@@ -91,6 +91,43 @@ struct FeatureCallbackGuard {
     }
 };
 
+// Python callable invoked as fn(row_begin, row_end, {"sh": dL_dsh, "means3D": ..., ...}) after every row chunk of the
+// per-Gaussian stage has been enqueued (include/f3dgs.h: f3dgs_set_grad_rows_ready_callback), and its chunk count.
+py::object& grad_rows_hook() {
+    static py::object* hook = new py::object(py::none());
+    return *hook;
+}
+int& grad_rows_chunks() {
+    static int chunks = 1;
+    return chunks;
+}
+struct RowsCallbackCtx {
+    const torch::Tensor *sh, *means3D, *scales, *rotations, *opacities, *colors, *means2D, *cov3D;
+};
+void rows_ready_trampoline(void* ctx, void* /*stream*/, int row_begin, int row_end) {
+    py::object& hook = grad_rows_hook();
+    if (hook.is_none() || pending_hook_error()) return;
+    try {
+        const auto* c = static_cast<const RowsCallbackCtx*>(ctx);
+        py::dict grads;
+        grads["sh"] = *c->sh; grads["means3D"] = *c->means3D; grads["scales"] = *c->scales; grads["rotations"] = *c->rotations;
+        grads["opacities"] = *c->opacities; grads["colors_precomp"] = *c->colors; grads["means2D"] = *c->means2D;
+        grads["cov3Ds_precomp"] = *c->cov3D;
+        hook(row_begin, row_end, grads);
+    } catch (...) {
+        pending_hook_error() = std::current_exception();
+    }
+}
+struct RowsCallbackGuard {
+    bool armed;
+    RowsCallbackGuard(bool on, void* ctx, int chunks) : armed(on) {
+        if (armed) f3dgs_set_grad_rows_ready_callback(rows_ready_trampoline, ctx, chunks);
+    }
+    ~RowsCallbackGuard() {
+        if (armed) f3dgs_set_grad_rows_ready_callback(nullptr, nullptr, 1);
+    }
+};
+
 void* current_stream(const torch::Tensor& ref) {
     return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(ref.device().index()).stream();
 }
@@ -192,6 +229,8 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     int rc;
     {
     FeatureCallbackGuard guard_cb(notify, &dL_dsemantic_feature);
+    RowsCallbackCtx rows_ctx = {&dL_dsh, &dL_dmeans3D, &dL_dscales, &dL_drotations, &dL_dopacity, &dL_dcolors, &dL_dmeans2D, &dL_dcov3D};
+    RowsCallbackGuard guard_rows(!grad_rows_hook().is_none() && P > 0, &rows_ctx, grad_rows_chunks());
     rc = f3dgs_backward(
         P, degree, M, C, R, fptr(bg), W, H, fptr(m3), fptr(shs), fptr(col), fptr(sf), fptr(sc), scale_modifier, fptr(rot),
         fptr(cov), fptr(vm), fptr(pm), fptr(cp), tan_fovx, tan_fovy, P ? rad.data_ptr<int>() : nullptr,
@@ -396,6 +435,10 @@ PYBIND11_MODULE(_C, m) {
     m.def("version", []() { return f3dgs_version(); });
     m.def("set_feature_grad_hook", [](py::object fn) { feature_grad_hook() = std::move(fn); },
           "callable(dL_dsemantic_feature) run inside rasterize_gaussians_backward once that tensor is final on the stream; None removes it");
+    m.def("set_grad_rows_hook", [](py::object fn, int chunks) { grad_rows_hook() = std::move(fn); grad_rows_chunks() = chunks > 0 ? chunks : 1; },
+          py::arg("fn"), py::arg("chunks") = 4,
+          "callable(row_begin, row_end, grads: dict) run inside rasterize_gaussians_backward after each of `chunks` row ranges of the "
+          "per-Gaussian gradients is final on the stream; None removes it");
     m.def("set_option", [](const std::string& name, int value) { check_status(f3dgs_set_option(name.c_str(), value), "set_option"); });
     m.def("get_option", [](const std::string& name) {
         int v = 0;

@@ -201,7 +201,8 @@ void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D
                                 const ViewParams& vp, const GeomState& g, const float* grec, float* dL_dmean2D,
                                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dz,
-                                hipStream_t s);
+                                int row_begin, int row_end, hipStream_t s);
+int preprocess_backward_row_align();     // row_begin of a partial launch must be a multiple of this
 
 // binning.hip
 // Two-level sums of in[gather[i]] (or in[i]) for the emit kernel: chunk_offsets[c] = exclusive prefix of the chunks of

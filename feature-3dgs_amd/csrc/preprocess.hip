@@ -556,14 +556,18 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
                            float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
                            float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-                           float* __restrict__ dL_dscale, float* __restrict__ dL_drot, float* __restrict__ dL_dz) {
-    const int i = blockIdx.x * PB_BLOCK + threadIdx.x;
+                           float* __restrict__ dL_dscale, float* __restrict__ dL_drot, float* __restrict__ dL_dz,
+                           int block0) {
+    // block0: first workgroup of this launch's row chunk (the rows of a call may be covered by several launches, see
+    // f3dgs_set_grad_rows_ready_callback)
+    const int blk = block0 + (int)blockIdx.x;
+    const int i = blk * PB_BLOCK + threadIdx.x;
     // SH coefficients in, SH gradients out: both are contiguous per workgroup and go through one LDS tile
     // (coalesced 16-byte global accesses; per-thread rows with an odd stride).
     extern __shared__ __attribute__((aligned(16))) float sh_lds[];
     const int row = 3 * M + 1;
     const bool use_sh = dL_dsh && M > 0;
-    const size_t sh_first = (size_t)blockIdx.x * PB_BLOCK * 3 * M;
+    const size_t sh_first = (size_t)blk * PB_BLOCK * 3 * M;
     const int sh_count = use_sh ? (int)min((size_t)PB_BLOCK * 3 * M, (size_t)P * 3 * M - sh_first) : 0;
     const int m3 = 3 * M;                           // LDS index of element e: e + e / m3 (row stride m3 + 1)
     const bool sh_vec = (m3 & 3) == 0;              // rows are whole float4s (sh_first = 768 M is always 16-B aligned)
@@ -787,12 +791,17 @@ void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D
                                 const ViewParams& vp, const GeomState& g, const float* grec, float* dL_dmean2D,
                                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dz,
-                                hipStream_t s) {
+                                int row_begin, int row_end, hipStream_t s) {
     (void)C;
+    // rows [row_begin, row_end): row_begin is a multiple of PB_BLOCK (preprocess_backward_row_align())
+    const int block0 = row_begin / PB_BLOCK, nblocks = (row_end - row_begin + PB_BLOCK - 1) / PB_BLOCK;
+    if (nblocks <= 0) return;
     const size_t lds = (dL_dsh && M > 0) ? (size_t)PB_BLOCK * (3 * M + 1) * sizeof(float) : 0;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + PB_BLOCK - 1) / PB_BLOCK), dim3(PB_BLOCK), lds, s, P, D, M, means3D, radii, shs,
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblocks), dim3(PB_BLOCK), lds, s, P, D, M, means3D, radii, shs,
                        scales, rotations, cov3D_precomp, vp, g.clamped, grec, dL_dmean2D, dL_dconic, dL_dopacity,
-                       dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dz);
+                       dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dz, block0);
 }
+
+int preprocess_backward_row_align() { return PB_BLOCK; }
 
 }  // namespace f3dgs

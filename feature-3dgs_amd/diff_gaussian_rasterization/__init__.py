@@ -30,6 +30,7 @@ except ImportError as exc:  # fail loudly — a silent fallback would void every
 
 
 _backward_done_hook = None
+_rows_done_hook = None
 
 
 def set_feature_grad_hook(on_ready, on_done=None) -> None:
@@ -40,6 +41,17 @@ def set_feature_grad_hook(on_ready, on_done=None) -> None:
     global _backward_done_hook
     _C.set_feature_grad_hook(on_ready)
     _backward_done_hook = on_done if on_ready is not None else None
+
+
+def set_grad_rows_hook(on_rows, chunks: int = 4, on_done=None) -> None:
+    """Data-parallel overlap (not in the reference): the per-Gaussian stage of the backward pass runs in `chunks` row
+    ranges and `on_rows(row_begin, row_end, grads)` is called after each has been enqueued - `grads` maps the op's
+    input names ("sh", "means3D", "scales", "rotations", "opacities", "colors_precomp", "means2D",
+    "cov3Ds_precomp") to the gradient tensors, whose rows [row_begin, row_end) are final on the current stream from
+    there on.  `on_done()` runs when the extension call has returned.  `None` removes both.  See dp.py: RowsGradOverlap."""
+    global _rows_done_hook
+    _C.set_grad_rows_hook(on_rows, chunks)
+    _rows_done_hook = on_done if on_rows is not None else None
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -106,6 +118,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
         if _backward_done_hook is not None:
             _backward_done_hook()
+        if _rows_done_hook is not None:
+            _rows_done_hook()
         # one gradient per forward input, in input order; raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_semantic_feature, grad_opacities,
                 grad_scales, grad_rotations, grad_cov3Ds_precomp, None)
@@ -150,4 +164,4 @@ class GaussianRasterizer(nn.Module):
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "cpu_deep_copy_tuple",
-           "set_feature_grad_hook"]
+           "set_feature_grad_hook", "set_grad_rows_hook"]

@@ -215,6 +215,86 @@ class FeatureGradOverlap:
         return list(feature_keys) if self._count > 0 else []
 
 
+class RowsGradOverlap:
+    """Overlaps the all-reduce of per-Gaussian op gradients - by default the SH gradient, 48 of the 59 non-feature
+    floats per Gaussian - with the per-Gaussian stage of the op's backward pass.
+
+    With the hook installed (`diff_gaussian_rasterization.set_grad_rows_hook`) that stage runs as `chunks` launches over
+    consecutive row ranges; after each the op calls `_hook(row_begin, row_end, grads)`: an event is recorded on the op's
+    stream, a side stream waits for it and starts the RCCL all-reduce of rows [row_begin, row_end) of every tensor named in
+    `names` (row slices of the contiguous (P, ...) gradients: no staging copy).  The chunk boundaries depend on P and
+    `chunks` only, so every rank issues the same collectives in the same order.  `finish()` (called by the op when its
+    backward call has returned) makes the current stream wait for them, so autograd - which still has to carry the op-level
+    gradient to the leaves (the SH gradient through the `cat` of features_dc / features_rest) - sees the SUM; those steps
+    are linear in the gradient, the leaves therefore end up with the sum over ranks and are skipped by the final reduce:
+
+        with RowsGradOverlap(group) as rv:
+            loss.backward()
+            all_reduce_gaussian_grads(grads, skip=rv.reduced({"sh": ("_features_dc", "_features_rest")}))
+
+    Every rank's backward pass must reach the op (a rank without a view must not use this)."""
+
+    def __init__(self, group=None, names: Sequence[str] = ("sh",), chunks: int = 4):
+        self.group = group
+        self.names = tuple(names)
+        self.chunks = int(chunks)
+        self._works = []
+        self._stream = None
+        self._device = None
+        self._installed = False
+        self._count = 0
+        self.rows: List[tuple] = []          # (row_begin, row_end) of every call since entered
+
+    def _hook(self, row_begin: int, row_end: int, grads: Dict[str, torch.Tensor]) -> None:
+        self.rows.append((int(row_begin), int(row_end)))
+        if not _active(self.group):
+            return
+        parts = [grads[n][row_begin:row_end] for n in self.names if grads[n].numel() > 0]
+        if not parts:
+            return
+        if parts[0].is_cuda:
+            self._device = parts[0].device
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=self._device)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self._device))
+            self._stream.wait_event(ready)
+            with torch.cuda.stream(self._stream):
+                for t in parts:
+                    self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for t in parts:
+                self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._count += 1
+
+    def __enter__(self):
+        import diff_gaussian_rasterization as dgr
+        dgr.set_grad_rows_hook(self._hook, self.chunks, self.finish)
+        self._installed = True
+        return self
+
+    def __exit__(self, *exc):
+        import diff_gaussian_rasterization as dgr
+        if self._installed:
+            dgr.set_grad_rows_hook(None)
+            self._installed = False
+        return False
+
+    def finish(self) -> None:
+        """Join: work queued on the current stream from here on sees the reduced rows.  No host synchronisation."""
+        for w in self._works:
+            w.wait()
+        if self._works and self._stream is not None:
+            torch.cuda.current_stream(self._device).wait_stream(self._stream)
+        self._works = []
+
+    def reduced(self, leaves_of: Dict[str, Sequence[str]]) -> List[str]:
+        """The leaf keys made final by this object since it was entered: `leaves_of[name]` for every reduced op gradient."""
+        if self._count == 0:
+            return []
+        return [leaf for n in self.names for leaf in leaves_of.get(n, ())]
+
+
 def shard_range(P: int, rank: int, world: int):
     """Gaussians [lo, hi) owned by `rank` under the contiguous sharding used by the sharded-optimiser path."""
     per = (P + world - 1) // world
@@ -282,11 +362,15 @@ def reduce_densification_stats(grad_norm_accum: torch.Tensor, denom: torch.Tenso
 
 def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.Tensor], view_ids: Iterable[int],
             group=None, buckets: Optional[GradBuckets] = None, overlap: bool = False,
-            feature_key: str = "semantic_feature") -> Dict[str, torch.Tensor]:
+            feature_key: str = "semantic_feature", rows_leaves: Optional[Dict[str, Sequence[str]]] = None,
+            rows_chunks: int = 4) -> Dict[str, torch.Tensor]:
     """One data-parallel step: `render_and_backward(view_id)` must run the op forward+backward for that view
     and accumulate into `leaves[k].grad`; afterwards `leaves[k].grad` holds the sum over all ranks' views for
     EVERY leaf (any names).  `overlap=True` starts the all-reduce of `leaves[feature_key].grad` inside the backward
-    pass (one view per rank and step; the leaf must be fed to the op directly; needs the HIP extension)."""
+    pass (one view per rank and step; the leaf must be fed to the op directly; needs the HIP extension).
+    `rows_leaves` (with overlap): op gradient name -> the leaves that receive nothing but that gradient, e.g.
+    {"sh": ("_features_dc", "_features_rest")} for the reference's model; those op gradients are reduced in `rows_chunks`
+    row ranges inside the per-Gaussian stage of the backward pass (RowsGradOverlap) and their leaves are not reduced again."""
     for v in leaves.values():
         v.grad = None
     view_ids = list(view_ids)
@@ -301,12 +385,22 @@ def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.
         return {k: v.grad for k, v in leaves.items() if v.grad is not None}
 
     if overlap and len(view_ids) == 1 and _active(group):
-        with FeatureGradOverlap(group) as ov:
+        import contextlib
+        rows_leaves = {n: tuple(k for k in ks if k in leaves) for n, ks in (rows_leaves or {}).items()}
+        rows_leaves = {n: ks for n, ks in rows_leaves.items() if ks}
+        rv_cm = RowsGradOverlap(group, tuple(rows_leaves), rows_chunks) if rows_leaves else contextlib.nullcontext()
+        with FeatureGradOverlap(group) as ov, rv_cm as rv:
             render_and_backward(view_ids[0])
             grads = all_grads()
+            rows_done: List[str] = []
+            if rows_leaves:
+                rows_done = rv.reduced(rows_leaves)
+                if not rows_done:
+                    raise RuntimeError("dp_step: rows overlap was requested but this rank's backward pass never reached the op "
+                                       "(its peers are waiting in the chunk all-reduces)")
             feat = leaves.get(feature_key)
             if feat is None or feat.numel() == 0:
-                return all_reduce_gaussian_grads(grads, group=group, buckets=buckets)
+                return all_reduce_gaussian_grads(grads, group=group, buckets=buckets, skip=rows_done)
             # exactly ONE all-reduce of the feature gradient per rank and step: started inside the backward pass where the
             # hook fired; a rank whose backward pass did not reach the op (or produced no feature gradient) issues the
             # matching one here, so that its peers' collective is not left without a partner
@@ -319,7 +413,7 @@ def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.
                 dist.all_reduce(fired, op=dist.ReduceOp.MAX, group=group)
                 if float(lo) != float(fired):
                     raise RuntimeError("dp_step: the feature-gradient hook fired on some ranks only (F3DGS_DP_DEBUG)")
-            return all_reduce_gaussian_grads(grads, group=group, buckets=buckets, skip=(feature_key,))
+            return all_reduce_gaussian_grads(grads, group=group, buckets=buckets, skip=[feature_key] + rows_done)
     for vid in view_ids:
         render_and_backward(vid)
     return all_reduce_gaussian_grads(all_grads(), group=group, buckets=buckets)

@@ -54,11 +54,14 @@ def densification_deltas(render_pkg: dict, P: int, device) -> tuple:
 
 def dp_train_step(render: Callable, loss_fn: Callable, model, cameras: Iterable, pipe, background: torch.Tensor,
                   group=None, overlap: bool = True, param_names: Sequence[str] = REFERENCE_PARAM_NAMES,
-                  feature_param: str = "_semantic_feature", densification_stats: bool = True) -> StepResult:
+                  feature_param: str = "_semantic_feature", densification_stats: bool = True,
+                  sh_params: Sequence[str] = ("_features_dc", "_features_rest"), rows_chunks: int = 4) -> StepResult:
     """Render + loss + backward for this rank's `cameras`, then make gradients and densification statistics
     global.  `render(camera, model, pipe, background)` is the reference's `gaussian_renderer.render`;
     `loss_fn(render_pkg, camera)` returns the scalar loss of one view.  The optimizer step stays with the caller
-    (train.py:146-151), exactly as in the reference."""
+    (train.py:146-151), exactly as in the reference.  `sh_params`: the parameters that receive nothing but the op's SH
+    gradient (scene/gaussian_model.py:113-116: get_features = cat(_features_dc, _features_rest)); with `overlap` their
+    all-reduce runs in `rows_chunks` row ranges inside the backward pass (empty: reduce them afterwards)."""
     params = {n: getattr(model, n) for n in param_names if getattr(model, n, None) is not None}
     cameras = list(cameras)
     P = next(iter(params.values())).shape[0]
@@ -75,7 +78,8 @@ def dp_train_step(render: Callable, loss_fn: Callable, model, cameras: Iterable,
     # the overlap needs the feature parameter to be the op's direct input (true for the reference's model:
     # get_semantic_feature returns the parameter itself, scene/gaussian_model.py:121-123)
     grads = dp.dp_step(render_and_backward, params, range(len(cameras)), group=group,
-                       overlap=overlap and len(cameras) == 1, feature_key=feature_param)
+                       overlap=overlap and len(cameras) == 1, feature_key=feature_param,
+                       rows_leaves={"sh": tuple(sh_params)} if sh_params else None, rows_chunks=rows_chunks)
 
     if densification_stats:
         with torch.no_grad():

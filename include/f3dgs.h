@@ -307,6 +307,19 @@ typedef void (*f3dgs_stage_fn)(void* ctx, void* stream /* hipStream_t */);
 void f3dgs_set_feature_grad_ready_callback(f3dgs_stage_fn fn, void* ctx);
 
 /*
+ * Second optional notification inside f3dgs_backward (no counterpart in the reference): with a callback registered the
+ * per-Gaussian stage (K8 + K9, R/cuda_rasterizer/backward.cu:145-404 - row-parallel) runs as `chunks` launches over
+ * consecutive row ranges, and `fn(ctx, stream, row_begin, row_end)` is called on the calling host thread right after the
+ * launch covering Gaussians [row_begin, row_end) has been ENQUEUED: from that point of the stream on, rows
+ * [row_begin, row_end) of EVERY per-Gaussian output (dL_dmean3D, dL_dsh, dL_dscale, dL_drot, dL_dopacity, dL_dcolor,
+ * dL_dmean2D, dL_dcov3D) are final.  A data-parallel caller starts the all-reduce of those rows (the SH gradient is
+ * 48 of the 59 non-feature floats per Gaussian) while the later chunks still run.  Ranges are disjoint, ascending and
+ * cover [0, P); row_begin is a multiple of 64.  chunks <= 1: one launch, one call.  Thread-local; NULL removes it.
+ */
+typedef void (*f3dgs_rows_fn)(void* ctx, void* stream /* hipStream_t */, int row_begin, int row_end);
+void f3dgs_set_grad_rows_ready_callback(f3dgs_rows_fn fn, void* ctx, int chunks);
+
+/*
  * Test / profiling hooks (not part of the reference surface).  They expose
  * the private state written by f3dgs_forward so that every stage can be
  * compared with the oracle in isolation.  Each copies `count` elements

@@ -178,3 +178,39 @@ def test_collective_schedule_does_not_depend_on_local_gradients(tmp_path):
         assert np.allclose(got["big"], 3.0 * base)
         assert np.allclose(got["c"], 1.0)                   # rank 1 contributed zeros instead of skipping the collective
         assert np.allclose(got["big2"], 2.0 * 3.0 * base)   # every rank holds the first SUM: reduced again = x world
+
+
+def _rows_worker(rank, world, port, out_dir):
+    """dp.RowsGradOverlap driven by hand (the op calls `_hook` after every row chunk of its per-Gaussian stage): row slices
+    of the op-level gradients are reduced in place, chunk by chunk; only the named tensors travel."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "feature-3dgs_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dp
+    P = 300
+    grads = {"sh": torch.arange(P * 16 * 3, dtype=torch.float32).reshape(P, 16, 3) * (rank + 1),
+             "means3D": torch.full((P, 3), float(rank + 1)), "empty": torch.zeros(0)}
+    rv = dp.RowsGradOverlap(None, names=("sh", "empty"), chunks=3)
+    for r0, r1 in ((0, 128), (128, 256), (256, 300)):
+        rv._hook(r0, r1, grads)
+    rv.finish()
+    done = rv.reduced({"sh": ("_features_dc", "_features_rest"), "means3D": ("_xyz",)})
+    np.savez(os.path.join(out_dir, f"rows{rank}.npz"), sh=grads["sh"].numpy(), m=grads["means3D"].numpy(),
+             rows=np.array(rv.rows), done=np.array(done))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rows_overlap_reduces_row_chunks_in_place(tmp_path):
+    world = 2
+    mp.spawn(_rows_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    base = np.arange(300 * 16 * 3, dtype=np.float32).reshape(300, 16, 3)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rows{rank}.npz"))
+        assert np.array_equal(got["sh"], 3.0 * base)                      # every row range was summed exactly once
+        assert np.array_equal(got["m"], np.full((300, 3), float(rank + 1), np.float32))      # not named: untouched
+        assert got["rows"].tolist() == [[0, 128], [128, 256], [256, 300]]
+        assert got["done"].tolist() == ["_features_dc", "_features_rest"]

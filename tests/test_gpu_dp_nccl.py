@@ -65,7 +65,10 @@ def _worker(rank, world, port, out_dir):
     res = {}
     for overlap in (False, True):
         leaves = _leaves(dev)
-        grads = dp.dp_step(lambda vid: _run_view(vid, leaves, dev), leaves, dp.views_for_rank(8, rank, world), overlap=overlap)
+        # with the overlap: feature gradient reduced from inside the blend stage, SH gradient in three row ranges from inside
+        # the per-Gaussian stage (dp.RowsGradOverlap; "shs" is the op's direct input here)
+        grads = dp.dp_step(lambda vid: _run_view(vid, leaves, dev), leaves, dp.views_for_rank(8, rank, world), overlap=overlap,
+                           rows_leaves={"sh": ("shs",)} if overlap else None, rows_chunks=3)
         torch.cuda.synchronize()
         for k in KEYS:
             assert grads[k] is leaves[k].grad
@@ -119,7 +122,8 @@ def _solo_worker(rank, port, out_dir):
     res = {}
     for overlap in (False, True):
         leaves = _leaves(dev)
-        dp.dp_step(lambda vid: _run_view(vid, leaves, dev), leaves, [0], overlap=overlap)
+        dp.dp_step(lambda vid: _run_view(vid, leaves, dev), leaves, [0], overlap=overlap,
+                   rows_leaves={"sh": ("shs",)} if overlap else None, rows_chunks=3)
         torch.cuda.synchronize()
         for k in KEYS:
             res[f"{'ov' if overlap else 'plain'}_{k}"] = leaves[k].grad.cpu().numpy()

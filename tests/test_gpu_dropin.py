@@ -247,3 +247,41 @@ def test_c_abi_direct_call_with_caller_owned_buffers():
                            fp(d["campos"]), ctypes.c_float(sc["tanfovx"]), ctypes.c_float(sc["tanfovy"]), 0, fp(color),
                            fp(feat), fp(depth), fp(radii), 0, stream, ctypes.byref(n_rendered))
     assert rc < 0 and b"null" in lib.f3dgs_last_error()
+
+
+def test_grad_rows_hook_sees_final_rows_chunk_by_chunk():
+    """f3dgs_set_grad_rows_ready_callback through the binding: the per-Gaussian stage runs in row chunks, the hook is called
+    once per chunk with disjoint ascending ranges covering [0, P), and what it reads of rows [r0, r1) at that point of the
+    stream is what the call finally returns; the gradients themselves do not depend on the chunking."""
+    import diff_gaussian_rasterization as dgr
+    sc = _scene()
+    d = ru.device_inputs(sc, sc["C"], DEV)
+    prod = ru.product_module()
+    fw = ru.raw_forward(prod, sc, d)
+    plain = ru.raw_backward(prod, sc, d, fw)
+    seen, snaps, done = [], [], []
+
+    def on_rows(r0, r1, grads):
+        seen.append((r0, r1))
+        snaps.append({k: v[r0:r1].clone() for k, v in grads.items() if v.numel()})     # enqueued behind the chunk's launch
+
+    dgr.set_grad_rows_hook(on_rows, 5, lambda: done.append(1))
+    try:
+        chunked = ru.raw_backward(prod, sc, d, fw)
+    finally:
+        dgr.set_grad_rows_hook(None)
+    P = sc["P"]
+    assert 2 <= len(seen) <= 5 and seen[0][0] == 0 and seen[-1][1] == P
+    assert all(a[1] == b[0] for a, b in zip(seen, seen[1:])) and all(r0 % 64 == 0 for r0, _ in seen)
+    for k in plain:      # the blend stage in front of it accumulates with atomics: equal up to their summation order
+        assert float((chunked[k] - plain[k]).abs().max()) <= 1e-4 * float(plain[k].abs().max()) + 1e-12, k
+    name_of = {"sh": "dL_dsh", "means3D": "dL_dmeans3D", "scales": "dL_dscales", "rotations": "dL_drotations",
+               "opacities": "dL_dopacity", "colors_precomp": "dL_dcolors", "means2D": "dL_dmeans2D", "cov3Ds_precomp": "dL_dcov3D"}
+    for (r0, r1), snap in zip(seen, snaps):
+        assert set(snap) == set(name_of)
+        for k, t in snap.items():
+            assert torch.equal(t, chunked[name_of[k]][r0:r1]), (k, r0, r1)
+    # the on_done hook belongs to the autograd function, not to the raw binding; without a hook the stage is one launch again
+    seen.clear()
+    ru.raw_backward(prod, sc, d, fw)
+    assert not seen and not done
