@@ -8,7 +8,8 @@ buffer sizing, the 8-byte instance-count read-back, output/gradient allocation; 
 with a FRESH set of upstream gradients every step (a rotating pool generated before the timed region).
 With N > 1 GPUs every rank renders its own view of the same Gaussians (view r is rotated r*5 degrees)
 and the per-Gaussian gradients ((59+C) floats each) are summed over RCCL inside the step; the feature
-gradient's all-reduce starts inside the backward pass (dp.FeatureGradOverlap).
+gradient's all-reduce starts inside the backward pass (dp.FeatureGradOverlap), the SH gradient's inside its last
+stage, row chunk by row chunk (dp.RowsGradOverlap).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1..c5] [--no-cpu-baseline] [--comm-only]
 
@@ -216,7 +217,10 @@ def make_step(scene, dev, pool=4, dist=None, overlap=True):
             fwd_bwd(i)
             return
         sub = {k: leaves[k] for k in reduce_keys}
-        dp.dp_step(lambda _vid: fwd_bwd(i), sub, [0], overlap=overlap)
+        # overlap: feature gradient reduced from inside the blend stage, SH gradient in four row ranges from inside the
+        # per-Gaussian stage ("shs" is the op's direct input here), the four small tensors in one bucket afterwards
+        dp.dp_step(lambda _vid: fwd_bwd(i), sub, [0], overlap=overlap, rows_leaves={"sh": ("shs",)} if overlap else None,
+                   rows_chunks=4)
     return step, leaves
 
 
@@ -594,7 +598,7 @@ def main():
                        "P": P, "Pv": stats["Pv"], "N": stats["N"], "N_r": stats["N_r"],
                        "parallelism": "single GPU" if world == 1 else
                        f"view-sharded dp{world} + RCCL all-reduce of (59+C) floats per Gaussian"
-                       + ("" if args.no_overlap else ", feature all-reduce started inside the backward pass")},
+                       + ("" if args.no_overlap else ", feature and SH all-reduces started inside the backward pass")},
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "n": len(per),
                         "source": "HIP event pair per step on the op's stream, rank 0, in the auxiliary run with all stage events",
                         "ms_per_step_without_events": 1e3 * el_plain / args.steps,

@@ -539,6 +539,11 @@ __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(
 }
 
 template <int CH, int PPL, int CHK, int GI, bool BASE>
+__global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(2, 4))) render_forward_mfma_kernel_w2(FwdArgs a) {
+    render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
+}
+
+template <int CH, int PPL, int CHK, int GI, bool BASE>
 __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(4, 4))) render_forward_mfma_kernel_w4(FwdArgs a) {
     render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
 }
@@ -556,6 +561,14 @@ void launch_shape(const FwdArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((render_forward_mfma_kernel_w4<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
             return;
         }
+    }
+    if constexpr (CH >= 128) {
+        // 128 accumulator registers per quadrant: two waves per SIMD, 70 KB of LDS per workgroup (above the 64 KB default limit)
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_forward_mfma_kernel_w2<CH, PPL, CHK, GI, BASE>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NW * sizeof(FwdChunkMF<CH, CHK>)));
+        (void)once;
+        hipLaunchKernelGGL((render_forward_mfma_kernel_w2<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
+        return;
     }
     if (CH <= 32 || (PPL == 1 && CHK == 32)) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
@@ -615,8 +628,13 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
         else launch_one<0, 4>(a, s);
         return;
     }
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        a.c0 = c0; a.nc = min(64, C - c0); a.write_base = (c0 == 0);
+    // channel window: 64 channels, or 128 on the matrix pipe when more than 64 remain (every window re-evaluates the
+    // blend weights of the whole list: fewer, wider windows - two waves per SIMD, the matrix pipe hides the rest)
+    const int wide = (mf && options().fwd_wide != 0) ? 128 : 64;
+    for (int c0 = 0; c0 < C;) {
+        const int win = (C - c0 > 64) ? wide : 64;
+        a.c0 = c0; a.nc = min(win, C - c0); a.write_base = (c0 == 0);
+        c0 += win;
         if (a.nc <= 4) {
             // small feature dims: one quadrant per wave measured fastest (c2, C = 16: 0.44 ms vs 0.47 / 0.60 for 2 / 4)
             if (ppl == 4) launch_one<4, 4>(a, s); else if (ppl == 2) launch_one<4, 2>(a, s); else launch_one<4, 1>(a, s);
@@ -625,9 +643,11 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
         } else if (a.nc <= 32) {
             if (mf) { if (ppl == 2) launch_one_mf<32, 2>(a, s); else launch_one_mf<32, 1>(a, s); }     // automatic: one quadrant per wave
             else if (ppl == 1) launch_one<32, 1>(a, s); else if (ppl == 4) launch_one<32, 4>(a, s); else launch_one<32, 2>(a, s);
-        } else {
+        } else if (a.nc <= 64) {
             if (mf) { if (ppl == 2) launch_one_mf<64, 2>(a, s); else launch_one_mf<64, 1>(a, s); }
             else if (ppl == 2) launch_one<64, 2>(a, s); else launch_one<64, 1>(a, s);
+        } else {
+            if (a.write_base) launch_shape<128, 1, 32, 2, true>(a, s); else launch_shape<128, 1, 32, 2, false>(a, s);
         }
     }
 }

@@ -11,13 +11,15 @@ xGMI on MI355X is a point-to-point mesh (7 links x ~153 GB/s per GPU): a ring al
 link, so the gradients travel as a few LARGE collectives (SH and feature gradients in place, the four
 small tensors in one flat bucket), which lets RCCL use its direct algorithms across all links.
 
-Three ways to exchange, all IN PLACE on the tensors handed in (so `leaf.grad` is what the optimiser reads):
+Four ways to exchange, all IN PLACE on the tensors handed in (so `leaf.grad` is what the optimiser reads):
 
   * `all_reduce_gaussian_grads(grads)`            after the backward pass, everything at once;
   * `FeatureGradOverlap`                          starts the all-reduce of the (largest) feature gradient as
                                                   soon as the blend backward has produced it, on a side
-                                                  stream, while the op's last kernel (preprocess backward)
+                                                  stream, while the op's last stage (preprocess backward)
                                                   still runs;
+  * `RowsGradOverlap`                             that last stage runs in row chunks; the SH gradient (48 of the
+                                                  59 remaining floats) is reduced chunk by chunk behind it;
   * `reduce_scatter_gaussian_grads(grads, ...)`   for a sharded optimiser: every rank receives only the sum
                                                   of ITS slice of Gaussians - half the bytes of an all-reduce;
                                                   `all_gather_params` redistributes the updated parameters.
