@@ -100,6 +100,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        # undefined upstream gradients arrive as None instead of zero tensors: `radii` is an integer output, autograd would
+        # otherwise fill a (P,) int32 zero tensor for it in front of every backward call (one launch for nothing)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, semantic_feature, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer)
         return color, feature_map, radii, depth
@@ -109,6 +112,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, semantic_feature, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
          binningBuffer, imgBuffer) = ctx.saved_tensors
+        H, W = rs.image_height, rs.image_width
+        if grad_out_color is None:      # an output the loss did not use: its gradient is zero
+            grad_out_color = means3D.new_zeros((3, H, W))
+        if grad_out_feature is None:
+            grad_out_feature = means3D.new_zeros((semantic_feature.shape[-1], H, W))
+        if grad_depth is None:
+            grad_depth = means3D.new_zeros((1, H, W))
         args = (rs.bg, means3D, radii, colors_precomp, semantic_feature, scales, rotations, rs.scale_modifier,
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color,
                 grad_out_feature, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,

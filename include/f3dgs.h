@@ -326,7 +326,7 @@ void f3dgs_set_grad_rows_ready_callback(f3dgs_rows_fn fn, void* ctx, int chunks)
  * starting at element 0 into a HOST buffer and synchronises the stream.
  *   what: "rec" (12 floats per Gaussian: mean_x, mean_y, conic a,b,c, opacity, r,g,b, depth, radius bits, pad;
  *         defined only where radii > 0)  "clamped"(u8 bitmask)  "tiles_touched"(u32)  "depth_key"(u32)
- *         "order"(u32 x P, depth order)  "offsets"(u32 x P)  "counters"(16 x u32: [0] = entries of point_list,
+ *         "order"(u32 x P, depth order)  "counters"(16 x u32: [0] = entries of point_list,
  *         [1] = reference-style num_rendered)  "point_list"(u32 x R)  "tile_sorted"(u32 x R)
  *         "ranges"(uint2 per tile)  "final_T"(float per pixel)  "n_contrib"(u32 per pixel)
  */
