@@ -197,6 +197,7 @@ const OptionDesc kOptions[] = {
     {"fwd_ppl", "F3DGS_FWD_PPL", &Options::fwd_ppl, 0},
     {"fwd_variant", "F3DGS_FWD_VARIANT", &Options::fwd_variant, 0},
     {"fwd_wide", "F3DGS_FWD_WIDE", &Options::fwd_wide, 1},
+    {"fwd_solo", "F3DGS_FWD_SOLO", &Options::fwd_solo, 1},
     {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},
 #ifdef F3DGS_DEV
     {"dev", "F3DGS_DEV_BITS", &Options::dev, 0},

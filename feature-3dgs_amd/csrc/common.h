@@ -172,6 +172,7 @@ struct Options {
     int fwd_ppl;         // quadrants per wave of the blend forward: 0 = automatic, 1/2/4
     int fwd_variant;     // blend forward chunk/group shape: 0 = default
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
+    int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)
     int sort_onesweep;   // 1: single-pass radix passes with decoupled look-back (measured slower on MI355X; default 0)
 #ifdef F3DGS_DEV
     int dev;             // development builds only (make DEV=1): work-skipping experiments, never in a release library

@@ -46,6 +46,7 @@ struct FwdArgs {
     int C;        // total feature channels (row stride of feat)
     int c0, nc;   // channel window handled by this launch
     int write_base;  // 1: also write colour / depth / final_T / n_contrib
+    int solo;        // one quadrant per wave: 64-thread workgroups, grid = 4 x tiles
     int dev;         // development builds: work-skipping bits (128: no feature gathers  256: no matrix instructions  512: no alpha evaluation skip)
 };
 
@@ -60,11 +61,14 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
     constexpr int NW = 4 / PPL;
     constexpr int CHV = CH / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    FwdChunk<CH>& ck = reinterpret_cast<FwdChunk<CH>*>(smem)[NW > 1 ? wave : 0];
+    // a.solo (one quadrant per wave): one 64-thread workgroup per quadrant, see render_forward_mfma_body
+    const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);
+    const bool solo = PPL == 1 && a.solo;
+    const int wave = solo ? (int)(vb & 3u) : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    FwdChunk<CH>& ck = reinterpret_cast<FwdChunk<CH>*>(smem)[(NW > 1 && !solo) ? wave : 0];
 
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t tile = solo ? vb >> 2 : vb;
     const int tx = tile % a.gx, ty = tile / a.gx;
     uint2 rg;
     if (a.write_base) {   // first channel window: decode {min, UINT_MAX - (max + 1)}; untouched = empty tile
@@ -273,11 +277,16 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     constexpr int NB = CH / 32;
     constexpr int NP = GI / 2;        // instance pairs (MFMA K = 2) per group
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    FwdChunkMF<CH, CHK>& ck = reinterpret_cast<FwdChunkMF<CH, CHK>*>(smem)[NW > 1 ? wave : 0];
+    // a.solo (one quadrant per wave only): every quadrant wave is its own 64-thread workgroup - the waves never
+    // synchronise, so a workgroup of four only keeps the slots of its finished quadrants occupied until the slowest one
+    // is done.  Four consecutive virtual ids = the quadrants of one tile (same XCD, see xcd_remap).
+    const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);
+    const bool solo = PPL == 1 && a.solo;
+    const int wave = solo ? (int)(vb & 3u) : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    FwdChunkMF<CH, CHK>& ck = reinterpret_cast<FwdChunkMF<CH, CHK>*>(smem)[(NW > 1 && !solo) ? wave : 0];
 
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t tile = solo ? vb >> 2 : vb;
     const int tx = tile % a.gx, ty = tile / a.gx;
     uint2 rg;
     if (a.write_base) {   // first channel window: decode {min, UINT_MAX - (max + 1)}; untouched = empty tile
@@ -554,8 +563,9 @@ __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(
 template <int CH, int PPL, int CHK, int GI, bool BASE>
 void launch_shape(const FwdArgs& a, hipStream_t s) {
     constexpr int NW = 4 / PPL;
-    const size_t lds = NW * sizeof(FwdChunkMF<CH, CHK>);
-    const dim3 grid(a.gx * a.gy), block(256 / PPL);
+    const bool solo = PPL == 1 && a.solo;
+    const size_t lds = (solo ? 1 : NW) * sizeof(FwdChunkMF<CH, CHK>);
+    const dim3 grid(solo ? 4 * a.gx * a.gy : a.gx * a.gy), block(solo ? 64 : 256 / PPL);
     if constexpr (CH <= 32 && PPL == 1 && CHK == 32) {
         if (options().fwd_w4) {
             hipLaunchKernelGGL((render_forward_mfma_kernel_w4<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
@@ -598,8 +608,9 @@ void launch_one_mf(const FwdArgs& a, hipStream_t s) {
 template <int CH, int PPL>
 void launch_one(const FwdArgs& a, hipStream_t s) {
     constexpr int NW = 4 / PPL;
-    const size_t lds = NW * sizeof(FwdChunk<CH>);
-    hipLaunchKernelGGL((render_forward_kernel<CH, PPL>), dim3(a.gx * a.gy), dim3(256 / PPL), lds, s, a);
+    const bool solo = PPL == 1 && a.solo;
+    const size_t lds = (solo ? 1 : NW) * sizeof(FwdChunk<CH>);
+    hipLaunchKernelGGL((render_forward_kernel<CH, PPL>), dim3(solo ? 4 * a.gx * a.gy : a.gx * a.gy), dim3(solo ? 64 : 256 / PPL), lds, s, a);
 }
 
 
@@ -614,6 +625,7 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     a.final_T = final_T; a.n_contrib = n_contrib; a.out_color = out_color; a.out_feat = out_feat;
     a.out_depth = out_depth;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
+    a.solo = options().fwd_solo;
 #ifdef F3DGS_DEV
     a.dev = options().dev;
 #else
