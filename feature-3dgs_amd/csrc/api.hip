@@ -194,6 +194,7 @@ const OptionDesc kOptions[] = {
     {"fwd_w4", "F3DGS_FWD_W4", &Options::fwd_w4, 1},
     {"bwd_wave_cull", "F3DGS_BWD_WAVE_CULL", &Options::bwd_wave_cull, 1},
     {"bwd_pl", "F3DGS_BWD_PL", &Options::bwd_pl, -1},
+    {"bwd_order", "F3DGS_BWD_ORDER", &Options::bwd_order, 1},
     {"fwd_ppl", "F3DGS_FWD_PPL", &Options::fwd_ppl, 0},
     {"fwd_variant", "F3DGS_FWD_VARIANT", &Options::fwd_variant, 0},
     {"fwd_wide", "F3DGS_FWD_WIDE", &Options::fwd_wide, 1},
@@ -401,6 +402,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     uint32_t* in_tile = (passes % 2 == 0) ? bin.tile_sorted : bin.tile_tmp;
     uint32_t* in_id = (passes % 2 == 0) ? bin.point_list : bin.id_tmp;
     if (onesweep) {
+        HIP_TRY(hipMemsetAsync(img.tile_len, 0, tiles * sizeof(uint32_t), s));
         // emits, builds the tile digit histograms, presets the ranges
         launch_emit_scan(P, geom, bin, order, vp.gx, vp.gy, cull, in_tile, in_id, N, bin.ranges_enc, s);
         if ((rc = check_debug(debug, s, "emit"))) return rc;
@@ -412,8 +414,9 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
         if (N == 0) {
             // all-ones = "no entry yet" for both halves of the encoded ranges (see BinState::ranges_enc)
             HIP_TRY(hipMemsetAsync(bin.ranges_enc, 0xFF, tiles * sizeof(uint2), s));
+            HIP_TRY(hipMemsetAsync(img.tile_len, 0, tiles * sizeof(uint32_t), s));
         } else {
-            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, bin.ranges_enc, s);   // presets the ranges too
+            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, bin.ranges_enc, img.tile_len, s);   // presets the ranges too
             if ((rc = check_debug(debug, s, "emit"))) return rc;
             tm.mark("emit");
             // the final pass also records the tile ranges
@@ -425,7 +428,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     }
 
     launch_render_forward(vp, C, bin.ranges_enc, img.ranges, bin.point_list, geom.rec, semantic_feature, img.final_T,
-                          img.n_contrib, out_color, out_feature_map, out_depth, s);
+                          img.n_contrib, out_color, out_feature_map, out_depth, img.tile_len, s);
     if ((rc = check_debug(debug, s, "render"))) return rc;
     tm.mark("render_fwd");
     HIP_TRY(hipGetLastError());
@@ -479,7 +482,7 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     tm.mark("zero");
     if (R > 0)
         launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,
-                               dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, s);
+                               dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, img.tile_len, img.tile_order, s);
     if ((rc = check_debug(debug, s, "render backward"))) return rc;
     tm.mark("render_bwd");
     if (g_feature_ready_fn) g_feature_ready_fn(g_feature_ready_ctx, stream);   // dL_dsemantic_feature is final on `s` here

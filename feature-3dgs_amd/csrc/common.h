@@ -143,12 +143,16 @@ struct ImageState {
     float* final_T;        // H*W
     uint32_t* n_contrib;   // H*W
     uint2* ranges;         // tiles
+    uint32_t* tile_len;    // tiles   longest walk of the tile = max n_contrib of its pixels (blend forward, atomicMax)
+    uint32_t* tile_order;  // tiles   tiles by descending tile_len: workgroup order of the pixel-lane blend backward
     static ImageState carve(char* base, size_t HW, size_t tiles, size_t* bytes) {
         Carver c(base);
         ImageState s;
         s.final_T = c.take<float>(HW);
         s.n_contrib = c.take<uint32_t>(HW);
         s.ranges = c.take<uint2>(tiles);
+        s.tile_len = c.take<uint32_t>(tiles);
+        s.tile_order = c.take<uint32_t>(tiles);
         if (bytes) *bytes = c.total();
         return s;
     }
@@ -168,6 +172,7 @@ struct Options {
     int bwd_half;        // blend backward: chunks of 32 instances against two pixel halves (64-pixel blocks only)
     int fwd_w4;          // blend forward, 32 channels, one quadrant per wave: four waves per SIMD (default 1)
     int bwd_wave_cull;   // blend backward: wave-level footprint culling (default 1)
+    int bwd_order;       // pixel-lane blend backward: workgroups take the tiles longest walk first (default 1)
     int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 16; needs feature_mfma
     int fwd_ppl;         // quadrants per wave of the blend forward: 0 = automatic, 1/2/4
     int fwd_variant;     // blend forward chunk/group shape: 0 = default
@@ -217,9 +222,9 @@ void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, ui
 // `ranges_enc` (optional): the final pass records every tile's [min, max + 1) output positions (BinState::ranges_enc)
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
                              uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s);
-// also presets `ranges_enc` (all-ones = "no entry yet") for the final tile-sort pass
+// also presets `ranges_enc` (all-ones = "no entry yet") for the final tile-sort pass and zeroes `tile_len`
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
-                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, hipStream_t s);
+                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, hipStream_t s);
 // single-pass flavour (option sort_onesweep): offsets by decoupled look-back inside the emit kernel, which also
 // produces the tile digit histograms, presets `ranges` for the final sort pass and zero-fills b.tile_status
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,
@@ -272,15 +277,19 @@ size_t knn_scratch_bytes(size_t P);
 void launch_knn_mean_dist2(int P, const float* points, float* out, char* scratch, hipStream_t s);
 
 // render_fwd.hip / render_bwd.hip
+// `tile_len` (zero-filled by the caller): receives the longest walk of every tile (max n_contrib of its pixels)
 void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc, uint2* ranges, const uint32_t* point_list,
                            const SplatRec* rec, const float* feat, float* final_T,
-                           uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, hipStream_t s);
+                           uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, uint32_t* tile_len,
+                           hipStream_t s);
+// `tile_len` / `tile_order`: the pixel-lane kernel takes its tiles longest walk first (order built here, one small launch)
 void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
                             const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                             const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
-                            float* dL_dfeature, hipStream_t s);
+                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, hipStream_t s);
 struct BwdArgs;
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s);     // render_bwd_pl.hip
+void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, hipStream_t s);
 
 // ---- device helpers --------------------------------------------------------------------------------
 #if defined(__HIPCC__)

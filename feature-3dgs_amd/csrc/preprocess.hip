@@ -347,13 +347,15 @@ __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_offsets,
                       const uint32_t* __restrict__ sub, const uint32_t* __restrict__ tiles_touched,
                       const SplatRec* __restrict__ rec, int gx, int gy, int cull, uint32_t* __restrict__ inst_tile,
-                      uint32_t* __restrict__ inst_id, uint2* __restrict__ ranges_enc) {
+                      uint32_t* __restrict__ inst_id, uint2* __restrict__ ranges_enc, uint32_t* __restrict__ tile_len) {
     __shared__ uint32_t s_tile[4][EMIT_CAP];
     __shared__ uint32_t s_id[4][EMIT_CAP];
     // all-ones = "no entry yet" for both halves of the encoded tile ranges (BinState::ranges_enc; the final sort pass,
-    // two launches further on, lowers them with atomicMin)
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (uint32_t)(gx * gy); t += gridDim.x * 256)
+    // two launches further on, lowers them with atomicMin); zero for the tiles' walk lengths (raised by the blend forward)
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (uint32_t)(gx * gy); t += gridDim.x * 256) {
         ranges_enc[t] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        tile_len[t] = 0u;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool valid = i < P;
@@ -773,9 +775,9 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
 }
 
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
-                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, hipStream_t s) {
+                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, hipStream_t s) {
     hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.scan_tmp, g.scan_sub,
-                       g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc);
+                       g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc, tile_len);
 }
 
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,

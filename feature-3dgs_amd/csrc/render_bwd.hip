@@ -682,8 +682,9 @@ void launch_npix(const BwdArgs& a, int npix, hipStream_t s) {
 void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
                             const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                             const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
-                            float* dL_dfeature, hipStream_t s) {
+                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, hipStream_t s) {
     BwdArgs a;
+    a.order = nullptr;
     a.ranges = ranges; a.point_list = point_list; a.rec = rec;
     a.bg = vp.bg;
     a.final_T = final_T; a.n_contrib = n_contrib; a.dL_dpix = dL_dpix; a.dL_dfeat = dL_dfeat;
@@ -715,6 +716,10 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     // pixel-lane formulation (render_bwd_pl.hip): option bwd_pl = 1 always, 0 never, -1 (default) from 17 channels on - with
     // 16 or fewer one of its four matrix-pipe waves has no columns and the instance-lane kernel is a few per cent faster
     if ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > 16)) && opt.feature_mfma && !opt.bwd_npix) {
+        if (opt.bwd_order && tile_len && tile_order) {
+            launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, s);
+            a.order = tile_order;
+        }
         a.strip = 0; a.half = 0;
         launch_render_backward_pl(a, C, s);
 #ifdef F3DGS_DEV

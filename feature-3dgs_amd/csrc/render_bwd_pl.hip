@@ -115,7 +115,9 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: quadrant in phase 1, column block in phase 2
     PL_PHASE_BEGIN();     // [0] staging  [1] window + barriers  [2] phase 1  [3] phase 2  [4] flush  [5] chunks  [6] entries
 
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    // longest walks first: the launch is ~8 rounds of workgroups whose lifetimes differ by an order of magnitude, and a long
+    // one that starts late has the CU to itself at the end (c3: 0.708 -> 0.667 ms in a development build)
+    const uint32_t tile = a.order ? a.order[blockIdx.x] : xcd_remap(blockIdx.x, gridDim.x);
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 rg = a.ranges[tile];
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
@@ -527,6 +529,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     render_backward_pl_body<GEO, P1_NE, P1_PREF>(a);
 }
 
+// Tiles by descending walk length: counting sort on min(len, 4095) / 4 (1024 buckets, one workgroup).  The order inside a
+// bucket is whatever the atomics make of it - only the launch order of the workgroups depends on it.
+__global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ tile_len, uint32_t tiles,
+                                                          uint32_t* __restrict__ order) {
+    __shared__ uint32_t bucket[1024];
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    bucket[tid] = 0;
+    __syncthreads();
+    for (uint32_t t = tid; t < tiles; t += 1024) atomicAdd(&bucket[1023u - (min(tile_len[t], 4095u) >> 2)], 1u);
+    __syncthreads();
+    // exclusive scan of the 1024 bucket counts (bucket 0 = longest walks)
+    const uint32_t c = bucket[tid];
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, d, 64);
+        if ((int)lane >= d) inc += v;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < w; k++) base += wsum[k];
+    __syncthreads();
+    bucket[tid] = base + inc - c;
+    __syncthreads();
+    for (uint32_t t = tid; t < tiles; t += 1024)
+        order[atomicAdd(&bucket[1023u - (min(tile_len[t], 4095u) >> 2)], 1u)] = t;
+}
+
 template <bool GEO>
 void launch_pl(const BwdArgs& a, hipStream_t s) {
 #ifdef F3DGS_DEV
@@ -545,6 +577,10 @@ void launch_pl(const BwdArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tile_len, (uint32_t)tiles, order);
+}
 
 // Channel windows: the first carries the geometric sums and up to 32 channels, later ones up to 64 channels.
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s) {

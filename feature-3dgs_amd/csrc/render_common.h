@@ -96,6 +96,7 @@ struct BwdArgs {
     int strip;        // NPIX = 64: 16x4 pixel strips instead of 8x8 quadrants
     int half;         // NPIX = 64: chunks of 32 instances, the two halves of the wave take different pixels
     int no_wave_cull; // option bwd_wave_cull = 0: no wave-level footprint culling / compaction
+    const uint32_t* order;   // pixel-lane kernel: workgroup -> tile, longest walk first (null: XCD-contiguous tile order)
 #ifdef F3DGS_DEV
     int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs, bit3 phase timing
     unsigned long long* dev_cycles;   // [0] staging, [1] window walk, [2] pixel trips, [3] flush, [4] waves

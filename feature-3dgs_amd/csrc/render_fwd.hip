@@ -46,6 +46,7 @@ struct FwdArgs {
     int C;        // total feature channels (row stride of feat)
     int c0, nc;   // channel window handled by this launch
     int write_base;  // 1: also write colour / depth / final_T / n_contrib
+    uint32_t* tile_len;   // per tile: max n_contrib of its pixels (first window's launch; zero-filled beforehand)
     int solo;        // one quadrant per wave: 64-thread workgroups, grid = 4 x tiles
     int dev;         // development builds: work-skipping bits (128: no feature gathers  256: no matrix instructions  512: no alpha evaluation skip)
 };
@@ -220,6 +221,13 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
     }
 
     const size_t HW = (size_t)a.W * a.H;
+    if (a.write_base) {     // the tile's longest walk: what the pixel-lane backward orders its workgroups by
+        uint32_t m = 0;
+#pragma unroll
+        for (int p = 0; p < PPL; p++) m = max(m, last[p]);
+        m = wave_max_u32(m);
+        if (lane == 0 && m) atomicMax(&a.tile_len[tile], m);
+    }
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         if (!inside[p]) continue;
@@ -500,6 +508,13 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     }
 
     const size_t HW = (size_t)a.W * a.H;
+    if (BASE && a.write_base) {     // the tile's longest walk: what the pixel-lane backward orders its workgroups by
+        uint32_t m = 0;
+#pragma unroll
+        for (int p = 0; p < PPL; p++) m = max(m, last[p]);
+        m = wave_max_u32(m);
+        if (lane == 0 && m) atomicMax(&a.tile_len[tile], m);
+    }
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         if (BASE && a.write_base && inside[p]) {
@@ -618,7 +633,8 @@ void launch_one(const FwdArgs& a, hipStream_t s) {
 
 void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc, uint2* ranges, const uint32_t* point_list,
                            const SplatRec* rec, const float* feat, float* final_T,
-                           uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, hipStream_t s) {
+                           uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, uint32_t* tile_len,
+                           hipStream_t s) {
     FwdArgs a;
     a.ranges_enc = ranges_enc; a.ranges = ranges; a.point_list = point_list; a.rec = rec; a.feat = feat;
     a.bg = vp.bg;
@@ -626,6 +642,7 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     a.out_depth = out_depth;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
     a.solo = options().fwd_solo;
+    a.tile_len = tile_len;
 #ifdef F3DGS_DEV
     a.dev = options().dev;
 #else
