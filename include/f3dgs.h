@@ -72,8 +72,9 @@ const char* f3dgs_last_error(void);
  *   "profile"        1: per-stage HIP events, see f3dgs_profile_read; 2: only around the two blend kernels
  *   "sort_onesweep"  0 (default): three-kernel radix passes; 1: single-pass radix scatter with decoupled look-back
  *                    (measured slower on MI355X, kept as a tested alternative)
- *   "bwd_npix", "bwd_part_major", "bwd_strip", "bwd_half", "bwd_wave_cull", "bwd_pl", "fwd_ppl", "fwd_variant", "fwd_w4":
- *                    kernel-shape tuning knobs (0 = automatic where applicable)
+ *   "bwd_npix", "bwd_part_major", "bwd_strip", "bwd_half", "bwd_wave_cull", "bwd_pl", "fwd_ppl", "fwd_variant", "fwd_w4",
+ *   "fwd_wide", "fwd_solo", "bwd_order":
+ *                    kernel-shape and scheduling knobs (0 = automatic where applicable)
  * Unknown names return F3DGS_ERR_INVALID_ARGUMENT.
  */
 int f3dgs_set_option(const char* name, int value);
