@@ -302,3 +302,24 @@ def test_pixel_lane_and_instance_lane_backward_agree(C, option):
         b = g0[k]
         scale = float(np.abs(b).max()) + 1e-30
         assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
+
+
+@pytest.mark.parametrize("name", ["fwd_solo", "fwd_wide", "bwd_order"])
+@pytest.mark.parametrize("C", [16, 32, 200])
+def test_scheduling_options_keep_the_results(name, C, option):
+    """Options fwd_solo (one workgroup per quadrant wave), fwd_wide (128-channel forward windows) and bwd_order (tiles longest
+    walk first in the pixel-lane backward) select between complete code paths that do the same arithmetic: the forward images
+    are bit-identical with the option off, the gradients equal up to the order of their atomic sums."""
+    from synth import make_scene
+    sc = make_scene(P=30000, C=C, width=333, height=208, seed=31)
+    out1, g1 = run_hip(sc)
+    option(name, 0)
+    out0, g0 = run_hip(sc)
+    for k in ("color", "feature_map", "depth", "radii"):
+        assert np.array_equal(out1[k], out0[k]), k
+    for k, a in g1.items():
+        if a is None or a.size == 0:
+            continue
+        b = g0[k]
+        scale = float(np.abs(b).max()) + 1e-30
+        assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
