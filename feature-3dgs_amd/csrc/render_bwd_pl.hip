@@ -529,13 +529,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     render_backward_pl_body<GEO, P1_NE, P1_PREF>(a);
 }
 
-// Tiles by descending walk length: counting sort on min(len, 4095) / 4 (1024 buckets, one workgroup).  The order inside a
-// bucket is whatever the atomics make of it - only the launch order of the workgroups depends on it.
-__global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ tile_len, uint32_t tiles,
+// Tiles by descending walk length, XCD by XCD: workgroup b runs on XCD b % 8 (xcd_remap) and every XCD keeps its contiguous
+// run of tiles (neighbouring tiles share splat records and feature rows behind one L2) but takes it longest walk first.
+// One workgroup per XCD: counting sort of its run on min(len, 4095) / 4 (1024 buckets); the k-th tile of XCD x goes to
+// order[8 k + x].  The order inside a bucket is whatever the atomics make of it - only the launch order depends on it.
+__global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ tile_len, uint32_t tiles_all,
                                                           uint32_t* __restrict__ order) {
     __shared__ uint32_t bucket[1024];
     __shared__ uint32_t wsum[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t x = blockIdx.x, q = tiles_all / 8, r = tiles_all % 8;
+    const uint32_t first = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;      // as xcd_remap
+    const uint32_t tiles = x < r ? q + 1 : q;
+    tile_len += first;
     bucket[tid] = 0;
     __syncthreads();
     for (uint32_t t = tid; t < tiles; t += 1024) atomicAdd(&bucket[1023u - (min(tile_len[t], 4095u) >> 2)], 1u);
@@ -556,7 +562,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __rest
     bucket[tid] = base + inc - c;
     __syncthreads();
     for (uint32_t t = tid; t < tiles; t += 1024)
-        order[atomicAdd(&bucket[1023u - (min(tile_len[t], 4095u) >> 2)], 1u)] = t;
+        order[8u * atomicAdd(&bucket[1023u - (min(tile_len[t], 4095u) >> 2)], 1u) + x] = first + t;
 }
 
 template <bool GEO>
@@ -579,7 +585,7 @@ void launch_pl(const BwdArgs& a, hipStream_t s) {
 }  // namespace
 
 void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, hipStream_t s) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tile_len, (uint32_t)tiles, order);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, s, tile_len, (uint32_t)tiles, order);
 }
 
 // Channel windows: the first carries the geometric sums and up to 32 channels, later ones up to 64 channels.
