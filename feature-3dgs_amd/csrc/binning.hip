@@ -23,11 +23,11 @@ namespace f3dgs {
 
 namespace {
 
-// ---------------- list offsets in depth order: two-level sums (reduce / spine) -----------------------
+// ---------------- list offsets in depth order: two-level sums ------------------------------------------
 // Two levels are kept: the sum of every run of 64 consecutive items (`sub`, 64 per workgroup chunk - one run is what
-// one wave of the emit kernel owns) and the chunk totals, which the spine kernel turns into chunk offsets.  The emit
-// kernel rebuilds its offsets from the two (one 256-byte read + a wave scan), so no per-item offset array is written
-// or read and there is no third scan launch.
+// one wave of the emit kernel owns) and the chunk totals.  An emit wave rebuilds its offset from the two (the totals of
+// the chunks in front of its own, one 256-byte read of its chunk's runs, a wave scan), so no per-item offset array is
+// written or read and the scan is ONE launch.
 __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* __restrict__ in,
                                                           const uint32_t* __restrict__ gather, size_t n,
                                                           uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sub) {
@@ -54,29 +54,6 @@ __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* __rest
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(256) scan_spine_kernel(uint32_t* __restrict__ block_sums, size_t nb,
-                                                         uint32_t* __restrict__ total,
-                                                         const uint32_t* __restrict__ extra, size_t n_extra,
-                                                         uint32_t* __restrict__ extra_total) {
-    __shared__ uint32_t sh[8];
-    if (extra) {
-        uint32_t acc = 0;
-        for (size_t i = threadIdx.x; i < n_extra; i += 256) acc += extra[i];
-        uint32_t tot;
-        block_excl_scan_256(acc, sh, &tot);
-        if (threadIdx.x == 0) *extra_total = tot;
-    }
-    uint32_t carry = 0;
-    for (size_t base = 0; base < nb; base += 256) {
-        const size_t i = base + threadIdx.x;
-        const uint32_t v = i < nb ? block_sums[i] : 0;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan_256(v, sh, &tot);
-        if (i < nb) block_sums[i] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0 && total) *total = carry;
-}
 
 // ---------------- radix sort pass -------------------------------------------------------------------
 // Item order inside a workgroup chunk: wave w owns [w*1024, (w+1)*1024), visited in 16 steps of 64
@@ -441,13 +418,11 @@ __global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ dst, s
 
 }  // namespace
 
-void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, uint32_t* chunk_offsets, uint32_t* sub,
+void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, uint32_t* chunk_sums, uint32_t* sub,
                         hipStream_t s) {
     const size_t nb = scan_blocks(n);
     if (nb == 0) return;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, in, gather, n, chunk_offsets, sub);
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, s, chunk_offsets, nb, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                       (size_t)0, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, in, gather, n, chunk_sums, sub);
 }
 
 // ITEMS = keys per thread: 8 for the depth sort (2048-key workgroups: P = 1M gives 489 workgroups, about two per CU;

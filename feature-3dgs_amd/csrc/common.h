@@ -68,7 +68,7 @@ struct GeomState {
     uint32_t* val_a;
     uint32_t* val_b;
     uint32_t* hist;           // RADIX_BINS * sort_blocks(P) + RADIX_BINS
-    uint32_t* scan_tmp;       // scan_blocks(P) + 8      list offset of every chunk of SCAN_CHUNK Gaussians in depth order
+    uint32_t* scan_tmp;       // scan_blocks(P) + 8      list entries of every chunk of SCAN_CHUNK Gaussians in depth order
     uint32_t* scan_sub;       // 64 x scan_blocks(P)     list entries of every run of 64 Gaussians in depth order
     uint32_t* ref_partial;    // per preprocess workgroup: bounding-rectangle tile counts, then list-entry counts
     uint32_t* counters;       // 16 words: [0] = instances in the (culled) lists, [1] = reference num_rendered
@@ -212,9 +212,9 @@ void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D
 int preprocess_backward_row_align();     // row_begin of a partial launch must be a multiple of this
 
 // binning.hip
-// Two-level sums of in[gather[i]] (or in[i]) for the emit kernel: chunk_offsets[c] = exclusive prefix of the chunks of
-// SCAN_CHUNK items, sub[64 c + r] = sum of run r (64 items) of chunk c.
-void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, uint32_t* chunk_offsets, uint32_t* sub,
+// Two-level sums of in[gather[i]] (or in[i]) for the emit kernel: chunk_sums[c] = total of chunk c (SCAN_CHUNK items),
+// sub[64 c + r] = sum of run r (64 items) of chunk c.
+void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, uint32_t* chunk_sums, uint32_t* sub,
                         hipStream_t s);
 // Stable LSD radix sort of (key,val) u32 pairs on key bits [0, nbits).  Result lands in (key_out,val_out);
 // (key_in,val_in) and the *_tmp buffers are clobbered.  key_out/val_out may alias the tmp or in buffers

@@ -344,7 +344,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
 // 0.061 ms for 42 MB at c3).  Waves whose range exceeds the LDS slice (a few huge splats) store directly.
 constexpr int EMIT_CAP = 1024;      // list entries per wave in LDS (8 KB)
 __global__ void __launch_bounds__(256)
-emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_offsets,
+emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_sums,
                       const uint32_t* __restrict__ sub, const uint32_t* __restrict__ tiles_touched,
                       const SplatRec* __restrict__ rec, int gx, int gy, int cull, uint32_t* __restrict__ inst_tile,
                       uint32_t* __restrict__ inst_id, uint2* __restrict__ ranges_enc, uint32_t* __restrict__ tile_len) {
@@ -361,14 +361,17 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
     const bool valid = i < P;
     const uint32_t g = valid ? order[i] : 0u;
     const uint32_t cnt = valid ? tiles_touched[g] : 0u;
-    // the wave's range of the list starts at: offset of its chunk of SCAN_CHUNK Gaussians + the runs of 64 in front of its
-    // own inside the chunk (binning.hip: scan_reduce_kernel); a lane's run starts behind the lanes in front of it
+    // the wave's range of the list starts behind the runs of 64 in front of its own inside its chunk of SCAN_CHUNK Gaussians
+    // (binning.hip: scan_reduce_kernel); a lane's run starts behind the lanes in front of it
     const uint32_t first = (uint32_t)(blockIdx.x * 256 + 64 * w);              // the wave's first Gaussian (depth order)
     const uint32_t chunk = first / SCAN_CHUNK, run = (first % SCAN_CHUNK) / 64;
     uint32_t before = (uint32_t)lane < run ? sub[(size_t)chunk * 64 + lane] : 0u;
+    // ... and the chunks in front of its own: their totals are summed here (a few coalesced reads) rather than scanned by a
+    // launch of their own
+    for (uint32_t c = lane; c < chunk; c += 64) before += chunk_sums[c];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
-    const uint32_t base = chunk_offsets[chunk] + before;
+    const uint32_t base = before;
     const uint32_t inc = wave_incl_scan(cnt, lane);
     const uint32_t off0 = base + inc - cnt;
     const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
