@@ -366,8 +366,10 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                             // the three tests as lane masks (scalar ANDs); the select takes the mask as it stands
                             const unsigned long long okm = __ballot(pos_hi - (uint32_t)(NE * p + k) < last) & __ballot(!(power2 > 0.0f)) & __ballot(!(v < ALPHA_MIN));
                             if (okm) tm |= 1u << (NE * p + k);
-                            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(au[k]) : "v"(v), "s"(okm));   // exp2 may be inf where power > 0: selected away, never multiplied
-                            al[k] = fminf(ALPHA_MAX, au[k]);
+                            // exp2 may be inf where power > 0: selected away, never multiplied.  The clamp sits in the same block: behind
+                            // an opaque value the compiler puts a canonicalising v_max in front of the fminf
+                            static_assert(ALPHA_MAX == 0.99f, "literal below");
+                            asm("v_cndmask_b32_e64 %0, 0, %2, %3\n\tv_min_f32_e32 %1, 0x3f7d70a4, %0" : "=&v"(au[k]), "=v"(al[k]) : "v"(v), "s"(okm));
                             f[k] = __builtin_amdgcn_rcpf(1.f - al[k]);                                 // exactly 1 for skipped pairs
                             if constexpr (GEO) qd[k] = fmaf(e1[k].z, dR, fmaf(e1[k].w, dG, fmaf(e2[k].x, dB, e2[k].y * dD)));
                         }
