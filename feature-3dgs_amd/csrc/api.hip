@@ -187,16 +187,9 @@ const OptionDesc kOptions[] = {
     {"tile_cull", "F3DGS_TILE_CULL", &Options::tile_cull, 1},
     {"feature_mfma", "F3DGS_FEATURE_MFMA", &Options::feature_mfma, 1},
     {"profile", "F3DGS_PROFILE", &Options::profile, 0},
-    {"bwd_npix", "F3DGS_BWD_NPIX", &Options::bwd_npix, 0},
-    {"bwd_part_major", "F3DGS_BWD_PART_MAJOR", &Options::bwd_part_major, 0},
-    {"bwd_strip", "F3DGS_BWD_STRIP", &Options::bwd_strip, 0},
     {"bwd_half", "F3DGS_BWD_HALF", &Options::bwd_half, 1},
-    {"fwd_w4", "F3DGS_FWD_W4", &Options::fwd_w4, 1},
-    {"bwd_wave_cull", "F3DGS_BWD_WAVE_CULL", &Options::bwd_wave_cull, 1},
     {"bwd_pl", "F3DGS_BWD_PL", &Options::bwd_pl, -1},
     {"bwd_order", "F3DGS_BWD_ORDER", &Options::bwd_order, 1},
-    {"fwd_ppl", "F3DGS_FWD_PPL", &Options::fwd_ppl, 0},
-    {"fwd_variant", "F3DGS_FWD_VARIANT", &Options::fwd_variant, 0},
     {"fwd_wide", "F3DGS_FWD_WIDE", &Options::fwd_wide, 1},
     {"fwd_solo", "F3DGS_FWD_SOLO", &Options::fwd_solo, 1},
     {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},
@@ -256,7 +249,7 @@ CountReadback& count_readback() {
 
 extern "C" {
 
-int f3dgs_version(void) { return 30000; }   // 3.0.0 (major * 10000 + minor * 100 + patch): + option bwd_pl (pixel-lane blend backward, render_bwd_pl.hip)
+int f3dgs_version(void) { return 30100; }   // 3.1.0 (major * 10000 + minor * 100 + patch): seven untested shape knobs removed, f3dgs_option_name
 
 int f3dgs_set_option(const char* name, int value) {
     if (!name) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null option name");
@@ -276,6 +269,11 @@ int f3dgs_get_option(const char* name, int* value) {
             return F3DGS_OK;
         }
     return fail(F3DGS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+}
+
+const char* f3dgs_option_name(int index) {
+    const int n = (int)(sizeof(kOptions) / sizeof(kOptions[0]));
+    return (index >= 0 && index < n) ? kOptions[index].name : nullptr;
 }
 
 const char* f3dgs_last_error(void) { return g_err.c_str(); }

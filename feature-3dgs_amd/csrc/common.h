@@ -166,16 +166,9 @@ struct Options {
     int tile_cull;       // 1: drop instances whose 1/255 ellipse misses the tile (default); 0: reference-identical lists
     int feature_mfma;    // 1: feature contraction on the matrix pipe where a kernel variant exists (default)
     int profile;         // 1: record per-stage HIP events (f3dgs_profile_read)
-    int bwd_npix;        // pixels per wave of the blend backward: 0 = automatic, 32/64/128/256
-    int bwd_part_major;  // blend backward workgroup order
-    int bwd_strip;       // blend backward: 16x4 strips instead of 8x8 quadrants
-    int bwd_half;        // blend backward: chunks of 32 instances against two pixel halves (64-pixel blocks only)
-    int fwd_w4;          // blend forward, 32 channels, one quadrant per wave: four waves per SIMD (default 1)
-    int bwd_wave_cull;   // blend backward: wave-level footprint culling (default 1)
+    int bwd_half;        // instance-lane blend backward: chunks of 32 instances against two pixel halves (default 1); 0: 64-lane chunks
     int bwd_order;       // pixel-lane blend backward: workgroups take the tiles longest walk first (default 1)
     int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 16; needs feature_mfma
-    int fwd_ppl;         // quadrants per wave of the blend forward: 0 = automatic, 1/2/4
-    int fwd_variant;     // blend forward chunk/group shape: 0 = default
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
     int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)
     int sort_onesweep;   // 1: single-pass radix passes with decoupled look-back (measured slower on MI355X; default 0)

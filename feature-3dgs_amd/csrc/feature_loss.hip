@@ -177,15 +177,24 @@ fl_decoder_kernel(int N, int Np, int Cout, const float* __restrict__ X, const fl
     const int ntiles = (Cout + 31) / 32;
     for (int t = 0; t < ntiles; t++) {
         const int co0 = 32 * t, buf = t & 1;
-        if (t + 1 < ntiles) load_tile(co0 + 32, wnext);          // in flight during this tile's MFMAs
+        // the next W tile: in flight during this tile's MFMAs.  C = 128: requested behind phase A instead (phase B alone is 4 k
+        // matrix-pipe cycles), so that its sixteen registers never live next to the sixteen ground-truth values - together
+        // they put the kernel 21 registers above the 256 of two waves per SIMD (spills inside the tile loop)
+        constexpr bool LATE_W = C >= 128;
+        if (!LATE_W && t + 1 < ntiles) load_tile(co0 + 32, wnext);
         // ground truth and bias of this tile's rows, requested before phase A
         float gtv[16];
         f32x16 acc;                                              // starts at the bias: y = W x + b
+        // addresses as (wave-uniform row base) + (one 32-bit lane offset shared by the sixteen rows): row(r, h) = row(r, 0) + 4 h,
+        // so the lane-dependent part, 4 h N + p, does not depend on r (sixteen 64-bit per-lane addresses - and sixteen more for
+        // the sign bytes below - would otherwise be kept in registers across the tile)
+        const uint32_t gt_lane = (uint32_t)(4 * h) * (uint32_t)N + (uint32_t)(p_ok ? p : 0);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int co = co0 + mfma_row(r, h);
             const bool ok = p_ok && co < Cout;
-            gtv[r] = ok ? gt[(size_t)co * N + p] : 0.f;
+            const float* grow = gt + (size_t)(co0 + mfma_row(r, 0)) * N;      // uniform
+            gtv[r] = ok ? grow[gt_lane] : 0.f;
             acc[r] = co < Cout ? bias[co] : 0.f;
         }
         // ---- phase A (scheduling fences: without them every LDS read of the unrolled loop is hoisted to the top and
@@ -209,11 +218,13 @@ fl_decoder_kernel(int N, int Np, int Cout, const float* __restrict__ X, const fl
                 const float res = acc[r] - gtv[r];
                 loss += fabsf(res);
                 gv = res > 0.f ? inv_n : (res < 0.f ? -inv_n : 0.f);
-                S[(size_t)co * Np + p] = res > 0.f ? 1 : (res < 0.f ? -1 : 0);     // co-major: 32 consecutive bytes per half-wave
+                int8_t* srow = S + (size_t)(co0 + mfma_row(r, 0)) * Np;            // uniform
+                srow[(uint32_t)(4 * h) * (uint32_t)Np + (uint32_t)p] = res > 0.f ? 1 : (res < 0.f ? -1 : 0);     // co-major: 32 consecutive bytes per half-wave
             }
             acc[r] = gv;
         }
         // ---- phase B
+        if (LATE_W && t + 1 < ntiles) load_tile(co0 + 32, wnext);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const float* wr = &L.Ws[buf][mfma_row(r, h)][li];

@@ -175,8 +175,7 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
     constexpr int NB = MF ? CH / 32 : 0;       // 32-channel column blocks on the matrix pipe
     constexpr int CHV = CH / 4;
     constexpr int PARTS = 256 / NPIX;          // waves (workgroups) per tile
-    constexpr int ROWS = NPIX / 16;            // pixel rows owned by this wave (NPIX = 256/128/64)
-    constexpr int NV = NPIX >= 64 ? NPIX / 64 : 1;   // pixel-state registers per lane (NPIX = 32: lanes 32-63 idle here)
+    constexpr int NV = NPIX / 64;              // pixel-state registers per lane
     using Lds = BwdLds<CH, NPIX, MF, HALF>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds& L = *reinterpret_cast<Lds*>(smem);
@@ -186,23 +185,20 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
 #endif
     F3DGS_PHASE_BEGIN();
 
+    // the PARTS waves of one tile are scheduled back to back (L2 reuse of the tile's splat records)
     const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    // a.part_major: the PARTS waves of one tile are scheduled far apart (fewer simultaneous atomics on the same
-    // gradient lines) instead of back to back (better L2 reuse of the tile's splat records)
-    const uint32_t ntiles = gridDim.x / PARTS;
-    const uint32_t tile = a.part_major ? wg % ntiles : wg / PARTS;
-    const int part = a.part_major ? wg / ntiles : wg % PARTS;
+    const uint32_t tile = wg / PARTS;
+    const int part = wg % PARTS;
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 rg = a.ranges[tile];
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
     const size_t HW = (size_t)a.W * a.H;
-    // pixel block of this wave: NPIX >= 128 -> ROWS full rows; 64 -> one 8x8 quadrant (or a 16x4 strip when
-    // a.strip is set); 32 -> half a quadrant (8x4)
-    const int qd = NPIX == 32 ? part >> 1 : part;
-    const bool strip = NPIX == 64 && a.strip;
-    const int px0 = tx * TILE + ((NPIX <= 64 && !strip) ? (qd & 1) * 8 : 0);
-    const int py0 = ty * TILE + (strip ? part * 4 : (NPIX <= 64 ? (qd >> 1) * 8 + (NPIX == 32 ? (part & 1) * 4 : 0) : part * ROWS));
-    const int PW = (NPIX <= 64 && !strip) ? 8 : 16;    // pixels per row of this wave's block
+    // pixel block of this wave: one 8x8 quadrant of the tile
+    static_assert(NPIX == 64, "one quadrant per wave");
+    const int qd = part;
+    const int px0 = tx * TILE + (qd & 1) * 8;
+    const int py0 = ty * TILE + (qd >> 1) * 8;
+    constexpr int PW = 8;    // pixels per row of this wave's block
 
     // ---- stage the per-pixel data into LDS (lane = pixel here) -----------------------------------------
     // Order of the requests (vector memory returns in order, so what is needed first is asked for first):
@@ -276,7 +272,7 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
     }
     __builtin_amdgcn_wave_barrier();
     F3DGS_PHASE_END(cyc_stage);
-    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+    const float ddelx_dx = uniform_f(0.5f * a.W), ddely_dy = uniform_f(0.5f * a.H);
 
     // ---- one (compacted) chunk of up to 64 splats against all live pixels of the wave ---------------------
     auto process = [&](const SplatLane& sl_in, const uint32_t gid_in, const uint32_t pos_min, const int n_inst) {
@@ -546,14 +542,14 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
     // ---- walk the list back to front in windows of 64 positions; splats whose 1/255 footprint misses this
     // wave's pixel block are dropped (rect_hit, exact-safe) and the survivors of consecutive windows are packed
     // into full 64-lane chunks with ds_permute (lane 0 = farthest back stays true across windows) ----------------
-    const float wx0 = (float)px0, wx1 = (float)(px0 + PW - 1), wy0 = (float)py0, wy1 = (float)(py0 + NPIX / PW - 1);
+    const float wx0 = uniform_f((float)px0), wx1 = uniform_f((float)(px0 + PW - 1));
+    const float wy0 = uniform_f((float)py0), wy1 = uniform_f((float)(py0 + NPIX / PW - 1));
     SplatLane cur;
     cur.mx = cur.my = cur.ca = cur.cb = cur.cc = cur.op = cur.cr = cur.cg = cur.cbl = cur.dep = 0.f;
     cur.pos = 0; cur.have = false;
     uint32_t cur_gid = 0;
     int count = 0;
     uint32_t cur_min = 0;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // software pipeline: the ids + records of window k0 - 64 are requested before window k0 is tested,
     // compacted and (possibly) processed, so the two dependent gathers never sit on the critical path
     // three-stage software pipeline over the windows: while window k0 is tested / compacted / processed, the splat
@@ -566,7 +562,8 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
         for (int k = 0; k < 10; k++) f[k] = 0.f;
         if (have) {
             const SplatRec* rp = a.rec + gid;
-            const float4 q0 = rp->q0, q1 = rp->q1, q2 = rp->q2;
+            const float4 q0 = rp->q0, q1 = rp->q1;
+            const float2 q2 = *reinterpret_cast<const float2*>(&rp->q2);      // blue, depth (the other half is not needed here)
             f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w; f[4] = q1.x; f[5] = q1.y;
             f[6] = q1.z; f[7] = q1.w; f[8] = q2.x; f[9] = q2.y;
         }
@@ -584,13 +581,14 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
         ngid = fgid;
         load_recs(k0 - 64, ngid, nf, nhave);
         fgid = load_ids(k0 - 128);
-        const bool hit = have && (a.no_wave_cull || rect_hit(f[0], f[1], f[2], f[3], f[4], f[5], wx0, wx1, wy0, wy1));
+        const bool hit = have && rect_hit(f[0], f[1], f[2], f[3], f[4], f[5], wx0, wx1, wy0, wy1);
         const unsigned long long hmask = __ballot(hit);
         const int c2 = __popcll(hmask);
         if (c2 == 0) continue;
         // push survivors [first, first + n) of this window (in lane order = back to front) to lanes at .. at + n - 1
         // of the chunk; the other lanes aim at a lane whose result is unused
-        const int rank = __popcll(hmask & lt_mask);
+        // survivors in front of this lane: v_mbcnt counts the mask bits below the lane (no per-lane mask register)
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hmask, 0u));
         auto append = [&](int first, int n, int at) {
             const bool mine = hit && rank >= first && rank < first + n;
             const int dest = mine ? at + rank - first : (at > 0 ? 0 : n & 63);
@@ -613,6 +611,10 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
             if (count == CAP) {
                 process(cur, cur_gid, cur_min, count);
                 count = 0;
+                // the chunk is consumed: an explicit reset ends the live range of its twelve registers at the top of
+                // process() (lanes the next append does not fill would otherwise carry them through the pixel trips)
+                cur.mx = cur.my = cur.ca = cur.cb = cur.cc = cur.op = cur.cr = cur.cg = cur.cbl = cur.dep = 0.f;
+                cur.pos = 0; cur_gid = 0;
             }
             const int n = min(c2 - first, CAP - count);
             append(first, n, count);
@@ -643,39 +645,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
     render_backward_body<CH, NPIX, MF, U, GEO, HALF>(a);
 }
 
-template <int CH, int NPIX, bool MF>
-void launch_one(const BwdArgs& a, hipStream_t s) {
-    const size_t lds = (NPIX == 64 && a.half) ? sizeof(BwdLds<CH, NPIX, MF, true>) : sizeof(BwdLds<CH, NPIX, MF, false>);
-    const dim3 grid(a.gx * a.gy * (256 / NPIX));
-    // later channel windows skip the geometric half of the work (default pixel-block size only: the other sizes are
-    // experiment options and keep the one kernel, which tests write_base at the flush)
-    if constexpr (NPIX == 64) {
-        if (a.half) {        // chunks of 32 instances against two pixel halves (default)
-            if constexpr (CH <= 32) {
-                if (CH > 0 && !a.write_base) hipLaunchKernelGGL((render_backward_kernel_w3<CH, NPIX, MF, 4, (CH == 0), true>), grid, dim3(64), lds, s, a);
-                else hipLaunchKernelGGL((render_backward_kernel_w3<CH, NPIX, MF, 4, true, true>), grid, dim3(64), lds, s, a);
-            } else {
-                if (!a.write_base) hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, false, true>), grid, dim3(64), lds, s, a);
-                else hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, true, true>), grid, dim3(64), lds, s, a);
-            }
-            return;
-        }
-        if (CH > 0 && !a.write_base) {
-            hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, (CH == 0), false>), grid, dim3(64), lds, s, a);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, true, false>), grid, dim3(64), lds, s, a);
-}
-
 template <int CH, bool MF>
-void launch_npix(const BwdArgs& a, int npix, hipStream_t s) {
-    if (npix == 256) launch_one<CH, 256, MF>(a, s);
-    else if (npix == 128) launch_one<CH, 128, MF>(a, s);
-    else if (npix == 32) launch_one<CH, 32, MF>(a, s);
-    else launch_one<CH, 64, MF>(a, s);
+void launch_one(const BwdArgs& a, hipStream_t s) {
+    constexpr int NPIX = 64;
+    const size_t lds = a.half ? sizeof(BwdLds<CH, NPIX, MF, true>) : sizeof(BwdLds<CH, NPIX, MF, false>);
+    const dim3 grid(a.gx * a.gy * (256 / NPIX));
+    // later channel windows skip the geometric half of the work
+    if (a.half) {        // chunks of 32 instances against two pixel halves (default)
+        if constexpr (CH <= 32) {
+            if (CH > 0 && !a.write_base) hipLaunchKernelGGL((render_backward_kernel_w3<CH, NPIX, MF, 4, (CH == 0), true>), grid, dim3(64), lds, s, a);
+            else hipLaunchKernelGGL((render_backward_kernel_w3<CH, NPIX, MF, 4, true, true>), grid, dim3(64), lds, s, a);
+        } else {
+            if (!a.write_base) hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, false, true>), grid, dim3(64), lds, s, a);
+            else hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, true, true>), grid, dim3(64), lds, s, a);
+        }
+        return;
+    }
+    if (CH > 0 && !a.write_base) hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, (CH == 0), false>), grid, dim3(64), lds, s, a);
+    else hipLaunchKernelGGL((render_backward_kernel<CH, NPIX, MF, 4, true, false>), grid, dim3(64), lds, s, a);
 }
-
 
 }  // namespace
 
@@ -710,17 +698,14 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
         }
     } report{dev_cycles, s, (a.dev & 8) != 0};
 #endif
-    const int npix = opt.bwd_npix ? opt.bwd_npix : 64;
-    a.part_major = opt.bwd_part_major;
-    a.no_wave_cull = !opt.bwd_wave_cull;
     // pixel-lane formulation (render_bwd_pl.hip): option bwd_pl = 1 always, 0 never, -1 (default) from 17 channels on - with
     // 16 or fewer one of its four matrix-pipe waves has no columns and the instance-lane kernel is a few per cent faster
-    if ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > 16)) && opt.feature_mfma && !opt.bwd_npix) {
+    if ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > 16)) && opt.feature_mfma) {
         if (opt.bwd_order && tile_len && tile_order) {
             launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, s);
             a.order = tile_order;
         }
-        a.strip = 0; a.half = 0;
+        a.half = 0;
         launch_render_backward_pl(a, C, s);
 #ifdef F3DGS_DEV
         if (a.dev & 8) {
@@ -738,21 +723,20 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
 #endif
         return;
     }
-    a.strip = opt.bwd_strip;
-    a.half = opt.bwd_half && !a.strip;
+    a.half = opt.bwd_half != 0;
     const bool mf = opt.feature_mfma != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
-        launch_npix<0, false>(a, npix, s);
+        launch_one<0, false>(a, s);
         return;
     }
     // channel windows of up to 64; the geometric sums ride along with the first window only
     for (int c0 = 0; c0 < C; c0 += 64) {
         a.c0 = c0; a.nc = min(64, C - c0); a.write_base = (c0 == 0);
-        if (a.nc <= 4) launch_npix<4, false>(a, npix, s);
-        else if (a.nc <= 16) launch_npix<16, false>(a, npix, s);
-        else if (a.nc <= 32) { if (mf) launch_npix<32, true>(a, npix, s); else launch_npix<32, false>(a, npix, s); }
-        else { if (mf) launch_npix<64, true>(a, 64, s); else launch_npix<64, false>(a, npix == 256 ? 128 : npix, s); }
+        if (a.nc <= 4) launch_one<4, false>(a, s);
+        else if (a.nc <= 16) launch_one<16, false>(a, s);
+        else if (a.nc <= 32) { if (mf) launch_one<32, true>(a, s); else launch_one<32, false>(a, s); }
+        else { if (mf) launch_one<64, true>(a, s); else launch_one<64, false>(a, s); }
     }
 }
 

@@ -53,6 +53,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+// A wave-uniform float pinned to a scalar register: float arithmetic is vector-pipe work on this chip, so a uniform value
+// computed in float otherwise occupies a vector register for as long as it lives (and is the first thing spilled).
+// (inline assembly: the compiler folds the builtin away for a value it already knows to be uniform and keeps the vector register)
+__device__ __forceinline__ float uniform_f(float v) {
+    float s;
+    asm("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v));
+    return s;
+}
+
 // Exact-safe footprint test of one splat against a pixel-centre rectangle [x0, x1] x [y0, y1]: the splat can
 // reach alpha >= 1/255 at some pixel of the rectangle only if the minimum of its (convex) quadratic form over
 // the rectangle - 0 if the mean lies inside, otherwise attained on one of the four edges at the clamped 1-D
@@ -92,10 +101,7 @@ struct BwdArgs {
     int W, H, gx, gy;
     int C, c0, nc;
     int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
-    int part_major;  // workgroup -> (tile, part) order, see kernel
-    int strip;        // NPIX = 64: 16x4 pixel strips instead of 8x8 quadrants
-    int half;         // NPIX = 64: chunks of 32 instances, the two halves of the wave take different pixels
-    int no_wave_cull; // option bwd_wave_cull = 0: no wave-level footprint culling / compaction
+    int half;         // instance-lane kernel: chunks of 32 instances, the two halves of the wave take different pixels
     const uint32_t* order;   // pixel-lane kernel: workgroup -> tile, longest walk first (null: XCD-contiguous tile order)
 #ifdef F3DGS_DEV
     int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs, bit3 phase timing

@@ -15,6 +15,8 @@
 //     wave as soon as all of its pixels are saturated;
 //   * channels beyond CH are handled by re-walking the list per 64-channel window.
 
+#include <cstddef>
+
 #include "render_common.h"
 
 namespace f3dgs {
@@ -279,10 +281,14 @@ struct FwdChunkMF {
 // than staging the chunk's feature rows in LDS: 0.62 vs 0.57 ms at config c3.)
 // BASE = false: a later channel window of a wide feature (C > 64): colour, depth, final_T and n_contrib were written by
 // the first window's launch; only the blend weights and the feature contraction are needed again.
+// CH = 16 (windows of 5..16 channels): the 32-column B operand has room to spare, so on the base launch columns 16..19 carry
+// the splat's colour and depth (CDB: read straight out of the staged entry) and their four multiply-adds per (pixel, entry)
+// leave the vector pipe - the pipe this kernel is bound by.
 template <int CH, int PPL, int CHK, int GI, bool BASE>
 __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     constexpr int NW = 4 / PPL;
-    constexpr int NB = CH / 32;
+    constexpr int NB = (CH + 31) / 32;
+    constexpr bool CDB = BASE && CH == 16;
     constexpr int NP = GI / 2;        // instance pairs (MFMA K = 2) per group
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -310,8 +316,8 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     float wx0, wx1, wy0, wy1;
     {
         const int q0 = wave * PPL, q1 = wave * PPL + PPL - 1;
-        wx0 = (float)(tx * TILE + (q0 & 1) * 8); wx1 = (float)(tx * TILE + (q1 & 1) * 8 + 7);
-        wy0 = (float)(ty * TILE + (q0 >> 1) * 8); wy1 = (float)(ty * TILE + (q1 >> 1) * 8 + 7);
+        wx0 = uniform_f((float)(tx * TILE + (q0 & 1) * 8)); wx1 = uniform_f((float)(tx * TILE + (q1 & 1) * 8 + 7));
+        wy0 = uniform_f((float)(ty * TILE + (q0 >> 1) * 8)); wy1 = uniform_f((float)(ty * TILE + (q1 >> 1) * 8 + 7));
     }
     const int lx = lane & 7, ly = lane >> 3;
     float pxf[PPL], pyf[PPL];
@@ -338,6 +344,18 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
             for (int nb = 0; nb < NB; nb++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[p][h][nb][r] = 0.f;
+    }
+
+    // CH = 16: where this lane's B column lives (dwords from the start of the chunk image, per staged entry): channels 0..15
+    // in the feature rows; columns 16..19 = colour and depth inside the 12-dword entry; the remaining columns re-read those
+    // (finite values; their sums are never looked at)
+    int b_stride = 0, b_off = 0;
+    if constexpr (CH == 16) {
+        const int n = lane & 31;
+        using Chunk = FwdChunkMF<CH, CHK>;
+        constexpr int FEAT_OFS = (int)(offsetof(Chunk, feat) / sizeof(float));
+        b_stride = n < 16 ? CH : (int)(sizeof(FwdEntry) / sizeof(float));
+        b_off = n < 16 ? FEAT_OFS + n : (int)(offsetof(FwdEntry, cd) / sizeof(float)) + ((n - 16) & 3);
     }
 
     // software pipeline: the splat records of chunk k+1 and the list ids of chunk k+2 are requested while chunk k
@@ -432,7 +450,7 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                 live_e[e] = j + e < cnt;
                 const int je = live_e[e] ? j + e : j;
                 g0[e] = ck.ent[je].geo;
-                cdv[e] = ck.ent[je].cd;
+                if constexpr (BASE && !CDB) cdv[e] = ck.ent[je].cd;
                 const float4 tail = *reinterpret_cast<const float4*>(&ck.ent[je].co_c);
                 g1[e] = make_float2(tail.x, tail.y);
                 pos_e[e] = __float_as_uint(tail.z);
@@ -443,8 +461,12 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                 // re-reads row j so that stale LDS contents can never inject a NaN)
                 const int e0 = 2 * k;
                 const int rsel = (lane >> 5) ? (live_e[e0 + 1] ? j + e0 + 1 : j) : (live_e[e0] ? j + e0 : j);
+                if constexpr (CH == 16) {
+                    Bv[k][0] = reinterpret_cast<const float*>(&ck)[rsel * b_stride + b_off];
+                } else {
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++) Bv[k][nb] = ck.feat[rsel * CH + (lane & 31) + 32 * nb];
+                    for (int nb = 0; nb < NB; nb++) Bv[k][nb] = ck.feat[rsel * CH + (lane & 31) + 32 * nb];
+                }
             }
             // a quadrant whose 64 pixels are all saturated is skipped as a whole (wave-uniform branch)
             bool slot_live[PPL];
@@ -479,10 +501,12 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                     T[p] = ok ? test_T : (term ? -fabsf(T[p]) : T[p]);
                     if constexpr (BASE) {
                         last[p] = ok ? pos_e[e] : last[p];
-                        col[p][0] = fmaf(cdv[e].x, wv, col[p][0]);
-                        col[p][1] = fmaf(cdv[e].y, wv, col[p][1]);
-                        col[p][2] = fmaf(cdv[e].z, wv, col[p][2]);
-                        dep[p] = fmaf(cdv[e].w, wv, dep[p]);
+                        if constexpr (!CDB) {
+                            col[p][0] = fmaf(cdv[e].x, wv, col[p][0]);
+                            col[p][1] = fmaf(cdv[e].y, wv, col[p][1]);
+                            col[p][2] = fmaf(cdv[e].z, wv, col[p][2]);
+                            dep[p] = fmaf(cdv[e].w, wv, dep[p]);
+                        }
                     }
                     any_blend = any_blend || ok;
                 }
@@ -517,7 +541,7 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     }
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
-        if (BASE && a.write_base && inside[p]) {
+        if (BASE && !CDB && a.write_base && inside[p]) {
             const size_t pid = (size_t)pix_id[p];
             const float Tf = fabsf(T[p]);
             a.final_T[pid] = Tf;
@@ -542,82 +566,74 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
             __builtin_amdgcn_wave_barrier();
             if (inside[p]) {
 #pragma unroll 8
-                for (int n = 0; n < 32; n++)
+                for (int n = 0; n < (CH < 32 ? CH : 32); n++)
                     if (32 * nb + n < a.nc)
                         a.out_feat[(size_t)(a.c0 + 32 * nb + n) * HW + (size_t)pix_id[p]] = ck.feat[n * 65 + lane];
+                if constexpr (CDB) {
+                    if (a.write_base) {      // columns 16..19 of the contraction: red, green, blue, depth
+                        const size_t pid = (size_t)pix_id[p];
+                        const float Tf = fabsf(T[p]);
+                        a.final_T[pid] = Tf;
+                        a.n_contrib[pid] = last[p];
+                        a.out_color[pid] = ck.feat[16 * 65 + lane] + Tf * a.bg[0];
+                        a.out_color[HW + pid] = ck.feat[17 * 65 + lane] + Tf * a.bg[1];
+                        a.out_color[2 * HW + pid] = ck.feat[18 * 65 + lane] + Tf * a.bg[2];
+                        a.out_depth[pid] = ck.feat[19 * 65 + lane];
+                    }
+                }
             }
         }
     }
 }
 
-// Two entry points over one body: the C = 32 shape sits 12 registers above the three-waves-per-SIMD budget and is
-// faster squeezed into it (a few spills outside the blend loop: 0.443 vs 0.506 ms at c3); the C = 64 shape is
-// faster left alone at two waves (2.75 vs 2.98 ms at c4).
-template <int CH, int PPL, int CHK, int GI, bool BASE>
-__global__ void __launch_bounds__(256 / PPL) render_forward_mfma_kernel(FwdArgs a) {
-    render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
+// Entry points by occupancy target over one body.  32 channels, one quadrant per wave, 32-instance chunks: 135 registers and
+// 5.7 KB of LDS per wave - squeezed into the four-waves-per-SIMD budget (128) it is the fastest shape at c3 (0.39 ms; 0.45
+// at three waves, 0.42-0.43 for two quadrants per wave with 64-instance chunks at three waves: 168 registers, 11.4 KB).
+// 64 channels, same shape: 150 registers and 9.7 KB, three waves per SIMD (c4: 2.58 -> 2.23 ms with 64-instance chunks at
+// two).  128 channels: 128 accumulator registers per quadrant, two waves per SIMD.
+template <int CH, bool BASE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_forward_mfma_kernel_w4(FwdArgs a) {
+    render_forward_mfma_body<CH, 1, 32, 2, BASE>(a);
 }
-template <int CH, int PPL, int CHK, int GI, bool BASE>
-__global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(3, 4))) render_forward_mfma_kernel_w3(FwdArgs a) {
-    render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
+template <int CH, bool BASE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) render_forward_mfma_kernel_w3(FwdArgs a) {
+    render_forward_mfma_body<CH, 1, 32, 2, BASE>(a);
+}
+template <int CH, bool BASE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) render_forward_mfma_kernel_w2(FwdArgs a) {
+    render_forward_mfma_body<CH, 1, 32, 2, BASE>(a);
 }
 
-template <int CH, int PPL, int CHK, int GI, bool BASE>
-__global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(2, 4))) render_forward_mfma_kernel_w2(FwdArgs a) {
-    render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
+// The 128-channel shape needs 70 KB of LDS per four-wave workgroup (above the 64 KB default limit): the limit is raised once
+// per device; where that is refused the caller falls back to 64-channel windows.
+template <bool BASE>
+bool wide_shape_usable() {
+    constexpr int MAX_DEV = 64;
+    static int state[MAX_DEV];      // 0: not asked yet, 1: usable, -1: refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_forward_mfma_kernel_w2<128, BASE>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(FwdChunkMF<128, 32>)));
+        if (e != hipSuccess) (void)hipGetLastError();     // not sticky: the narrower windows take over
+        state[dev] = e == hipSuccess ? 1 : -1;
+    }
+    return state[dev] > 0;
 }
 
-template <int CH, int PPL, int CHK, int GI, bool BASE>
-__global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(4, 4))) render_forward_mfma_kernel_w4(FwdArgs a) {
-    render_forward_mfma_body<CH, PPL, CHK, GI, BASE>(a);
-}
-// Entry point by shape.  32 channels, one quadrant per wave, 32-instance chunks: 135 registers and 5.7 KB of LDS per wave -
-// squeezed into the four-waves-per-SIMD budget (128) it is the fastest shape at c3 (0.39 ms; 0.45 at three waves, 0.42-0.43
-// for two quadrants per wave with 64-instance chunks at three waves: 168 registers, 11.4 KB).  64 channels, same shape:
-// 150 registers and 9.7 KB, three waves per SIMD instead of two with 64-instance chunks (c4: 2.58 -> 2.23 ms).
-template <int CH, int PPL, int CHK, int GI, bool BASE>
+template <int CH, bool BASE>
 void launch_shape(const FwdArgs& a, hipStream_t s) {
-    constexpr int NW = 4 / PPL;
-    const bool solo = PPL == 1 && a.solo;
-    const size_t lds = (solo ? 1 : NW) * sizeof(FwdChunkMF<CH, CHK>);
-    const dim3 grid(solo ? 4 * a.gx * a.gy : a.gx * a.gy), block(solo ? 64 : 256 / PPL);
-    if constexpr (CH <= 32 && PPL == 1 && CHK == 32) {
-        if (options().fwd_w4) {
-            hipLaunchKernelGGL((render_forward_mfma_kernel_w4<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
-            return;
-        }
-    }
-    if constexpr (CH >= 128) {
-        // 128 accumulator registers per quadrant: two waves per SIMD, 70 KB of LDS per workgroup (above the 64 KB default limit)
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_forward_mfma_kernel_w2<CH, PPL, CHK, GI, BASE>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NW * sizeof(FwdChunkMF<CH, CHK>)));
-        (void)once;
-        hipLaunchKernelGGL((render_forward_mfma_kernel_w2<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
-        return;
-    }
-    if (CH <= 32 || (PPL == 1 && CHK == 32)) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((render_forward_mfma_kernel<CH, PPL, CHK, GI, BASE>), grid, block, lds, s, a);
+    const bool solo = a.solo != 0;
+    const size_t lds = (solo ? 1 : 4) * sizeof(FwdChunkMF<CH, 32>);
+    const dim3 grid(solo ? 4 * a.gx * a.gy : a.gx * a.gy), block(solo ? 64 : 256);
+    if constexpr (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w4<CH, BASE>), grid, block, lds, s, a);
+    else if constexpr (CH <= 64) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, BASE>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((render_forward_mfma_kernel_w2<CH, BASE>), grid, block, lds, s, a);
 }
-template <int CH, int PPL, int CHK, int GI>
-void launch_one_mf2(const FwdArgs& a, hipStream_t s) {
-    // the two default shapes also exist without the colour / depth half (later channel windows of wide features)
-    if constexpr ((CHK == 64 && GI == 4) || (CHK == 32 && GI == 2 && PPL == 1)) {
-        if (!a.write_base) {
-            launch_shape<CH, PPL, CHK, GI, false>(a, s);
-            return;
-        }
-    }
-    launch_shape<CH, PPL, CHK, GI, true>(a, s);
-}
-template <int CH, int PPL>
+template <int CH>
 void launch_one_mf(const FwdArgs& a, hipStream_t s) {
-    const int v = options().fwd_variant;   // tuning knob: chunk size / group size
-    if (v == 1) launch_one_mf2<CH, PPL, 32, 4>(a, s);
-    else if (v == 2) launch_one_mf2<CH, PPL, 32, 2>(a, s);
-    else if (v == 3) launch_one_mf2<CH, PPL, 64, 2>(a, s);
-    else if (v == 4) launch_one_mf2<CH, PPL, 64, 4>(a, s);
-    else if (PPL == 1) launch_one_mf2<CH, PPL, 32, 2>(a, s);   // default for one quadrant per wave, see launch_shape
-    else launch_one_mf2<CH, PPL, 64, 4>(a, s);   // 64-instance chunks, 4-instance groups (best for two quadrants per wave)
+    // later channel windows of wide features run without the colour / depth half
+    if (a.write_base) launch_shape<CH, true>(a, s); else launch_shape<CH, false>(a, s);
 }
 
 template <int CH, int PPL>
@@ -627,7 +643,6 @@ void launch_one(const FwdArgs& a, hipStream_t s) {
     const size_t lds = (solo ? 1 : NW) * sizeof(FwdChunk<CH>);
     hipLaunchKernelGGL((render_forward_kernel<CH, PPL>), dim3(solo ? 4 * a.gx * a.gy : a.gx * a.gy), dim3(solo ? 64 : 256 / PPL), lds, s, a);
 }
-
 
 }  // namespace
 
@@ -648,36 +663,26 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
 #else
     a.dev = 0;
 #endif
-    const int ppl = options().fwd_ppl;
     const bool mf = options().feature_mfma != 0;
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
-        if (ppl == 1) launch_one<0, 1>(a, s);
-        else if (ppl == 2) launch_one<0, 2>(a, s);
-        else launch_one<0, 4>(a, s);
+        launch_one<0, 4>(a, s);
         return;
     }
     // channel window: 64 channels, or 128 on the matrix pipe when more than 64 remain (every window re-evaluates the
     // blend weights of the whole list: fewer, wider windows - two waves per SIMD, the matrix pipe hides the rest)
-    const int wide = (mf && options().fwd_wide != 0) ? 128 : 64;
+    const bool wide_ok = mf && options().fwd_wide != 0 && C > 64 && wide_shape_usable<true>() && wide_shape_usable<false>();
+    const int wide = wide_ok ? 128 : 64;
     for (int c0 = 0; c0 < C;) {
         const int win = (C - c0 > 64) ? wide : 64;
         a.c0 = c0; a.nc = min(win, C - c0); a.write_base = (c0 == 0);
         c0 += win;
-        if (a.nc <= 4) {
-            // small feature dims: one quadrant per wave measured fastest (c2, C = 16: 0.44 ms vs 0.47 / 0.60 for 2 / 4)
-            if (ppl == 4) launch_one<4, 4>(a, s); else if (ppl == 2) launch_one<4, 2>(a, s); else launch_one<4, 1>(a, s);
-        } else if (a.nc <= 16) {
-            if (ppl == 4) launch_one<16, 4>(a, s); else if (ppl == 2) launch_one<16, 2>(a, s); else launch_one<16, 1>(a, s);
-        } else if (a.nc <= 32) {
-            if (mf) { if (ppl == 2) launch_one_mf<32, 2>(a, s); else launch_one_mf<32, 1>(a, s); }     // automatic: one quadrant per wave
-            else if (ppl == 1) launch_one<32, 1>(a, s); else if (ppl == 4) launch_one<32, 4>(a, s); else launch_one<32, 2>(a, s);
-        } else if (a.nc <= 64) {
-            if (mf) { if (ppl == 2) launch_one_mf<64, 2>(a, s); else launch_one_mf<64, 1>(a, s); }
-            else if (ppl == 2) launch_one<64, 2>(a, s); else launch_one<64, 1>(a, s);
-        } else {
-            if (a.write_base) launch_shape<128, 1, 32, 2, true>(a, s); else launch_shape<128, 1, 32, 2, false>(a, s);
-        }
+        // up to four channels: vector pipe; 5..16: the 32-column matrix shape with colour and depth in its spare columns
+        if (a.nc <= 4) launch_one<4, 1>(a, s);
+        else if (a.nc <= 16) { if (mf) launch_one_mf<16>(a, s); else launch_one<16, 1>(a, s); }
+        else if (a.nc <= 32) { if (mf) launch_one_mf<32>(a, s); else launch_one<32, 2>(a, s); }
+        else if (a.nc <= 64) { if (mf) launch_one_mf<64>(a, s); else launch_one<64, 1>(a, s); }
+        else launch_one_mf<128>(a, s);
     }
 }
 

@@ -54,31 +54,38 @@ extern "C" {
  * resizeFunctional() of rasterize_points.cu:27-33. */
 typedef char* (*f3dgs_resize_fn)(void* ctx, size_t nbytes);
 
-/* Library / ABI version: major*10000 + minor*100 + patch (3.0.0 -> 30000). */
+/* Library / ABI version: major*10000 + minor*100 + patch (3.1.0 -> 30100). */
 int f3dgs_version(void);
 
 /* Thread-local message of the last error raised on this host thread. */
 const char* f3dgs_last_error(void);
 
 /*
- * Process-wide options (no counterpart in the reference).  Each option selects between complete, tested code
- * paths; none removes work.  Defaults are seeded ONCE, at first use of the library, from the environment
- * variable F3DGS_<NAME IN CAPITALS>; afterwards only these calls change them (no launch path reads the
- * environment).
+ * Process-wide options (no counterpart in the reference).  Each option selects between complete code paths that
+ * are exercised by the test suite (tests/test_abi_and_surface.py fails on an option without a test); none removes
+ * work.  Defaults are seeded ONCE, at first use of the library, from the environment variable
+ * F3DGS_<NAME IN CAPITALS>; afterwards only these calls change them (no launch path reads the environment).
  *   "tile_cull"      1 (default): instances whose 1/255-alpha ellipse misses a tile are never emitted (they
  *                    could not blend at any of its pixels, so outputs are unchanged); 0: the reference's
  *                    bounding-rectangle lists, bit-identical private state (used by the parity tests)
- *   "feature_mfma"   1 (default): feature contraction of the blend kernels on the matrix pipe (exact fp32)
+ *   "feature_mfma"   1 (default): feature contraction of the blend kernels on the matrix pipe (exact fp32);
+ *                    0: vector pipe only
  *   "profile"        1: per-stage HIP events, see f3dgs_profile_read; 2: only around the two blend kernels
  *   "sort_onesweep"  0 (default): three-kernel radix passes; 1: single-pass radix scatter with decoupled look-back
  *                    (measured slower on MI355X, kept as a tested alternative)
- *   "bwd_npix", "bwd_part_major", "bwd_strip", "bwd_half", "bwd_wave_cull", "bwd_pl", "fwd_ppl", "fwd_variant", "fwd_w4",
- *   "fwd_wide", "fwd_solo", "bwd_order":
- *                    kernel-shape and scheduling knobs (0 = automatic where applicable)
+ *   "bwd_pl"         blend backward formulation: 1 pixel-lane kernel (all sums on the matrix pipe), 0 instance-lane
+ *                    kernel, -1 (default) by channel count
+ *   "bwd_half"       instance-lane blend backward: 1 (default) chunks of 32 instances against two pixel halves,
+ *                    0 chunks of 64
+ *   "bwd_order"      pixel-lane blend backward: 1 (default) workgroups take the tiles longest walk first
+ *   "fwd_wide"       blend forward: 1 (default) 128-channel windows where more than 64 channels remain
+ *   "fwd_solo"       blend forward: 1 (default) one 64-thread workgroup per quadrant wave
  * Unknown names return F3DGS_ERR_INVALID_ARGUMENT.
  */
 int f3dgs_set_option(const char* name, int value);
 int f3dgs_get_option(const char* name, int* value /* host pointer, out */);
+/* Enumeration: the name of option `index` (0, 1, ...), NULL past the end. */
+const char* f3dgs_option_name(int index);
 
 /*
  * Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:24-29,

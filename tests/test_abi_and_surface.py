@@ -35,6 +35,41 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.f3dgs_backward_scratch_bytes(1000, 32) >= 1000 * 40
 
 
+def test_every_option_is_exercised_by_a_test():
+    """include/f3dgs.h: "each option selects between complete code paths that are exercised by the test suite" - every name
+    the library enumerates must be set by some test (option("name", ...) / set_option("name", ...)), apart from `profile`
+    (no code path of its own: it only records events; bench.py drives it) which must at least be read back here."""
+    import glob
+    so = _ensure_built()
+    lib = ctypes.CDLL(so)
+    lib.f3dgs_option_name.restype = ctypes.c_char_p
+    names, i = [], 0
+    while (n := lib.f3dgs_option_name(i)) is not None:
+        names.append(n.decode())
+        i += 1
+    assert "tile_cull" in names and len(names) == len(set(names))
+    assert "dev" not in names, "development hooks in a release build"
+    v = ctypes.c_int(-7)
+    for n in names:
+        assert lib.f3dgs_get_option(n.encode(), ctypes.byref(v)) == 0
+    assert lib.f3dgs_get_option(b"no_such_option", ctypes.byref(v)) < 0
+    text = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "tests", "test_*.py")))
+    for n in names:
+        if n == "profile":
+            continue
+        assert re.search(r'(option|set_option)\(\s*"%s"' % n, text) or re.search(r'parametrize\("name", \[[^\]]*"%s"' % n, text), \
+            f"option {n} is not set by any test"
+
+
+def test_no_default_kernel_spills():
+    """Every kernel of the shipped library: no spilled vector registers, no scratch (tools/kernel_resources.py reads the
+    code-object metadata; needs the object files of an in-tree build)."""
+    import subprocess, sys
+    _ensure_built()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_argument_validation_without_gpu():
     """Errors that must be raised before any device work (so they are testable on CPU)."""
     so = _ensure_built()

@@ -1,7 +1,7 @@
 """Per-stage timing of one config on the GPU under a list of environment settings (development aid;
 bench.py is the contract).
 
-    python tools/quick_bench.py c3 10 "" "fwd_ppl=1" "fwd_ppl=1 fwd_variant=2"
+    python tools/quick_bench.py c3 10 "" "bwd_pl=0" "fwd_solo=0 bwd_order=0"
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
