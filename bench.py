@@ -224,6 +224,57 @@ def make_step(scene, dev, pool=4, dist=None, overlap=True):
     return step, leaves
 
 
+def make_step_views(scene, yaws, dev, pool=4, dist=None, overlap=True, pipelined=True):
+    """Several views of the same Gaussians per rank and step (`--views-per-iter`): returns (step(i), leaves).  One step =
+    forward+backward of every view in `yaws` (camera rotated about y by that many degrees) + the gradient exchange, through
+    dp.dp_step_views: views alternate between two streams (view v + 1's preprocess / binning under view v's blend kernels),
+    the feature gradient is accumulated in place across the views and - data parallel - reduced from inside the last view's
+    backward pass.  pipelined=False: the same views strictly one after the other on one stream, one gradient tensor per view
+    (what dp.dp_step did with several views until round 3) - the comparison leg."""
+    import torch
+
+    import diff_gaussian_rasterization as dgr
+    import dp
+    from synth import make_camera
+    P, C = scene["P"], scene["C"]
+    W, H = scene["image_width"], scene["image_height"]
+    t = lambda x: x.to(dev)
+    bg = t(scene["bg"])
+    rasterizers = []
+    for yaw in yaws:
+        cam = make_camera(W, H, yaw_deg=yaw)
+        rasterizers.append(dgr.GaussianRasterizer(dgr.GaussianRasterizationSettings(
+            H, W, cam["tanfovx"], cam["tanfovy"], bg, 1.0, t(cam["viewmatrix"]), t(cam["projmatrix"]), scene["sh_degree"],
+            t(cam["campos"]), False, False)))
+    leaves = dict(means3D=t(scene["means3D"]).requires_grad_(), means2D=torch.zeros(P, 3, device=dev, requires_grad=True),
+                  opacities=t(scene["opacities"]).requires_grad_(), shs=t(scene["shs"]).requires_grad_(),
+                  semantic_feature=t(scene["semantic_feature"]).requires_grad_(),
+                  scales=t(scene["scales"]).requires_grad_(), rotations=t(scene["rotations"]).requires_grad_())
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    hw = float(W * H)
+    ups = []
+    for _ in range(pool):
+        dd = scene["dL_ddepth"] if float(scene["dL_ddepth"].abs().max()) == 0.0 else torch.randn(1, H, W, generator=g) / hw
+        ups.append([t(torch.randn(3, H, W, generator=g) / hw), t(torch.randn(C, H, W, generator=g) / hw), t(dd)])
+    reduce_keys = ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")
+    sub = {k: leaves[k] for k in reduce_keys}
+    state = {"i": 0}
+
+    def forward(j):
+        color, feat, _radii, depth = rasterizers[j](**leaves)
+        return (color, feat, depth, j)
+
+    def backward(h):
+        torch.autograd.backward([h[0], h[1], h[2]], ups[(state["i"] + h[3]) % pool])
+
+    def step(i):
+        state["i"] = i
+        leaves["means2D"].grad = None
+        dp.dp_step_views(forward, backward, sub, range(len(yaws)), overlap=overlap and pipelined, n_streams=2 if pipelined else 1,
+                         accumulate=None if pipelined else False)
+    return step, leaves
+
+
 def config_label(P, W, H, C):
     """'1M Gaussians @1080p, feat_dim=32' for the headline config, the same wording for the others."""
     ps = f"{P // 1000000}M" if P % 1000000 == 0 else (f"{P // 1000}k" if P % 1000 == 0 else str(P))
@@ -381,6 +432,9 @@ def main():
     ap.add_argument("--comm-only", action="store_true", help="time only the gradient exchange of the config (N > 1)")
     ap.add_argument("--no-overlap", action="store_true", help="exchange all gradients after the backward pass")
     ap.add_argument("--feat-dim", type=int, default=None, help="override the config's feature dim (development)")
+    ap.add_argument("--views-per-iter", type=int, default=0,
+                    help="V views of the same Gaussians per step over all GPUs (V / N per rank, pipelined over two streams, "
+                         "gradients accumulated across the views): total work is fixed as N grows - the line says scaling: strong")
     ap.add_argument("--valu", action="store_true",
                     help="library option feature_mfma = 0: every blend kernel on the vector pipe only (the north-star-literal configuration)")
     ap.add_argument("--densify-every", type=int, default=0,
@@ -427,10 +481,18 @@ def main():
     cfg_kw = dict(CONFIGS[args.config])
     if args.feat_dim is not None:
         cfg_kw["C"] = args.feat_dim
-    scene = make_scene(seed=0, yaw_deg=5.0 * rank, **cfg_kw)
+    V = args.views_per_iter
+    if V and (V % world != 0):
+        raise SystemExit(f"--views-per-iter {V} is not a multiple of --gpus {world}")
+    per_rank = V // world if V else 1
+    scene = make_scene(seed=0, yaw_deg=5.0 * rank * per_rank, **cfg_kw)
     P, C = scene["P"], scene["C"]
     W, H = scene["image_width"], scene["image_height"]
-    step, leaves = make_step(scene, dev, dist=dist, overlap=not args.no_overlap)
+    if V:
+        yaws = [5.0 * (rank * per_rank + j) for j in range(per_rank)]
+        step, leaves = make_step_views(scene, yaws, dev, dist=dist, overlap=not args.no_overlap)
+    else:
+        step, leaves = make_step(scene, dev, dist=dist, overlap=not args.no_overlap)
 
     def timed(n_steps, per_step_events):       # (`step` is looked up at call time)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)] if per_step_events else None
@@ -506,8 +568,29 @@ def main():
     prof = {name: (ms, calls) for name, ms, calls in _C.profile_read()}
     _C.set_option("profile", 0)
 
+    views_breakdown = None
+    if V:
+        # the same K steps with the views strictly one after the other (one stream, one gradient tensor per view), and one view
+        # alone: what the pipelining and the in-place accumulation buy
+        _step = step
+        step, _lv = make_step_views(scene, yaws, dev, dist=dist, overlap=False, pipelined=False)
+        for i in range(3):
+            step(i)
+        el_seq, _ = timed(args.steps, per_step_events=False)
+        del _lv
+        step, _lv = make_step_views(scene, yaws[:1], dev, dist=None, overlap=False, pipelined=False)
+        for i in range(3):
+            step(i)
+        el_one, _ = timed(args.steps, per_step_events=False)
+        del _lv
+        step = _step
+        views_breakdown = {"views_per_rank": per_rank, "pipelined_ms_per_step": 1e3 * elapsed / args.steps,
+                           "sequential_ms_per_step": 1e3 * el_seq / args.steps, "one_view_ms": 1e3 * el_one / args.steps,
+                           "pipelined_over_views_x_one_view": (elapsed / args.steps) / (per_rank * el_one / args.steps),
+                           "note": "sequential = the same views one after the other on one stream with a gradient tensor per view; "
+                                   "one_view = a single view of this rank without any exchange"}
     dp_breakdown = None
-    if dist is not None:
+    if dist is not None and not V:
         # the same K steps without the exchange, and the exchange alone on the gradients they left: what the scaling is made of
         import dp
         step_local, leaves_local = make_step(scene, dev, dist=None)
@@ -537,7 +620,7 @@ def main():
                                 "ms_per_step below their sum = overlap achieved"}
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        mpix = world * W * H / 1e6 / (elapsed / args.steps)
+        mpix = (V if V else world) * W * H / 1e6 / (elapsed / args.steps)
         stage_ms = {k: v[0] / max(1, v[1]) for k, v in prof.items()}
         alg = algorithmic_bytes(P, stats["Pv"], stats["N"], stats["N_r"], W * H, stats["tiles"], C)
         kernel_stage = {"preprocess": "preprocess", "render_fwd": "render_fwd", "render_bwd": "render_bwd",
@@ -590,11 +673,13 @@ def main():
         out = {
             "metric": f"rendered Mpix/s of rasterizer fwd+bwd (train-step ms in ms_per_step), {config_label(P, W, H, C)}",
             "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if V else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "blend_kernels": "vector pipe only (option feature_mfma = 0)" if args.valu else "feature / gradient contractions on the matrix pipe (exact fp32)",
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {scene['sh_degree']}, feat_dim={C}, "
-                                   f"one view per GPU (SURVEY.md 8d recipe, seed 0), fresh upstream gradients per step",
+                                   + (f"{V} views per step ({per_rank} per GPU, rotated 5 degrees apart, pipelined over two streams, "
+                                      f"gradients accumulated across the views)" if V else "one view per GPU")
+                                   + " (SURVEY.md 8d recipe, seed 0), fresh upstream gradients per step",
                        "P": P, "Pv": stats["Pv"], "N": stats["N"], "N_r": stats["N_r"],
                        "parallelism": "single GPU" if world == 1 else
                        f"view-sharded dp{world} + RCCL all-reduce of (59+C) floats per Gaussian"
@@ -614,6 +699,7 @@ def main():
                                     "achieved": alg["total"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                                     "frac": alg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "dp_breakdown": dp_breakdown,
+            "views_breakdown": views_breakdown,
             "stage_ms": stage_ms,
             "stage_ms_source": "auxiliary run of the same K steps with an event at every stage boundary (not the timed region)",
         }

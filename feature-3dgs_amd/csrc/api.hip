@@ -26,6 +26,7 @@ thread_local void* g_feature_ready_ctx = nullptr;
 thread_local f3dgs_rows_fn g_rows_ready_fn = nullptr;
 thread_local void* g_rows_ready_ctx = nullptr;
 thread_local int g_rows_ready_chunks = 1;
+thread_local int g_feature_accumulate = 0;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -221,29 +222,43 @@ Options& options() {
 }  // namespace f3dgs
 
 namespace {
-// Pinned landing zone + event for the instance-count read-back; one per host thread (the ABI is re-entrant
-// across threads), created on first use and kept for the life of the thread.  The event is re-created when
-// the thread's current device changes.
+// Pinned landing zone + event for the instance-count read-back: one per (host thread, device, stream), created on first use
+// and kept for the life of the thread - forward calls in flight on two streams of one thread (a multi-view step that overlaps
+// the binning of view v + 1 with the blend kernels of view v, dp.py) never share a slot.  The words are allocated portable and
+// mapped, and the kernel that stores the totals receives the DEVICE-side address of the mapping for the device it runs on.
 struct CountReadback {
-    uint32_t* host = nullptr;
+    uint32_t* host = nullptr;       // host address (read by this thread)
+    uint32_t* dev = nullptr;        // the same words as the current device sees them (written by a kernel)
     hipEvent_t done = nullptr;
     int device = -1;
+    hipStream_t stream = nullptr;
 };
-CountReadback& count_readback() {
-    thread_local CountReadback rb;
+CountReadback* count_readback(hipStream_t s) {
+    thread_local std::vector<CountReadback> slots;
     int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!rb.host) {
-        void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocDefault) == hipSuccess) rb.host = static_cast<uint32_t*>(p);
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (CountReadback& rb : slots)
+        if (rb.device == dev && rb.stream == s) return &rb;
+    CountReadback rb;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    rb.host = static_cast<uint32_t*>(p);
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || hipEventCreateWithFlags(&rb.done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(p);
+        return nullptr;
     }
-    if (rb.host && rb.device != dev) {
-        if (rb.done) (void)hipEventDestroy(rb.done);
-        rb.done = nullptr;
-        if (hipEventCreateWithFlags(&rb.done, hipEventDisableTiming) == hipSuccess) rb.device = dev;
-        else { rb.device = -1; }
+    rb.dev = static_cast<uint32_t*>(d);
+    rb.device = dev;
+    rb.stream = s;
+    if (slots.size() >= 64) {       // a caller that churns through streams: recycle the oldest slot
+        (void)hipEventDestroy(slots.front().done);
+        (void)hipHostFree(slots.front().host);
+        slots.erase(slots.begin());
     }
-    return rb;
+    slots.push_back(rb);
+    return &slots.back();
 }
 }  // namespace
 
@@ -282,6 +297,8 @@ void f3dgs_set_feature_grad_ready_callback(f3dgs_stage_fn fn, void* ctx) {
     g_feature_ready_fn = fn;
     g_feature_ready_ctx = ctx;
 }
+
+void f3dgs_set_feature_grad_accumulate(int on) { g_feature_accumulate = on ? 1 : 0; }
 
 void f3dgs_set_grad_rows_ready_callback(f3dgs_rows_fn fn, void* ctx, int chunks) {
     g_rows_ready_fn = fn;
@@ -361,8 +378,9 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // Both instance totals are final here.  Their read-back (the counterpart of rasterizer_impl.cu:283) is
     // requested now and awaited only after the depth sort has been enqueued, so the host round
     // trip hides behind ~0.1 ms of GPU work instead of idling the device.
-    CountReadback& rb = count_readback();
-    if (!rb.host || !rb.done) return fail(F3DGS_ERR_ALLOC, "pinned read-back buffer / event creation failed");
+    CountReadback* rbp = count_readback(s);
+    if (!rbp) return fail(F3DGS_ERR_ALLOC, "pinned read-back buffer / event creation failed");
+    CountReadback& rb = *rbp;
     if (onesweep) {
         HIP_TRY(hipMemcpyAsync(rb.host, geom.counters, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(rb.done, s));
@@ -371,7 +389,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // depth sort of the Gaussians (ids start in index order -> ties keep ascending id).  Three-kernel flavour: its
     // first kernel adds up the totals and stores them into the pinned host words itself (no totals / copy launches);
     // rb.done is recorded right behind that kernel.
-    const TotalsJob tj = {geom.ref_partial, (P + 255) / 256, geom.counters, rb.host, rb.done};
+    const TotalsJob tj = {geom.ref_partial, (P + 255) / 256, geom.counters, rb.dev, rb.done};
     if (onesweep) launch_depth_sort_onesweep(geom, (size_t)P, s);
     else HIP_TRY(launch_depth_sort(geom.depth_key, geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, geom.hist, &tj, s));
     if ((rc = check_debug(debug, s, "depth sort"))) return rc;
@@ -476,7 +494,8 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
 
     StageTimer tm(s);
     HIP_TRY(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
-    if (C > 0) HIP_TRY(hipMemsetAsync(dL_dsemantic_feature, 0, (size_t)P * C * sizeof(float), s));
+    // (f3dgs_set_feature_grad_accumulate: the caller's buffer already holds the sum over its earlier views)
+    if (C > 0 && !g_feature_accumulate) HIP_TRY(hipMemsetAsync(dL_dsemantic_feature, 0, (size_t)P * C * sizeof(float), s));
     tm.mark("zero");
     if (R > 0)
         launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,

@@ -91,6 +91,20 @@ struct FeatureCallbackGuard {
     }
 };
 
+// Accumulation buffer for the feature gradient across the views of one optimiser step (include/f3dgs.h:
+// f3dgs_set_feature_grad_accumulate): while it is set, the backward binding hands IT to the library as
+// dL_dsemantic_feature (accumulate mode) and returns an empty tensor in its place - the Python side then reports "no
+// gradient" for the input to autograd, the sum lives in the buffer (normally the leaf's .grad).
+torch::Tensor& feature_grad_accumulator() {
+    static torch::Tensor* t = new torch::Tensor();
+    return *t;
+}
+struct AccumulateGuard {
+    bool armed;
+    explicit AccumulateGuard(bool on) : armed(on) { if (armed) f3dgs_set_feature_grad_accumulate(1); }
+    ~AccumulateGuard() { if (armed) f3dgs_set_feature_grad_accumulate(0); }
+};
+
 // Python callable invoked as fn(row_begin, row_end, {"sh": dL_dsh, "means3D": ..., ...}) after every row chunk of the
 // per-Gaussian stage has been enqueued (include/f3dgs.h: f3dgs_set_grad_rows_ready_callback), and its chunk count.
 py::object& grad_rows_hook() {
@@ -203,7 +217,14 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     torch::Tensor dL_dmeans3D = torch::empty({P, 3}, o);
     torch::Tensor dL_dmeans2D = torch::empty({P, 3}, o);
     torch::Tensor dL_dcolors = torch::empty({P, 3}, o);
-    torch::Tensor dL_dsemantic_feature = torch::empty({P, F1, C}, o);
+    torch::Tensor& acc = feature_grad_accumulator();
+    const bool accumulate = acc.defined() && P > 0 && C > 0;
+    if (accumulate) {
+        TORCH_CHECK(acc.is_cuda() && acc.device() == means3D.device() && acc.scalar_type() == torch::kFloat32 && acc.is_contiguous() &&
+                    acc.numel() == (int64_t)P * C,
+                    "feature gradient accumulator must be a contiguous float32 tensor of ", P, " x ", C, " elements on the op's device");
+    }
+    torch::Tensor dL_dsemantic_feature = accumulate ? acc.view({P, F1, C}) : torch::empty({P, F1, C}, o);
     torch::Tensor dL_dopacity = torch::empty({P, 1}, o);
     torch::Tensor dL_dcov3D = torch::empty({P, 6}, o);
     torch::Tensor dL_dsh = torch::empty({P, M, 3}, o);
@@ -228,6 +249,7 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     pending_hook_error() = nullptr;
     int rc;
     {
+    AccumulateGuard guard_acc(accumulate);
     FeatureCallbackGuard guard_cb(notify, &dL_dsemantic_feature);
     RowsCallbackCtx rows_ctx = {&dL_dsh, &dL_dmeans3D, &dL_dscales, &dL_drotations, &dL_dopacity, &dL_dcolors, &dL_dmeans2D, &dL_dcov3D};
     RowsCallbackGuard guard_rows(!grad_rows_hook().is_none() && P > 0, &rows_ctx, grad_rows_chunks());
@@ -249,8 +271,9 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
         std::rethrow_exception(e);
     }
     check_status(rc, "rasterize_gaussians_backward");
-    return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dsemantic_feature, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
-                           dL_dscales, dL_drotations);
+    // accumulate mode: the sum lives in the caller's buffer; an empty tensor tells the Python side "no gradient to hand on"
+    return std::make_tuple(dL_dmeans2D, dL_dcolors, accumulate ? torch::empty({0}, o) : dL_dsemantic_feature, dL_dopacity, dL_dmeans3D,
+                           dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
 }
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix) {
@@ -435,6 +458,12 @@ PYBIND11_MODULE(_C, m) {
     m.def("version", []() { return f3dgs_version(); });
     m.def("set_feature_grad_hook", [](py::object fn) { feature_grad_hook() = std::move(fn); },
           "callable(dL_dsemantic_feature) run inside rasterize_gaussians_backward once that tensor is final on the stream; None removes it");
+    m.def("set_feature_grad_accumulator", [](py::object t) {
+              if (t.is_none()) feature_grad_accumulator() = torch::Tensor();
+              else feature_grad_accumulator() = t.cast<torch::Tensor>();
+          },
+          "tensor (P*C float32, contiguous, on the op's device) that the following backward calls ADD dL/dsemantic_feature into "
+          "(they then return an empty tensor for that gradient); None restores the default");
     m.def("set_grad_rows_hook", [](py::object fn, int chunks) { grad_rows_hook() = std::move(fn); grad_rows_chunks() = chunks > 0 ? chunks : 1; },
           py::arg("fn"), py::arg("chunks") = 4,
           "callable(row_begin, row_end, grads: dict) run inside rasterize_gaussians_backward after each of `chunks` row ranges of the "

@@ -234,6 +234,14 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
     present[i] = xform3(vp.view, p).z > 0.2f ? 1 : 0;
 }
 
+// M3C = 3 M when known at compile time (48: sixteen SH coefficients), 0 = any M / precomputed colours.  With M3C the SH
+// block of a wave's 64 Gaussians goes through a wave-private LDS tile: twelve coalesced 16-byte requests per lane, all in
+// flight together, rows of culled Gaussians skipped (their requests re-read the wave's first line), then per-lane rows with
+// an odd stride.  Round 3 read the coefficients per lane straight from global memory: 48 dword requests per lane with a
+// 192-byte lane stride (64 cache lines per request, the 48 KB a workgroup touches do not fit its 32 KB vector cache) in
+// four dependent rounds (one per SH band) - 3.8 TB/s, 47 % of the kernel's cycles vector-pipe busy.
+constexpr int PF_ROW = 49;        // LDS row stride of the SH tile (floats): odd, so that the per-lane rows are conflict-free
+template <int M3C>
 __global__ void __launch_bounds__(256)
 preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
                   const float* __restrict__ rotations, const float* __restrict__ opacities,
@@ -242,13 +250,27 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   SplatRec* __restrict__ rec, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
                   uint32_t* __restrict__ depth_key, int cull, uint32_t* __restrict__ ref_partial,
                   uint32_t* __restrict__ depth_hist) {
+    extern __shared__ __attribute__((aligned(16))) float sh_tile[];      // M3C: four wave-private tiles of 64 x PF_ROW floats
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // the digit histograms of the depth sort are accumulated by the NEXT kernel: zero them here (1024 words)
     if (blockIdx.x < 4) depth_hist[blockIdx.x * 256 + threadIdx.x] = 0;
     int out_radius = 0;
     uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu, bbox_tiles = 0;
+    // ---- part 1: projection and culling.  Every input of the Gaussian is requested first (index clamped: no branch in
+    // front of a load), `alive` says whether it survived
+    const size_t si = (size_t)(i < P ? i : 0);
+    const V3 p = {means3D[3 * si], means3D[3 * si + 1], means3D[3 * si + 2]};
+    const float opacity = opacities[si];
+    const bool have_sr = !cov3D_precomp;
+    const float* sp = have_sr ? scales + 3 * si : means3D + 3 * si;             // valid either way, see preprocess_backward_kernel
+    const float4* rp = have_sr ? reinterpret_cast<const float4*>(rotations) + si : reinterpret_cast<const float4*>(rec + si);
+    const V3 sc_in = {sp[0], sp[1], sp[2]};
+    const float4 q_in = *rp;
+    bool alive = false;
+    float px = 0.f, py = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, rad = 0.f, depth = 0.f;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (i < P) do {
-        const V3 p = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
         const V3 pv = xform3(vp.view, p);
         if (pv.z <= 0.2f) break;
         const float* pm = vp.proj;
@@ -262,9 +284,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
 #pragma unroll
             for (int k = 0; k < 6; k++) cov6[k] = cov3D_precomp[6 * (size_t)i + k];
         } else {
-            const V3 sc = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
-            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
-            cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov6);
+            cov3d_from_scale_rot(sc_in, vp.scale_modifier, q_in, cov6);
         }
         const Ewa e = ewa_setup(p, vp, cov6);
         float a, b, c;
@@ -272,32 +292,67 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         const float det = a * c - b * b;
         if (det == 0.0f) break;
         const float det_inv = 1.f / det;
-        const float ca = c * det_inv, cb = -b * det_inv, cc = a * det_inv;
+        ca = c * det_inv; cb = -b * det_inv; cc = a * det_inv;
         const float mid = 0.5f * (a + c);
         const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
         const float l1 = mid + root, l2 = mid - root;
-        const float rad = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
-        const float px = ndc_to_pix(projx, vp.W), py = ndc_to_pix(projy, vp.H);
-        int x0, y0, x1, y1;
+        rad = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+        px = ndc_to_pix(projx, vp.W); py = ndc_to_pix(projy, vp.H);
         tile_rect(px, py, (int)rad, vp.gx, vp.gy, x0, y0, x1, y1);
         if ((x1 - x0) * (y1 - y0) == 0) break;
+        depth = pv.z;
+        alive = true;
+    } while (false);
+
+    // ---- part 2 (M3C): the SH rows of the wave's surviving Gaussians -> the wave's LDS tile
+    float* const tile = sh_tile + w * (64 * PF_ROW);
+    if constexpr (M3C != 0) {
+        const unsigned long long amask = __ballot(alive);
+        const int wave_first = blockIdx.x * 256 + 64 * w;        // the wave's first Gaussian
+        if (amask != 0ull) {                                      // (wave-uniform; a wave with a survivor starts inside [0, P))
+            constexpr int NQ = M3C / 4;                           // 16-byte requests per lane
+            const float4* src = reinterpret_cast<const float4*>(shs + (size_t)wave_first * M3C);
+            float4 q[NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+                const int f = lane + 64 * k;                      // request f covers floats [4 f, 4 f + 4) of row f / (M3C / 4)
+                const bool on = (amask >> (f / NQ)) & 1ull;
+                q[k] = src[on ? f : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+                const int f = lane + 64 * k;
+                if ((amask >> (f / NQ)) & 1ull) {
+                    float* d = tile + 4 * f + f / NQ;             // element e of row r at e + r  (row stride M3C + 1 = PF_ROW)
+                    d[0] = q[k].x; d[1] = q[k].y; d[2] = q[k].z; d[3] = q[k].w;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wave's own LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- part 3: colour, record, tile count
+    if (alive) {
         V3 col;
         uint8_t cl = 0;
         if (colors_precomp) {
             col = {colors_precomp[3 * (size_t)i], colors_precomp[3 * (size_t)i + 1], colors_precomp[3 * (size_t)i + 2]};
+        } else if constexpr (M3C != 0) {
+            col = sh_to_rgb(D, p, vp.campos, tile + lane * PF_ROW, cl);
         } else {
-            col = sh_to_rgb(D, p, vp.campos, shs + 3 * (size_t)M * i, cl);   // (LDS staging measured slower here)
+            col = sh_to_rgb(D, p, vp.campos, shs + 3 * (size_t)M * i, cl);
         }
         SplatRec r;
         r.q0 = make_float4(px, py, ca, cb);
-        r.q1 = make_float4(cc, opacities[i], col.x, col.y);
-        r.q2 = make_float4(col.z, pv.z, __int_as_float((int)rad), 0.f);  // q2.z = radius bits (for emit)
+        r.q1 = make_float4(cc, opacity, col.x, col.y);
+        r.q2 = make_float4(col.z, depth, __int_as_float((int)rad), 0.f);  // q2.z = radius bits (for emit)
         rec[i] = r;
         clamped[i] = cl;
         out_radius = (int)rad;
         bbox_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
         if (cull) {
-            const CullParams ck = make_cull(px, py, ca, cb, cc, opacities[i]);
+            const CullParams ck = make_cull(px, py, ca, cb, cc, opacity);
             const float cdet_inv = 1.0f / (ca * cc - cb * cb);
             for (int ty = y0; ty < y1; ty++) {
                 int xa, xb;
@@ -306,8 +361,8 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         } else {
             out_tiles = bbox_tiles;
         }
-        out_key = __float_as_uint(pv.z);
-    } while (false);
+        out_key = __float_as_uint(depth);
+    }
     if (i < P) {
         if (radii) radii[i] = out_radius;
         tiles_touched[i] = out_tiles;
@@ -553,6 +608,12 @@ __device__ void sh_grad(int deg, V3 mean, const float* campos, const float* sh, 
 // with 256 threads, 49 KB each) and their load / compute / store phases interleave more finely: 0.160 -> 0.151 ms at
 // c3, 0.74 -> 0.68 at c5 (128 threads: 0.156 / 0.69).
 constexpr int PB_BLOCK = 64;
+// M3C = 3 M when known at compile time (48: the model's sixteen SH coefficients), 0 = any M.  With M3C the kernel issues
+// EVERY global load of a Gaussian block up front and branch-free - twelve 16-byte SH requests per lane, radius, gradient
+// record, mean, scale, rotation: one memory latency per wave.  (Round 3 staged the SH block in a rolled loop - one request,
+// one wait, twelve times - and fetched the gradient record behind the radius test: ~17 dependent round trips per wave,
+// 3.8 TB/s with 12 waves per CU.)
+template <int M3C>
 __global__ void __launch_bounds__(PB_BLOCK)
 preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
                            const float* __restrict__ shs, const float* __restrict__ scales,
@@ -574,10 +635,50 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
     const bool use_sh = dL_dsh && M > 0;
     const size_t sh_first = (size_t)blk * PB_BLOCK * 3 * M;
     const int sh_count = use_sh ? (int)min((size_t)PB_BLOCK * 3 * M, (size_t)P * 3 * M - sh_first) : 0;
-    const int m3 = 3 * M;                           // LDS index of element e: e + e / m3 (row stride m3 + 1)
+    const int m3 = M3C ? M3C : 3 * M;               // LDS index of element e: e + e / m3 (row stride m3 + 1)
     const bool sh_vec = (m3 & 3) == 0;              // rows are whole float4s (sh_first = 768 M is always 16-B aligned)
+    const bool in_range = i < P;
+    const size_t si = (size_t)(in_range ? i : 0);
+    constexpr int NQ = M3C ? M3C / 4 : 1;           // 16-byte SH requests per lane (PB_BLOCK rows of M3C floats)
+    float4 shq[NQ];
+    if constexpr (M3C != 0) {
+        if (use_sh) {
+            const float4* src = reinterpret_cast<const float4*>(shs + sh_first);
+            const int last = sh_count / 4 - 1;      // the block's tail (P not a multiple of 64) re-reads its last request
+#pragma unroll
+            for (int k = 0; k < NQ; k++) shq[k] = src[min((int)threadIdx.x + PB_BLOCK * k, last)];
+        }
+    }
+    // per-Gaussian inputs, requested unconditionally (a culled Gaussian's record is read and dropped: 14 % of the rows, one
+    // dependent latency less for everyone)
+    const int radius = radii[si];
+    float gr[GREC];
+    {
+        const float4* g4 = reinterpret_cast<const float4*>(grec + si * GREC);
+        const float4 a = g4[0], b = g4[1], c = g4[2];
+        gr[0] = a.x; gr[1] = a.y; gr[2] = a.z; gr[3] = a.w; gr[4] = b.x; gr[5] = b.y; gr[6] = b.z; gr[7] = b.w;
+        gr[8] = c.x; gr[9] = c.y; gr[10] = c.z; gr[11] = c.w;
+    }
+    const V3 mean = {means3D[3 * si], means3D[3 * si + 1], means3D[3 * si + 2]};
+    // scale / rotation: a valid address either way (precomputed covariances: the mean / the gradient record are re-read and
+    // dropped) - a branch here would make the compiler wait for every request above before it merges the two paths
+    const bool have_sr = scales && !cov3D_precomp;
+    const float* sp = have_sr ? scales + 3 * si : means3D + 3 * si;
+    const float4* rp = have_sr ? reinterpret_cast<const float4*>(rotations) + si : reinterpret_cast<const float4*>(grec + si * GREC);
+    const V3 sc_in = {sp[0], sp[1], sp[2]};
+    const float4 q_in = *rp;
+    const uint8_t clamp_bits = clamped[si];
     if (use_sh) {
-        if (sh_vec) {
+        if constexpr (M3C != 0) {
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+                const int e = 4 * ((int)threadIdx.x + PB_BLOCK * k);
+                if (e < sh_count) {
+                    float* d = sh_lds + e + e / M3C;
+                    d[0] = shq[k].x; d[1] = shq[k].y; d[2] = shq[k].z; d[3] = shq[k].w;
+                }
+            }
+        } else if (sh_vec) {
             for (int e = 4 * threadIdx.x; e < sh_count; e += 4 * PB_BLOCK) {
                 const float4 q = *reinterpret_cast<const float4*>(shs + sh_first + e);
                 float* d = sh_lds + e + e / m3;
@@ -588,16 +689,8 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
         }
         __syncthreads();
     }
-    const bool in_range = i < P;
-    const size_t si = (size_t)(in_range ? i : 0);
-    const bool vis = in_range && radii[si] > 0;
-    float gr[GREC];
-    if (vis) {
-        const float4* g4 = reinterpret_cast<const float4*>(grec + si * GREC);
-        const float4 a = g4[0], b = g4[1], c = g4[2];
-        gr[0] = a.x; gr[1] = a.y; gr[2] = a.z; gr[3] = a.w; gr[4] = b.x; gr[5] = b.y; gr[6] = b.z; gr[7] = b.w;
-        gr[8] = c.x; gr[9] = c.y; gr[10] = c.z; gr[11] = c.w;
-    } else {
+    const bool vis = in_range && radius > 0;
+    if (!vis) {
 #pragma unroll
         for (int k = 0; k < GREC; k++) gr[k] = 0.f;
     }
@@ -614,17 +707,14 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
     V3 dmean = {0, 0, 0};
     float dscale[3] = {0, 0, 0};
     float drot[4] = {0, 0, 0, 0};
-    const V3 mean = {means3D[3 * si], means3D[3 * si + 1], means3D[3 * si + 2]};
     if (vis) {
         float cov6[6];
-        V3 sc = {0, 0, 0};
-        float4 q = make_float4(0, 0, 0, 0);
+        const V3 sc = sc_in;
+        const float4 q = q_in;
         if (cov3D_precomp) {
 #pragma unroll
             for (int k = 0; k < 6; k++) cov6[k] = cov3D_precomp[6 * si + k];
         } else {
-            sc = {scales[3 * si], scales[3 * si + 1], scales[3 * si + 2]};
-            q = reinterpret_cast<const float4*>(rotations)[si];
             cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov6);
         }
         // ---- conic -> cov2D -> (cov3D, t), in matrix form ------------------------------------------------
@@ -739,10 +829,19 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3
         for (int k = 3 * usedc; k < m3; k++) rowp[k] = 0.f;
         if (vis) {
             const V3 dcol = {gr[6], gr[7], gr[8]};
-            sh_grad(D, mean, vp.campos, shc, clamped[si], dcol, dmean, rowp);
+            sh_grad(D, mean, vp.campos, shc, clamp_bits, dcol, dmean, rowp);
         }
         __syncthreads();
-        if (sh_vec) {
+        if constexpr (M3C != 0) {
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+                const int e = 4 * ((int)threadIdx.x + PB_BLOCK * k);
+                if (e < sh_count) {
+                    const float* d = sh_lds + e + e / M3C;
+                    *reinterpret_cast<float4*>(dL_dsh + sh_first + e) = make_float4(d[0], d[1], d[2], d[3]);
+                }
+            }
+        } else if (sh_vec) {
             for (int e = 4 * threadIdx.x; e < sh_count; e += 4 * PB_BLOCK) {
                 const float* d = sh_lds + e + e / m3;
                 *reinterpret_cast<float4*>(dL_dsh + sh_first + e) = make_float4(d[0], d[1], d[2], d[3]);
@@ -772,9 +871,14 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
                        const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull, hipStream_t s) {
     // at least 4 workgroups so that the depth_hist zero-fill above is complete even for tiny P
     const int grid = max(4, (P + 255) / 256);
-    hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, P, D, M, means3D, scales, rotations,
-                       opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped, g.tiles_touched,
-                       g.depth_key, cull, g.ref_partial, g.depth_hist);
+    if (M == 16 && shs && !colors_precomp)
+        hipLaunchKernelGGL(preprocess_kernel<48>, dim3(grid), dim3(256), 4 * 64 * PF_ROW * sizeof(float), s, P, D, M, means3D, scales,
+                           rotations, opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped,
+                           g.tiles_touched, g.depth_key, cull, g.ref_partial, g.depth_hist);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<0>, dim3(grid), dim3(256), 0, s, P, D, M, means3D, scales, rotations,
+                           opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped, g.tiles_touched,
+                           g.depth_key, cull, g.ref_partial, g.depth_hist);
 }
 
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
@@ -802,9 +906,14 @@ void launch_preprocess_backward(int P, int D, int M, int C, const float* means3D
     const int block0 = row_begin / PB_BLOCK, nblocks = (row_end - row_begin + PB_BLOCK - 1) / PB_BLOCK;
     if (nblocks <= 0) return;
     const size_t lds = (dL_dsh && M > 0) ? (size_t)PB_BLOCK * (3 * M + 1) * sizeof(float) : 0;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblocks), dim3(PB_BLOCK), lds, s, P, D, M, means3D, radii, shs,
-                       scales, rotations, cov3D_precomp, vp, g.clamped, grec, dL_dmean2D, dL_dconic, dL_dopacity,
-                       dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dz, block0);
+    if (M == 16)
+        hipLaunchKernelGGL(preprocess_backward_kernel<48>, dim3(nblocks), dim3(PB_BLOCK), lds, s, P, D, M, means3D, radii, shs,
+                           scales, rotations, cov3D_precomp, vp, g.clamped, grec, dL_dmean2D, dL_dconic, dL_dopacity,
+                           dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dz, block0);
+    else
+        hipLaunchKernelGGL(preprocess_backward_kernel<0>, dim3(nblocks), dim3(PB_BLOCK), lds, s, P, D, M, means3D, radii, shs,
+                           scales, rotations, cov3D_precomp, vp, g.clamped, grec, dL_dmean2D, dL_dconic, dL_dopacity,
+                           dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dz, block0);
 }
 
 int preprocess_backward_row_align() { return PB_BLOCK; }

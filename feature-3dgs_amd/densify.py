@@ -243,10 +243,19 @@ def compact(model) -> None:
     one of them by an exact-size clone (same values, optimizer state re-keyed) - call it before capturing a checkpoint, or
     before handing tensors to code that keeps them."""
     opt = getattr(model, "optimizer", None)
-    group_of = {g["name"]: g for g in opt.param_groups} if opt is not None else {}
+    group_of = {g.get("name"): g for g in opt.param_groups} if opt is not None else {}
+    if opt is not None:
+        # every parameter must be found in the optimizer BEFORE anything is replaced: with a missing or renamed group the
+        # optimizer would keep stepping the old pool view while the model holds the new tensor - training of that parameter
+        # would silently stop (ADVICE r3)
+        missing = [name for name, _attr in GROUPS if name not in group_of]
+        if missing:
+            raise KeyError(f"compact(): the optimizer has no param_group named {missing} (its groups: {sorted(map(str, group_of))})")
     for name, attr in GROUPS:
         p = getattr(model, attr)
         new_p = nn.Parameter(p.detach().clone().requires_grad_(True))
+        if p.grad is not None:          # called between backward() and step(): the gradient moves along
+            new_p.grad = p.grad.detach().clone()
         g = group_of.get(name)
         if g is not None:
             st = opt.state.pop(g["params"][0], None)

@@ -54,6 +54,14 @@ def set_grad_rows_hook(on_rows, chunks: int = 4, on_done=None) -> None:
     _rows_done_hook = on_done if on_rows is not None else None
 
 
+def set_feature_grad_accumulator(buffer: Optional[torch.Tensor]) -> None:
+    """Several views per optimiser step (not in the reference): while `buffer` - a contiguous float32 tensor with the P x C
+    elements of `semantic_feature`, normally the leaf's zero-initialised `.grad` - is set, every backward call ADDS its
+    feature gradient into it (no per-view gradient tensor, zero-fill or add) and reports no gradient for `semantic_feature`
+    to autograd.  The feature-gradient hook then sees the running sum.  `None` restores the default.  See dp.py: dp_step_views."""
+    _C.set_feature_grad_accumulator(buffer)
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -126,6 +134,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         (grad_means2D, grad_colors_precomp, grad_semantic_feature, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
          grad_sh, grad_scales, grad_rotations) = _call_with_snapshot(
             _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        if grad_semantic_feature.numel() == 0 and semantic_feature.numel() != 0:
+            grad_semantic_feature = None        # accumulated into the buffer of set_feature_grad_accumulator
         if _backward_done_hook is not None:
             _backward_done_hook()
         if _rows_done_hook is not None:
@@ -174,4 +184,4 @@ class GaussianRasterizer(nn.Module):
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "cpu_deep_copy_tuple",
-           "set_feature_grad_hook", "set_grad_rows_hook"]
+           "set_feature_grad_hook", "set_grad_rows_hook", "set_feature_grad_accumulator"]

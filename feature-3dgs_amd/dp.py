@@ -46,12 +46,18 @@ def _active(group) -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
-def views_for_rank(num_views: int, rank: int, world: int, iteration: int = 0) -> List[int]:
-    """Deterministic sharding: rank r renders views world*iteration + r (mod num_views) - every rank a
-    different view of the same step, every view visited equally often."""
+def views_for_rank(num_views: int, rank: int, world: int, iteration: int = 0, views_per_iter: Optional[int] = None) -> List[int]:
+    """Deterministic sharding: an iteration covers `views_per_iter` consecutive views (default: one per rank), rank r
+    renders its contiguous share of them - every rank different views of the same step, every view visited equally
+    often.  `views_per_iter` must be a multiple of the world size (every rank renders the same number: the collective
+    schedule and the step time are the same everywhere)."""
     if num_views <= 0:
         return []
-    return [(world * iteration + rank) % num_views]
+    V = world if views_per_iter is None else int(views_per_iter)
+    if V <= 0 or V % world != 0:
+        raise ValueError(f"views_per_iter = {V} is not a positive multiple of the world size {world}")
+    per = V // world
+    return [(V * iteration + rank * per + j) % num_views for j in range(per)]
 
 
 class GradBuckets:
@@ -244,11 +250,13 @@ class RowsGradOverlap:
         self._stream = None
         self._device = None
         self._installed = False
-        self._count = 0
+        self._count = 0                      # chunks actually reduced
+        self.fired = 0                       # hook invocations (the op was reached), reduced or not
         self.rows: List[tuple] = []          # (row_begin, row_end) of every call since entered
 
     def _hook(self, row_begin: int, row_end: int, grads: Dict[str, torch.Tensor]) -> None:
         self.rows.append((int(row_begin), int(row_end)))
+        self.fired += 1
         if not _active(self.group):
             return
         parts = [grads[n][row_begin:row_end] for n in self.names if grads[n].numel() > 0]
@@ -291,7 +299,9 @@ class RowsGradOverlap:
         self._works = []
 
     def reduced(self, leaves_of: Dict[str, Sequence[str]]) -> List[str]:
-        """The leaf keys made final by this object since it was entered: `leaves_of[name]` for every reduced op gradient."""
+        """The leaf keys made final by this object since it was entered: `leaves_of[name]` for every reduced op gradient.
+        Empty when the hook fired but the named gradients were empty (the op was fed precomputed colours: dL_dsh has zero
+        width, a property of the call that is the same on every rank) - those leaves then belong to the final all-reduce."""
         if self._count == 0:
             return []
         return [leaf for n in self.names for leaf in leaves_of.get(n, ())]
@@ -397,7 +407,10 @@ def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.
             rows_done: List[str] = []
             if rows_leaves:
                 rows_done = rv.reduced(rows_leaves)
-                if not rows_done:
+                # hook fired, nothing to reduce (zero-width SH gradient: colours were precomputed - the same on every rank):
+                # rows_done stays empty and the leaves go through the final all-reduce.  Only a hook that never fired means this
+                # rank did not reach the op while its peers wait in the chunk all-reduces.
+                if rv.fired == 0:
                     raise RuntimeError("dp_step: rows overlap was requested but this rank's backward pass never reached the op "
                                        "(its peers are waiting in the chunk all-reduces)")
             feat = leaves.get(feature_key)
@@ -419,3 +432,118 @@ def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.
     for vid in view_ids:
         render_and_backward(vid)
     return all_reduce_gaussian_grads(all_grads(), group=group, buckets=buckets)
+
+
+_stream_pool: Dict[tuple, list] = {}
+
+
+def _side_streams(device, n: int) -> list:
+    key = (device.type, device.index)
+    pool = _stream_pool.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+def dp_step_views(forward: Callable[[int], object], backward: Callable[[object], None], leaves: Dict[str, torch.Tensor],
+                  view_ids: Iterable[int], group=None, buckets: Optional[GradBuckets] = None, overlap: bool = True,
+                  feature_key: str = "semantic_feature", n_streams: int = 2, accumulate: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+    """One data-parallel step over SEVERAL views per rank (a step of `views_per_iter` views on fewer GPUs than views;
+    SURVEY.md 8(e): config c4 is "8 views per iteration").  `forward(view_id)` runs the op forward and the loss of one view
+    and returns a handle; `backward(handle)` runs its backward pass, accumulating into `leaves[k].grad`.  Afterwards
+    `leaves[k].grad` holds the sum over all views of all ranks, for every leaf.  Against `dp_step` with the same views:
+
+      * pipelining (HIP devices, `n_streams` >= 2): the views alternate between two side streams and view v + 1's forward
+        is enqueued right behind view v's backward - its preprocess and binning (launch- and HBM-bound, one host round
+        trip for the instance count) run under view v's blend kernels (issue-bound) instead of behind them.  Backward passes
+        stay ordered among themselves (they add into the same gradients);
+      * in-place accumulation (`accumulate`, default: on where the extension is present and the feature leaf is fed to the op
+        directly): the feature gradient - C of the 59 + C floats per Gaussian - of every view is ADDED by the blend backward
+        into the leaf's `.grad` itself (`set_feature_grad_accumulator`): one zero-fill per step instead of one per view, no
+        per-view (P, C) tensor, no per-view add;
+      * overlap: the all-reduce of that accumulated feature gradient starts inside the LAST view's backward pass, as soon as
+        its blend backward is enqueued (`FeatureGradOverlap`), under that view's per-Gaussian stage; the remaining leaves
+        follow in the bucketed all-reduce.  (The row-chunked SH overlap of `dp_step` needs the op-level gradient to BE the
+        step's gradient, i.e. one view per rank.)
+
+    The collective schedule depends on the leaves and the view COUNT only - every rank must render the same number of views."""
+    for v in leaves.values():
+        v.grad = None
+    view_ids = list(view_ids)
+    V = len(view_ids)
+    first = next(iter(leaves.values()))
+    dev = first.device
+    on_gpu = dev.type == "cuda"
+    feat = leaves.get(feature_key)
+    have_feat = feat is not None and feat.numel() > 0
+    if accumulate is None:
+        accumulate = on_gpu and have_feat and V > 0
+    dgr = None
+    if accumulate or (overlap and on_gpu):
+        import diff_gaussian_rasterization as dgr        # (the HIP extension; CPU stand-ins of the op run without it)
+    if accumulate:
+        if not (have_feat and feat.is_contiguous()):
+            raise ValueError("accumulate=True needs a contiguous feature leaf")
+        feat.grad = torch.zeros_like(feat)
+        dgr.set_feature_grad_accumulator(feat.grad)
+    active = _active(group)
+    ov = None
+    try:
+        pipelined = on_gpu and V > 1 and n_streams >= 2
+        if pipelined:
+            main = torch.cuda.current_stream(dev)
+            pool = _side_streams(dev, n_streams)
+            for st in pool:
+                st.wait_stream(main)                     # leaves, zeroed accumulator: ready on `main`
+            with torch.cuda.stream(pool[0]):
+                handle = forward(view_ids[0])
+            prev_done = None
+            for i in range(V):
+                st = pool[i % n_streams]
+                last = i == V - 1
+                with torch.cuda.stream(st):
+                    if prev_done is not None:
+                        st.wait_event(prev_done)         # backward passes add into the same gradients: one after the other
+                    if last and overlap and active and have_feat and dgr is not None:
+                        ov = FeatureGradOverlap(group)
+                        with ov:
+                            backward(handle)
+                    else:
+                        backward(handle)
+                    prev_done = torch.cuda.Event()
+                    prev_done.record(st)
+                if not last:
+                    with torch.cuda.stream(pool[(i + 1) % n_streams]):
+                        handle = forward(view_ids[i + 1])        # enqueued behind backward(i): runs under it
+            for st in pool:
+                main.wait_stream(st)
+        else:
+            for i, vid in enumerate(view_ids):
+                handle = forward(vid)
+                if i == V - 1 and overlap and active and have_feat and on_gpu and dgr is not None:
+                    ov = FeatureGradOverlap(group)
+                    with ov:
+                        backward(handle)
+                else:
+                    backward(handle)
+    finally:
+        if accumulate:
+            dgr.set_feature_grad_accumulator(None)
+    # the SAME key list on every rank (see dp_step)
+    if active:
+        for v in leaves.values():
+            if v.grad is None:
+                v.grad = torch.zeros_like(v)
+    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    if not active:
+        return grads
+    skip: List[str] = []
+    if have_feat and overlap and on_gpu:
+        # exactly ONE all-reduce of the feature gradient per rank and step (dp_step): inside the last backward pass where the
+        # hook fired, here otherwise
+        if ov is not None and ov.reduced((feature_key,)):
+            skip = [feature_key]
+        elif accumulate:
+            dist.all_reduce(grads[feature_key], op=dist.ReduceOp.SUM, group=group)
+            skip = [feature_key]
+    return all_reduce_gaussian_grads(grads, group=group, buckets=buckets, skip=skip)

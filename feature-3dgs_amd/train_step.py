@@ -75,11 +75,25 @@ def dp_train_step(render: Callable, loss_fn: Callable, model, cameras: Iterable,
         pkgs.append(pkg)
         losses.append(loss.detach())
 
+    def forward(i):
+        pkg = render(cameras[i], model, pipe, background)
+        loss = loss_fn(pkg, cameras[i])
+        pkgs.append(pkg)
+        losses.append(loss.detach())
+        return loss
+
     # the overlap needs the feature parameter to be the op's direct input (true for the reference's model:
     # get_semantic_feature returns the parameter itself, scene/gaussian_model.py:121-123)
-    grads = dp.dp_step(render_and_backward, params, range(len(cameras)), group=group,
-                       overlap=overlap and len(cameras) == 1, feature_key=feature_param,
-                       rows_leaves={"sh": tuple(sh_params)} if sh_params else None, rows_chunks=rows_chunks)
+    if len(cameras) > 1:
+        # several views per rank: pipelined over two streams, the feature gradient accumulated in place across the views and
+        # reduced from inside the last view's backward pass (dp.dp_step_views)
+        grads = dp.dp_step_views(forward, lambda loss: loss.backward(), params, range(len(cameras)), group=group,
+                                 overlap=overlap, feature_key=feature_param,
+                                 accumulate=None if overlap else False)
+    else:
+        grads = dp.dp_step(render_and_backward, params, range(len(cameras)), group=group,
+                           overlap=overlap and len(cameras) == 1, feature_key=feature_param,
+                           rows_leaves={"sh": tuple(sh_params)} if sh_params else None, rows_chunks=rows_chunks)
 
     if densification_stats:
         with torch.no_grad():

@@ -315,6 +315,17 @@ typedef void (*f3dgs_stage_fn)(void* ctx, void* stream /* hipStream_t */);
 void f3dgs_set_feature_grad_ready_callback(f3dgs_stage_fn fn, void* ctx);
 
 /*
+ * Gradient accumulation across views (no counterpart in the reference, which renders one view per step): with `on` != 0
+ * the following f3dgs_backward calls of this host thread ADD their feature gradient into `dL_dsemantic_feature` instead
+ * of overwriting it (the blend backward accumulates with atomics anyway: the zero-fill in front of it is skipped).  A
+ * caller that renders several views per optimiser step hands in ONE (P, C) buffer, zeroed once, for all of them - no
+ * per-view gradient tensor, no per-view zero-fill, no per-view add - and, data parallel, reduces that buffer from inside
+ * the LAST view's backward pass (f3dgs_set_feature_grad_ready_callback).  Every other output is overwritten as always.
+ * Thread-local; 0 restores the default.
+ */
+void f3dgs_set_feature_grad_accumulate(int on);
+
+/*
  * Second optional notification inside f3dgs_backward (no counterpart in the reference): with a callback registered the
  * per-Gaussian stage (K8 + K9, R/cuda_rasterizer/backward.cu:145-404 - row-parallel) runs as `chunks` launches over
  * consecutive row ranges, and `fn(ctx, stream, row_begin, row_end)` is called on the calling host thread right after the

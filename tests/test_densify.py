@@ -277,6 +277,17 @@ def test_compact_gives_exact_size_storage_for_checkpoints(tmp_path):
         p = getattr(m, a)
         p.grad = torch.randn_like(p) * 0.01
     m.optimizer.step()
+    # between backward() and step(): the gradients move along with the parameters
+    g_before = {a: getattr(m, a).grad.clone() for _, a in GROUPS}
+    densify.compact(m)
+    for _, a in GROUPS:
+        assert torch.equal(getattr(m, a).grad, g_before[a])
+    # a renamed optimizer group: refused before anything is replaced (the optimizer would keep stepping the old tensor)
+    m.optimizer.param_groups[0]["name"] = "positions"
+    held = m._xyz
+    with pytest.raises(KeyError, match="xyz"):
+        densify.compact(m)
+    assert m._xyz is held
 
 
 def test_c_abi_rejects_bad_plans():

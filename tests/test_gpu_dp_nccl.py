@@ -151,3 +151,84 @@ def test_rccl_code_paths_on_one_rank(tmp_path):
             w = leaves[k].grad.cpu().numpy().astype(np.float64)
             assert np.abs(got[f"{mode}_{k}"] - w).max() <= 1e-4 * np.abs(w).max() + 1e-12, (mode, k)
     assert got["rs_ok"][0] == 1.0
+
+
+def _run_views_fb(leaves, dev):
+    """(forward, backward) for dp.dp_step_views over the views of `_scene`."""
+    import diff_gaussian_rasterization as dgr
+    t = lambda x: x.to(dev)
+    P = leaves["means3D"].shape[0]
+    means2D = torch.zeros(P, 3, device=dev)
+
+    def forward(view_id):
+        sc = _scene(view_id)
+        st = dgr.GaussianRasterizationSettings(sc["image_height"], sc["image_width"], sc["tanfovx"], sc["tanfovy"], t(sc["bg"]), 1.0,
+                                               t(sc["viewmatrix"]), t(sc["projmatrix"]), 3, t(sc["campos"]), False, False)
+        color, feat, radii, depth = dgr.GaussianRasterizer(st)(means2D=means2D, **leaves)
+        return color, feat, t(sc["dL_dcolor"]), t(sc["dL_dfeature"])
+
+    def backward(h):
+        torch.autograd.backward([h[0], h[1]], [h[2], h[3]])
+    return forward, backward
+
+
+def _want_sum(views, dev):
+    want = None
+    for v in views:
+        leaves = _leaves(dev)
+        _run_view(v, leaves, dev)
+        g = {k: leaves[k].grad.cpu().numpy().astype(np.float64) for k in KEYS}
+        want = g if want is None else {k: want[k] + g[k] for k in KEYS}
+    return want
+
+
+@pytest.mark.parametrize("n_streams,accumulate", [(2, None), (1, None), (2, False)], ids=["pipelined+inplace", "one-stream+inplace", "pipelined+per-view-tensors"])
+def test_several_views_per_rank_pipelined_and_accumulated(n_streams, accumulate):
+    """dp.dp_step_views on one GPU, no process group: four views on two alternating streams with the feature gradient
+    accumulated in place by the blend backward (set_feature_grad_accumulator) give the sum of the four single-view gradients;
+    so do the same views on one stream, and the pipelined schedule with one gradient tensor per view."""
+    import dp
+    dev = torch.device("cuda", 0)
+    views = [0, 1, 2, 3]
+    want = _want_sum(views, dev)
+    leaves = _leaves(dev)
+    fwd, bwd = _run_views_fb(leaves, dev)
+    grads = dp.dp_step_views(fwd, bwd, leaves, views, n_streams=n_streams, accumulate=accumulate)
+    torch.cuda.synchronize()
+    for k in KEYS:
+        assert grads[k] is leaves[k].grad
+        err = np.abs(leaves[k].grad.cpu().numpy() - want[k]).max()
+        assert err <= 1e-4 * np.abs(want[k]).max() + 1e-12, (k, err)
+    # the accumulator is released: a plain step afterwards hands the feature gradient to autograd again
+    leaves2 = _leaves(dev)
+    _run_view(0, leaves2, dev)
+    assert leaves2["semantic_feature"].grad is not None and float(leaves2["semantic_feature"].grad.abs().max()) > 0
+
+
+def _solo_views_worker(rank, port, out_dir):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "feature-3dgs_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import dp
+    dp._active = lambda group: True          # take the collective code paths although the sum has one term
+    leaves = _leaves(dev)
+    fwd, bwd = _run_views_fb(leaves, dev)
+    dp.dp_step_views(fwd, bwd, leaves, [0, 1, 2], overlap=True)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "solo_views.npz"), **{k: leaves[k].grad.cpu().numpy() for k in KEYS})
+    dist.destroy_process_group()
+
+
+def test_views_step_rccl_code_paths_on_one_rank(tmp_path):
+    """The multi-view step through a one-rank `nccl` group: the all-reduce of the in-place accumulated feature gradient starts
+    inside the LAST view's backward pass on the side stream (FeatureGradOverlap), the rest follows in the bucketed all-reduce."""
+    mp.spawn(_solo_views_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(os.path.join(tmp_path, "solo_views.npz"))
+    want = _want_sum([0, 1, 2], torch.device("cuda", 0))
+    for k in KEYS:
+        assert np.abs(got[k] - want[k]).max() <= 1e-4 * np.abs(want[k]).max() + 1e-12, k

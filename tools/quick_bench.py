@@ -42,7 +42,7 @@ for setting in settings:
         k, v = kv.split("=")
         added.append((k, _C.get_option(k)))
         _C.set_option(k, int(v))
-    for _ in range(3):
+    for _ in range(10):
         step()
     torch.cuda.synchronize()
     _C.profile_reset()
