@@ -58,11 +58,18 @@ def _quat_to_rot(q: torch.Tensor) -> torch.Tensor:
 
 def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, projmatrix, campos, tanfovx,
               tanfovy, image_height, image_width, sh_degree=0, shs=None, colors_precomp=None, scales=None,
-              rotations=None, cov3D_precomp=None, scale_modifier=1.0, dtype=torch.float64) -> Dict[str, object]:
-    """Differentiable forward.  Inputs are torch tensors (leaf tensors may require grad)."""
+              rotations=None, cov3D_precomp=None, scale_modifier=1.0, dtype=torch.float64, tiles=None, alpha_min=1.0 / 255.0,
+              t_min=0.0001) -> Dict[str, object]:
+    """Differentiable forward.  Inputs are torch tensors (leaf tensors may require grad); the arithmetic runs on the device
+    of `means3D` (the integer binning always on the host).  `tiles` (iterable of tile ids, optional): only these tiles are
+    binned and blended - every pixel outside them keeps the background, and the gradient of a Gaussian is complete iff all
+    tiles of its bounding rectangle are listed (the fp64 adjudicator of the GPU parity tests, tests/adjudicate.py, evaluates a
+    handful of tiles of a full-size scene this way).  `alpha_min` / `t_min`: the two blend thresholds (forward.cu:349-358), movable
+    by the adjudicator to ask whether a pixel's discrete decisions are borderline."""
     H, W = int(image_height), int(image_width)
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
-    cast = lambda t: None if t is None else t.to(dtype)
+    dev = means3D.device
+    cast = lambda t: None if t is None else t.to(device=dev, dtype=dtype)
     bg, viewmatrix, projmatrix, campos = cast(bg), cast(viewmatrix), cast(projmatrix), cast(campos)
     means3D, opacities = cast(means3D), cast(opacities)
     P = means3D.shape[0]
@@ -70,7 +77,7 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
     feat = cast(semantic_feature).reshape(P, C)
     fx, fy = W / (2.0 * tanfovx), H / (2.0 * tanfovy)
 
-    ones = torch.ones(P, 1, dtype=dtype)
+    ones = torch.ones(P, 1, dtype=dtype, device=dev)
     p_view = (torch.cat([means3D, ones], 1) @ viewmatrix)[:, :3]
     p_hom = torch.cat([means3D, ones], 1) @ projmatrix
     p_w = 1.0 / (p_hom[:, 3] + 1e-7)
@@ -132,15 +139,35 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
         rgb = torch.clamp_min(_sh_to_rgb(int(sh_degree), cast(shs), d) + 0.5, 0.0)   # Q10
 
     # ---- binning (integer work, numpy) --------------------------------------------------------------
-    vidx = torch.nonzero(visible).flatten().numpy()
-    depth32 = p_view[:, 2].detach().to(torch.float32).numpy()
-    x0n, x1n, y0n, y1n = x0.numpy(), x1.numpy(), y0.numpy(), y1.numpy()
+    tile_set = None
+    cand = visible
+    if tiles is not None:
+        tile_set = np.unique(np.asarray(list(tiles), np.int64))
+        if tile_set.size:
+            t_x, t_y = tile_set % gx, tile_set // gx
+            cand = visible & (x0 <= int(t_x.max())) & (x1 > int(t_x.min())) & (y0 <= int(t_y.max())) & (y1 > int(t_y.min()))
+        else:
+            cand = visible & False
+    depth32 = p_view[:, 2].detach().to(torch.float32).cpu().numpy()
     keys, vals = [], []
-    for i in vidx:
-        ys, xs = np.meshgrid(np.arange(y0n[i], y1n[i]), np.arange(x0n[i], x1n[i]), indexing="ij")
-        t = (ys * gx + xs).reshape(-1).astype(np.uint64)
-        keys.append((t << np.uint64(32)) | np.uint64(depth32[i:i + 1].view(np.uint32)[0]))
-        vals.append(np.full(t.shape, i, np.int64))
+    if tile_set is not None:
+        # a handful of tiles of a possibly huge scene: one vectorised rectangle test per tile (ids come out ascending, the
+        # stable sort below orders them by depth bits) instead of a Python loop over every visible Gaussian
+        dbits = depth32.view(np.uint32).astype(np.uint64)
+        for t in tile_set.tolist():
+            t_x, t_y = t % gx, t // gx
+            ids = torch.nonzero(cand & (x0 <= t_x) & (x1 > t_x) & (y0 <= t_y) & (y1 > t_y)).flatten().cpu().numpy()
+            if ids.size:
+                keys.append((np.uint64(t) << np.uint64(32)) | dbits[ids])
+                vals.append(ids.astype(np.int64))
+    else:
+        vidx = torch.nonzero(cand).flatten().cpu().numpy()
+        x0n, x1n, y0n, y1n = x0.cpu().numpy(), x1.cpu().numpy(), y0.cpu().numpy(), y1.cpu().numpy()
+        for i in vidx:
+            ys, xs = np.meshgrid(np.arange(y0n[i], y1n[i]), np.arange(x0n[i], x1n[i]), indexing="ij")
+            t = (ys * gx + xs).reshape(-1).astype(np.uint64)
+            keys.append((t << np.uint64(32)) | np.uint64(depth32[i:i + 1].view(np.uint32)[0]))
+            vals.append(np.full(t.shape, i, np.int64))
     if keys:
         keys = np.concatenate(keys)
         vals = np.concatenate(vals)
@@ -154,21 +181,21 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
     ends = np.searchsorted(tiles, np.arange(n_tiles), side="right")
 
     # ---- blend, one tile at a time -------------------------------------------------------------------
-    out_color = torch.zeros(3, H, W, dtype=dtype) + bg[:, None, None]
-    out_feat = torch.zeros(C, H, W, dtype=dtype)
-    out_depth = torch.zeros(1, H, W, dtype=dtype)
+    out_color = torch.zeros(3, H, W, dtype=dtype, device=dev) + bg[:, None, None]
+    out_feat = torch.zeros(C, H, W, dtype=dtype, device=dev)
+    out_depth = torch.zeros(1, H, W, dtype=dtype, device=dev)
     n_contrib = np.zeros((H, W), np.int64)
-    final_T = torch.ones(H, W, dtype=dtype)
+    final_T = torch.ones(H, W, dtype=dtype, device=dev)
     color_tiles, feat_tiles, depth_tiles, slots = [], [], [], []
-    vals_t = torch.from_numpy(vals)
+    vals_t = torch.from_numpy(vals).to(dev)
     depth_all = p_view[:, 2]
-    for t in range(n_tiles):
+    for t in (range(n_tiles) if tile_set is None else tile_set.tolist()):
         lo, hi = int(starts[t]), int(ends[t])
         if hi == lo:
             continue
         tx_, ty_ = t % gx, t // gx
-        xs = torch.arange(tx_ * TILE, min(W, (tx_ + 1) * TILE))
-        ys = torch.arange(ty_ * TILE, min(H, (ty_ + 1) * TILE))
+        xs = torch.arange(tx_ * TILE, min(W, (tx_ + 1) * TILE), device=dev)
+        ys = torch.arange(ty_ * TILE, min(H, (ty_ + 1) * TILE), device=dev)
         py, px = torch.meshgrid(ys, xs, indexing="ij")
         pxf, pyf = px.reshape(-1, 1).to(dtype), py.reshape(-1, 1).to(dtype)
         g = vals_t[lo:hi]
@@ -180,11 +207,11 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
         a_raw = opacities[g, 0][None, :] * Gv
         alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()        # Q1 straight-through
         with torch.no_grad():
-            valid = (power <= 0) & (alpha >= 1.0 / 255.0)
+            valid = (power <= 0) & (alpha >= alpha_min)
         a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
         cum = torch.cumprod(1.0 - a_eff, dim=1)
         with torch.no_grad():
-            term = valid & (cum < 0.0001)
+            term = valid & (cum < t_min)
             after = torch.cumsum(term.to(torch.int64), dim=1) > 0               # Q5
             contrib = valid & ~after
         T_before = torch.cat([torch.ones_like(cum[:, :1]), cum[:, :-1]], dim=1)
@@ -193,16 +220,16 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
         col = w @ rgb[g] + T_fin[:, None] * bg[None, :]
         dep = w @ depth_all[g]
         ft = w.detach() @ feat[g]                                              # Q2
-        idx = torch.arange(1, hi - lo + 1)[None, :] * contrib.to(torch.int64)
-        n_contrib[py.reshape(-1).numpy(), px.reshape(-1).numpy()] = idx.max(dim=1).values.numpy()
+        idx = torch.arange(1, hi - lo + 1, device=dev)[None, :] * contrib.to(torch.int64)
+        n_contrib[py.reshape(-1).cpu().numpy(), px.reshape(-1).cpu().numpy()] = idx.max(dim=1).values.cpu().numpy()
         color_tiles.append(col); feat_tiles.append(ft); depth_tiles.append(dep)
         slots.append((py.reshape(-1), px.reshape(-1), T_fin.detach()))
     if slots:
         PY = torch.cat([s[0] for s in slots]); PX = torch.cat([s[1] for s in slots])
-        out_color = out_color.index_put((torch.arange(3)[:, None], PY[None, :], PX[None, :]), torch.cat(color_tiles).t())
+        out_color = out_color.index_put((torch.arange(3, device=dev)[:, None], PY[None, :], PX[None, :]), torch.cat(color_tiles).t())
         if C:
-            out_feat = out_feat.index_put((torch.arange(C)[:, None], PY[None, :], PX[None, :]), torch.cat(feat_tiles).t())
-        out_depth = out_depth.index_put((torch.zeros(1, dtype=torch.int64)[:, None], PY[None, :], PX[None, :]),
+            out_feat = out_feat.index_put((torch.arange(C, device=dev)[:, None], PY[None, :], PX[None, :]), torch.cat(feat_tiles).t())
+        out_depth = out_depth.index_put((torch.zeros(1, dtype=torch.int64, device=dev)[:, None], PY[None, :], PX[None, :]),
                                         torch.cat(depth_tiles)[None, :])
         final_T[PY, PX] = torch.cat([s[2] for s in slots])
     return dict(color=out_color, feature_map=out_feat, depth=out_depth, radii=radii, num_rendered=int(len(vals)),
@@ -210,16 +237,17 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
 
 
 def forward_backward(scene: dict, dtype=torch.float64, use_precomp_color=False, use_precomp_cov=False,
-                     want_grads=True) -> Dict[str, object]:
-    """Run forward (+ autograd backward against the scene's upstream gradients)."""
-    leaf = lambda t: t.detach().clone().to(dtype).requires_grad_(want_grads)
+                     want_grads=True, device="cpu", tiles=None, upstream=None, alpha_min=1.0 / 255.0, t_min=0.0001) -> Dict[str, object]:
+    """Run forward (+ autograd backward against the scene's upstream gradients, or `upstream` = (dL_dcolor, dL_dfeature,
+    dL_ddepth) in their place) on `device`, optionally restricted to `tiles` (see rasterize)."""
+    leaf = lambda t: t.detach().clone().to(device=device, dtype=dtype).requires_grad_(want_grads)
     P = scene["means3D"].shape[0]
     L = dict(means3D=leaf(scene["means3D"]), means2D=leaf(torch.zeros(P, 3)), opacities=leaf(scene["opacities"]),
              semantic_feature=leaf(scene["semantic_feature"]))
     kw = dict(bg=scene["bg"], viewmatrix=scene["viewmatrix"], projmatrix=scene["projmatrix"], campos=scene["campos"],
               tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], image_height=scene["image_height"],
               image_width=scene["image_width"], sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"],
-              dtype=dtype)
+              dtype=dtype, tiles=tiles, alpha_min=alpha_min, t_min=t_min)
     if use_precomp_color:
         L["colors_precomp"] = leaf(scene["colors_precomp"])
     else:
@@ -231,9 +259,11 @@ def forward_backward(scene: dict, dtype=torch.float64, use_precomp_color=False, 
     out = rasterize(**L, **kw)
     res = dict(out=out, leaves=L)
     if want_grads:
-        loss = (out["color"] * scene["dL_dcolor"].to(dtype)).sum() + (out["depth"] * scene["dL_ddepth"].to(dtype)).sum()
+        up = upstream if upstream is not None else (scene["dL_dcolor"], scene["dL_dfeature"], scene["dL_ddepth"])
+        up = [u.to(device=device, dtype=dtype) for u in up]
+        loss = (out["color"] * up[0]).sum() + (out["depth"] * up[2]).sum()
         if scene["semantic_feature"].shape[-1]:
-            loss = loss + (out["feature_map"] * scene["dL_dfeature"].to(dtype)).sum()
+            loss = loss + (out["feature_map"] * up[1]).sum()
         loss.backward()
         res["grads"] = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in L.items()}
     return res

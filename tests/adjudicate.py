@@ -1,0 +1,118 @@
+"""fp64 adjudicator for the GPU parity tests (TEST INFRASTRUCTURE; nothing in the product imports it).
+
+`tests/test_gpu_vs_ref.py` compares two fp32 implementations of the same algorithm - the product and the reference's own
+kernels compiled for gfx950.  Where they differ by more than a bar, neither is "the truth".  This module asks a third
+party: `oracle/torch_oracle.py` evaluated in fp64 FROM THE RAW INPUTS (its own projection, covariances, colours, its own
+list order), restricted to the handful of tiles the question is about (it runs on the GPU in fp64; a full 1080p image
+would take minutes).  Two questions:
+
+  * `forward_truth(scene, pixels)`: colour / feature / depth / final transmittance / n_contrib of the given pixels as the
+    exact arithmetic gives them, plus the same with the two blend thresholds (alpha >= 1/255, T >= 1e-4; forward.cu:349-358)
+    moved by a relative `delta` either way - a pixel whose value changes under that move has a discrete decision that fp32
+    round-off can flip (a BORDERLINE pixel);
+  * `gradient_truth(scene, gaussians, upstream)`: every leaf gradient of the given Gaussians (all tiles of their bounding
+    rectangles are evaluated, so their gradients are complete).
+
+The verdict functions turn them into statements the tests assert:
+
+  * a pixel where product and reference differ by more than the bar is acceptable iff the product is within the bar of
+    the truth under SOME threshold position in [1 - delta, 1 + delta] (then the difference is a borderline decision taken
+    the other way), or the product's error against the truth is within `slack` x the reference's own error against the
+    truth (+ bar) (then the pixel is ill-conditioned for fp32 and the product is no further from the exact value than the
+    reference is);
+  * the same for gradient elements.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+TILE = 16
+DELTA = 2e-4          # relative move of the blend thresholds that fp32 evaluation of alpha / T can explain
+
+
+def _tiles_of_pixels(pix: np.ndarray, W: int, H: int) -> np.ndarray:
+    gx = (W + TILE - 1) // TILE
+    y, x = pix // W, pix % W
+    return np.unique((y // TILE) * gx + (x // TILE))
+
+
+def _run(scene, pc, pv, dev, tiles, want_grads=False, upstream=None, alpha_min=1.0 / 255.0, t_min=1e-4):
+    from oracle import torch_oracle
+    return torch_oracle.forward_backward(scene, dtype=torch.float64, use_precomp_color=pc, use_precomp_cov=pv,
+                                         want_grads=want_grads, device=dev, tiles=tiles, upstream=upstream,
+                                         alpha_min=alpha_min, t_min=t_min)
+
+
+def forward_truth(scene: dict, pix: np.ndarray, pc=False, pv=False, dev="cuda:0", delta=DELTA, max_tiles=96):
+    """fp64 values at the flat pixel indices `pix` (at most `max_tiles` tiles are evaluated; pixels of further tiles are
+    reported as not adjudicated).  Returns (done_mask, variants) where variants is a list of dicts - nominal thresholds
+    first, then both thresholds moved by (1 + delta), then by (1 - delta) - of numpy arrays indexed like pix[done_mask]:
+    color (n,3), depth (n,), feature (n,C), final_T (n,), n_contrib (n,)."""
+    W, H = scene["image_width"], scene["image_height"]
+    pix = np.asarray(pix, np.int64)
+    tiles_all = _tiles_of_pixels(pix, W, H)
+    tiles = tiles_all[:max_tiles]
+    gx = (W + TILE - 1) // TILE
+    t_of = ((pix // W) // TILE) * gx + ((pix % W) // TILE)
+    done = np.isin(t_of, tiles)
+    sel = pix[done]
+    ys, xs = torch.from_numpy(sel // W), torch.from_numpy(sel % W)
+    out = []
+    for f in (1.0, 1.0 + delta, 1.0 - delta):
+        r = _run(scene, pc, pv, dev, tiles.tolist(), alpha_min=f / 255.0, t_min=f * 1e-4)["out"]
+        out.append(dict(color=r["color"][:, ys, xs].t().cpu().numpy(), depth=r["depth"][0, ys, xs].cpu().numpy(),
+                        feature=r["feature_map"][:, ys, xs].t().cpu().numpy(), final_T=r["final_T"][ys, xs].cpu().numpy(),
+                        n_contrib=r["n_contrib"][sel // W, sel % W]))
+    return done, out
+
+
+def forward_verdict(truths, prod: dict, ref: dict, bars: dict, slack=3.0):
+    """Per adjudicated pixel: (ok, e_prod, e_ref, borderline) with errors normalised by the bars (<= 1 means inside).
+    prod / ref: dicts like a truth variant (without n_contrib).  See the module docstring for the rule."""
+    def nerr(val, tr):
+        e = np.zeros(len(tr["final_T"]))
+        for k, bar in bars.items():
+            a, b = np.asarray(val[k], np.float64), np.asarray(tr[k], np.float64)
+            if a.size == 0:
+                continue
+            d = np.abs(a - b)
+            if k == "depth_rel":
+                continue
+            e = np.maximum(e, (d.reshape(len(e), -1).max(axis=1) if d.ndim > 1 else d) / bar)
+        return e
+    e_p = [nerr(prod, t) for t in truths]
+    e_r = [nerr(ref, t) for t in truths]
+    ep_best = np.minimum.reduce(e_p)
+    borderline = (ep_best <= 1.0) & (e_p[0] > 1.0)
+    ok = (ep_best <= 1.0) | (e_p[0] <= slack * e_r[0] + 1.0)
+    return ok, e_p[0], e_r[0], borderline
+
+
+def gradient_truth(scene: dict, gaussians: np.ndarray, upstream, pc=False, pv=False, dev="cuda:0", max_tiles=400):
+    """fp64 leaf gradients of the given Gaussians (dict: the op's input names -> (n, ...) arrays), or None when their bounding
+    rectangles cover more than `max_tiles` tiles.  `upstream` = the (dL_dcolor, dL_dfeature, dL_ddepth) actually used."""
+    W, H = scene["image_width"], scene["image_height"]
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    ids = np.asarray(gaussians, np.int64)
+    radii = _run(scene, pc, pv, dev, tiles=[])["out"]["radii"].cpu().numpy()       # fp64 projection of every Gaussian, no blending
+    # tile rectangles of the selected Gaussians (rasterizer_impl.cu:35-50) with one pixel of margin on the radius: the
+    # fp32 radius of either implementation may be one larger than the fp64 one
+    m = scene["means3D"][ids].double()
+    hom = torch.cat([m, torch.ones(len(ids), 1, dtype=torch.float64)], 1) @ scene["projmatrix"].double()
+    ndc = hom[:, :2] / (hom[:, 3:4] + 1e-7)
+    px = ((ndc[:, 0] + 1.0) * W - 1.0) * 0.5
+    py = ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5
+    r = torch.from_numpy(radii[ids].astype(np.float64)) + 1.0
+    x0 = ((px - r) / TILE).floor().clamp(0, gx - 1).long(); x1 = ((px + r) / TILE).floor().clamp(0, gx - 1).long()
+    y0 = ((py - r) / TILE).floor().clamp(0, gy - 1).long(); y1 = ((py + r) / TILE).floor().clamp(0, gy - 1).long()
+    tiles = set()
+    for a, b, c, d in zip(x0.tolist(), x1.tolist(), y0.tolist(), y1.tolist()):
+        for ty in range(c, d + 1):
+            for tx in range(a, b + 1):
+                tiles.add(ty * gx + tx)
+    if len(tiles) > max_tiles:
+        return None
+    res = _run(scene, pc, pv, dev, sorted(tiles), want_grads=True, upstream=upstream)
+    idt = torch.from_numpy(ids).to(dev)
+    return {k: v[idt].cpu().numpy() for k, v in res["grads"].items()}

@@ -1,0 +1,81 @@
+"""GPU box: what do the fp64 truths say about the pixels / gradient elements where product and reference differ by more than
+the strict bars?  (development probe behind tests/test_gpu_adjudicate.py)
+
+    python tools/adjudicate_probe.py c3 0        # config, yaw index
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "feature-3dgs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import refutil as ru, adjudicate as adj
+from synth import CONFIGS, make_scene, make_camera
+from util import set_option
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+yaw = float(sys.argv[2]) * 5.0 if len(sys.argv) > 2 else 0.0
+DEV = "cuda:0"
+scene = make_scene(seed=0, **CONFIGS[cfg])
+scene.update(make_camera(scene["image_width"], scene["image_height"], yaw_deg=yaw))
+W, H, P, C = scene["image_width"], scene["image_height"], scene["P"], scene["C"]
+ref, prod = ru.load_ref(C), ru.product_module()
+d = ru.device_inputs(scene, C, DEV)
+f_ref, f_prod = ru.raw_forward(ref, scene, d), ru.raw_forward(prod, scene, d)
+old = set_option("tile_cull", 0); f_prod0 = ru.raw_forward(prod, scene, d); set_option("tile_cull", old)
+img_ref, img_prod = ru.ref_image_state(f_ref, W, H), ru.product_image_state(scene, f_prod0)
+flips = ru.flip_pixels(img_ref, img_prod)
+dT = np.abs(img_ref["final_T"] - img_prod["final_T"])
+over = flips | (dT > 1e-5)
+errs = {}
+for i, k in ((1, "color"), (2, "feature"), (3, "depth")):
+    e = (f_ref[i] - f_prod[i]).abs().amax(dim=0).reshape(-1).cpu().numpy()
+    errs[k] = e
+    over |= e > 1e-4
+pix = np.nonzero(over)[0]
+print(f"{cfg} yaw {yaw}: {int(flips.sum())} proven flips, {int((dT > 1e-5).sum())} final_T over 1e-5, "
+      + ", ".join(f"{k} over 1e-4: {int((e > 1e-4).sum())}" for k, e in errs.items()) + f"; adjudicating {len(pix)} pixels")
+if len(pix):
+    done, truths = adj.forward_truth(scene, pix, dev=DEV)
+    sel = pix[done]
+    ys, xs = torch.from_numpy(sel // W).to(DEV), torch.from_numpy(sel % W).to(DEV)
+    take = lambda f: dict(color=f[1][:, ys, xs].t().cpu().numpy(), feature=f[2][:, ys, xs].t().cpu().numpy(), depth=f[3][0, ys, xs].cpu().numpy())
+    pv_, rv_ = take(f_prod), take(f_ref)
+    pv_["final_T"], rv_["final_T"] = img_prod["final_T"][sel], img_ref["final_T"][sel]
+    bars = dict(color=1e-4, feature=1e-4, depth=1e-4, final_T=1e-5)
+    ok, ep, er, bl = adj.forward_verdict(truths, pv_, rv_, bars)
+    print(f"adjudicated {len(sel)} pixels: ok {int(ok.sum())}, borderline {int(bl.sum())}; e_prod/bar: median {np.median(ep):.2f} max {ep.max():.2f}; "
+          f"e_ref/bar: median {np.median(er):.2f} max {er.max():.2f}")
+    for j in np.argsort(-ep)[:12]:
+        print(f"  pixel {sel[j]} flip={bool(flips[sel[j]])} nc ref/prod/truth {img_ref['n_contrib'][sel[j]]}/{img_prod['n_contrib'][sel[j]]}/{truths[0]['n_contrib'][j]} "
+              f"e_prod {ep[j]:.2f} e_ref {er[j]:.2f} ok={bool(ok[j])} borderline={bool(bl[j])} T ref/prod/truth {rv_['final_T'][j]:.6g}/{pv_['final_T'][j]:.6g}/{truths[0]['final_T'][j]:.6g}")
+# gradients
+keep = torch.from_numpy((~over).reshape(1, H, W)).to(DEV)
+up = (d["dL_dcolor"] * keep, d["dL_dfeature"] * keep, d["dL_ddepth"] * keep)
+g_ref = ru.raw_backward(ref, scene, d, f_ref, *up)
+g_prod = ru.raw_backward(prod, scene, d, f_prod, *up)
+names = {"dL_dmeans3D": "means3D", "dL_dmeans2D": "means2D", "dL_dopacity": "opacities", "dL_dsh": "shs", "dL_dscales": "scales",
+         "dL_drotations": "rotations", "dL_dsemantic_feature": "semantic_feature"}
+bad = {}
+for k, leaf in names.items():
+    a, b = g_ref[k].double(), g_prod[k].double()
+    scale = float(a.abs().max()) + 1e-30
+    ratio = ((b - a).abs() / (1e-3 * a.abs() + 1e-5 * scale)).reshape(P, -1).amax(dim=1)
+    idx = torch.nonzero(ratio > 1.0).flatten().cpu().numpy()
+    print(f"{k}: worst {float(ratio.max()):.2f}, {len(idx)} Gaussians over the bound")
+    for i in idx[:8]:
+        bad.setdefault(int(i), []).append(k)
+if bad:
+    ids = np.array(sorted(bad))
+    tr = adj.gradient_truth(scene, ids, tuple(u.cpu() for u in up), dev=DEV)
+    if tr is None:
+        print("rectangles too large to adjudicate")
+    else:
+        for n, i in enumerate(ids):
+            for k in bad[int(i)]:
+                t = tr[names[k]][n].reshape(-1)
+                a = g_ref[k][i].reshape(-1).double().cpu().numpy(); b = g_prod[k][i].reshape(-1).double().cpu().numpy()
+                if k == "dL_dmeans2D":
+                    t = np.concatenate([t[:2], [0.0]])[:len(a)]
+                scale = float(g_ref[k].abs().max())
+                bound = 1e-3 * np.abs(t) + 1e-5 * scale
+                print(f"  gaussian {i} {k}: e_prod/bound {np.max(np.abs(b - t) / bound):.2f}  e_ref/bound {np.max(np.abs(a - t) / bound):.2f}")
