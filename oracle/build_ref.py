@@ -42,7 +42,7 @@ DEFAULT_CHANNELS = (3, 16, 32, 64, 128, 256)
 # compiler's default contraction, as nvcc builds the reference.  Integer artefacts (radii, tile counts, num_rendered)
 # are asserted EXACTLY equal against the strict flavour at the full BASELINE sizes (tests/test_gpu_vs_ref.py); what
 # is left against the contracted flavour is then a documented property of the checker's build, not of the product.
-STRICT_CHANNELS = (16, 32, 128, 256)
+STRICT_CHANNELS = (3, 16, 32, 64, 128, 256)
 
 FILES = [
     "cuda_rasterizer/auxiliary.h", "cuda_rasterizer/backward.cu", "cuda_rasterizer/backward.h",

@@ -59,7 +59,7 @@ def _quat_to_rot(q: torch.Tensor) -> torch.Tensor:
 def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, projmatrix, campos, tanfovx,
               tanfovy, image_height, image_width, sh_degree=0, shs=None, colors_precomp=None, scales=None,
               rotations=None, cov3D_precomp=None, scale_modifier=1.0, dtype=torch.float64, tiles=None, alpha_min=1.0 / 255.0,
-              t_min=0.0001) -> Dict[str, object]:
+              t_min=0.0001, variants=None) -> Dict[str, object]:
     """Differentiable forward.  Inputs are torch tensors (leaf tensors may require grad); the arithmetic runs on the device
     of `means3D` (the integer binning always on the host).  `tiles` (iterable of tile ids, optional): only these tiles are
     binned and blended - every pixel outside them keeps the background, and the gradient of a Gaussian is complete iff all
@@ -181,14 +181,12 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
     ends = np.searchsorted(tiles, np.arange(n_tiles), side="right")
 
     # ---- blend, one tile at a time -------------------------------------------------------------------
-    out_color = torch.zeros(3, H, W, dtype=dtype, device=dev) + bg[:, None, None]
-    out_feat = torch.zeros(C, H, W, dtype=dtype, device=dev)
-    out_depth = torch.zeros(1, H, W, dtype=dtype, device=dev)
-    n_contrib = np.zeros((H, W), np.int64)
-    final_T = torch.ones(H, W, dtype=dtype, device=dev)
-    color_tiles, feat_tiles, depth_tiles, slots = [], [], [], []
+    # `variants`: several positions of the two thresholds evaluated on the SAME projection, lists and alphas (the adjudicator
+    # asks for five); the returned top-level outputs are those of the first
+    thresholds = list(variants) if variants else [(alpha_min, t_min)]
     vals_t = torch.from_numpy(vals).to(dev)
     depth_all = p_view[:, 2]
+    acc = [dict(color=[], feat=[], depth=[], slots=[], n_contrib=np.zeros((H, W), np.int64)) for _ in thresholds]
     for t in (range(n_tiles) if tile_set is None else tile_set.tolist()):
         lo, hi = int(starts[t]), int(ends[t])
         if hi == lo:
@@ -206,38 +204,50 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
         Gv = torch.exp(power)
         a_raw = opacities[g, 0][None, :] * Gv
         alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()        # Q1 straight-through
-        with torch.no_grad():
-            valid = (power <= 0) & (alpha >= alpha_min)
-        a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
-        cum = torch.cumprod(1.0 - a_eff, dim=1)
-        with torch.no_grad():
-            term = valid & (cum < t_min)
-            after = torch.cumsum(term.to(torch.int64), dim=1) > 0               # Q5
-            contrib = valid & ~after
-        T_before = torch.cat([torch.ones_like(cum[:, :1]), cum[:, :-1]], dim=1)
-        w = torch.where(contrib, alpha * T_before, torch.zeros_like(alpha))
-        T_fin = torch.prod(torch.where(contrib, 1.0 - alpha, torch.ones_like(alpha)), dim=1)
-        col = w @ rgb[g] + T_fin[:, None] * bg[None, :]
-        dep = w @ depth_all[g]
-        ft = w.detach() @ feat[g]                                              # Q2
-        idx = torch.arange(1, hi - lo + 1, device=dev)[None, :] * contrib.to(torch.int64)
-        n_contrib[py.reshape(-1).cpu().numpy(), px.reshape(-1).cpu().numpy()] = idx.max(dim=1).values.cpu().numpy()
-        color_tiles.append(col); feat_tiles.append(ft); depth_tiles.append(dep)
-        slots.append((py.reshape(-1), px.reshape(-1), T_fin.detach()))
-    if slots:
-        PY = torch.cat([s[0] for s in slots]); PX = torch.cat([s[1] for s in slots])
-        out_color = out_color.index_put((torch.arange(3, device=dev)[:, None], PY[None, :], PX[None, :]), torch.cat(color_tiles).t())
-        if C:
-            out_feat = out_feat.index_put((torch.arange(C, device=dev)[:, None], PY[None, :], PX[None, :]), torch.cat(feat_tiles).t())
-        out_depth = out_depth.index_put((torch.zeros(1, dtype=torch.int64, device=dev)[:, None], PY[None, :], PX[None, :]),
-                                        torch.cat(depth_tiles)[None, :])
-        final_T[PY, PX] = torch.cat([s[2] for s in slots])
-    return dict(color=out_color, feature_map=out_feat, depth=out_depth, radii=radii, num_rendered=int(len(vals)),
-                n_contrib=n_contrib, final_T=final_T, point_list=vals, ranges=np.stack([starts, ends], 1))
+        py_n, px_n = py.reshape(-1).cpu().numpy(), px.reshape(-1).cpu().numpy()
+        for (a_min, T_min), A in zip(thresholds, acc):
+            with torch.no_grad():
+                valid = (power <= 0) & (alpha >= a_min)
+            a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
+            cum = torch.cumprod(1.0 - a_eff, dim=1)
+            with torch.no_grad():
+                term = valid & (cum < T_min)
+                after = torch.cumsum(term.to(torch.int64), dim=1) > 0               # Q5
+                contrib = valid & ~after
+            T_before = torch.cat([torch.ones_like(cum[:, :1]), cum[:, :-1]], dim=1)
+            w = torch.where(contrib, alpha * T_before, torch.zeros_like(alpha))
+            T_fin = torch.prod(torch.where(contrib, 1.0 - alpha, torch.ones_like(alpha)), dim=1)
+            col = w @ rgb[g] + T_fin[:, None] * bg[None, :]
+            dep = w @ depth_all[g]
+            ft = w.detach() @ feat[g]                                              # Q2
+            idx = torch.arange(1, hi - lo + 1, device=dev)[None, :] * contrib.to(torch.int64)
+            A["n_contrib"][py_n, px_n] = idx.max(dim=1).values.cpu().numpy()
+            A["color"].append(col); A["feat"].append(ft); A["depth"].append(dep)
+            A["slots"].append((py.reshape(-1), px.reshape(-1), T_fin.detach()))
+    results = []
+    for A in acc:
+        out_color = torch.zeros(3, H, W, dtype=dtype, device=dev) + bg[:, None, None]
+        out_feat = torch.zeros(C, H, W, dtype=dtype, device=dev)
+        out_depth = torch.zeros(1, H, W, dtype=dtype, device=dev)
+        final_T = torch.ones(H, W, dtype=dtype, device=dev)
+        if A["slots"]:
+            PY = torch.cat([s_[0] for s_ in A["slots"]]); PX = torch.cat([s_[1] for s_ in A["slots"]])
+            out_color = out_color.index_put((torch.arange(3, device=dev)[:, None], PY[None, :], PX[None, :]), torch.cat(A["color"]).t())
+            if C:
+                out_feat = out_feat.index_put((torch.arange(C, device=dev)[:, None], PY[None, :], PX[None, :]), torch.cat(A["feat"]).t())
+            out_depth = out_depth.index_put((torch.zeros(1, dtype=torch.int64, device=dev)[:, None], PY[None, :], PX[None, :]),
+                                            torch.cat(A["depth"])[None, :])
+            final_T[PY, PX] = torch.cat([s_[2] for s_ in A["slots"]])
+        results.append(dict(color=out_color, feature_map=out_feat, depth=out_depth, final_T=final_T, n_contrib=A["n_contrib"]))
+    first = results[0]
+    return dict(color=first["color"], feature_map=first["feature_map"], depth=first["depth"], radii=radii, num_rendered=int(len(vals)),
+                n_contrib=first["n_contrib"], final_T=first["final_T"], point_list=vals, ranges=np.stack([starts, ends], 1),
+                variants=results if variants else None)
 
 
 def forward_backward(scene: dict, dtype=torch.float64, use_precomp_color=False, use_precomp_cov=False,
-                     want_grads=True, device="cpu", tiles=None, upstream=None, alpha_min=1.0 / 255.0, t_min=0.0001) -> Dict[str, object]:
+                     want_grads=True, device="cpu", tiles=None, upstream=None, alpha_min=1.0 / 255.0, t_min=0.0001,
+                     variants=None) -> Dict[str, object]:
     """Run forward (+ autograd backward against the scene's upstream gradients, or `upstream` = (dL_dcolor, dL_dfeature,
     dL_ddepth) in their place) on `device`, optionally restricted to `tiles` (see rasterize)."""
     leaf = lambda t: t.detach().clone().to(device=device, dtype=dtype).requires_grad_(want_grads)
@@ -247,7 +257,7 @@ def forward_backward(scene: dict, dtype=torch.float64, use_precomp_color=False, 
     kw = dict(bg=scene["bg"], viewmatrix=scene["viewmatrix"], projmatrix=scene["projmatrix"], campos=scene["campos"],
               tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], image_height=scene["image_height"],
               image_width=scene["image_width"], sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"],
-              dtype=dtype, tiles=tiles, alpha_min=alpha_min, t_min=t_min)
+              dtype=dtype, tiles=tiles, alpha_min=alpha_min, t_min=t_min, variants=variants)
     if use_precomp_color:
         L["colors_precomp"] = leaf(scene["colors_precomp"])
     else:

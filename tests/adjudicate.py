@@ -37,17 +37,16 @@ def _tiles_of_pixels(pix: np.ndarray, W: int, H: int) -> np.ndarray:
     return np.unique((y // TILE) * gx + (x // TILE))
 
 
-def _run(scene, pc, pv, dev, tiles, want_grads=False, upstream=None, alpha_min=1.0 / 255.0, t_min=1e-4):
+def _run(scene, pc, pv, dev, tiles, want_grads=False, upstream=None, variants=None):
     from oracle import torch_oracle
     return torch_oracle.forward_backward(scene, dtype=torch.float64, use_precomp_color=pc, use_precomp_cov=pv,
-                                         want_grads=want_grads, device=dev, tiles=tiles, upstream=upstream,
-                                         alpha_min=alpha_min, t_min=t_min)
+                                         want_grads=want_grads, device=dev, tiles=tiles, upstream=upstream, variants=variants)
 
 
 def forward_truth(scene: dict, pix: np.ndarray, pc=False, pv=False, dev="cuda:0", delta=DELTA, max_tiles=96):
     """fp64 values at the flat pixel indices `pix` (at most `max_tiles` tiles are evaluated; pixels of further tiles are
     reported as not adjudicated).  Returns (done_mask, variants) where variants is a list of dicts - nominal thresholds
-    first, then both thresholds moved by (1 + delta), then by (1 - delta) - of numpy arrays indexed like pix[done_mask]:
+    first, then the four (+-, +-) moves of the two thresholds by a relative delta - of numpy arrays indexed like pix[done_mask]:
     color (n,3), depth (n,), feature (n,C), final_T (n,), n_contrib (n,)."""
     W, H = scene["image_width"], scene["image_height"]
     pix = np.asarray(pix, np.int64)
@@ -58,12 +57,12 @@ def forward_truth(scene: dict, pix: np.ndarray, pc=False, pv=False, dev="cuda:0"
     done = np.isin(t_of, tiles)
     sel = pix[done]
     ys, xs = torch.from_numpy(sel // W), torch.from_numpy(sel % W)
-    out = []
-    for f in (1.0, 1.0 + delta, 1.0 - delta):
-        r = _run(scene, pc, pv, dev, tiles.tolist(), alpha_min=f / 255.0, t_min=f * 1e-4)["out"]
-        out.append(dict(color=r["color"][:, ys, xs].t().cpu().numpy(), depth=r["depth"][0, ys, xs].cpu().numpy(),
-                        feature=r["feature_map"][:, ys, xs].t().cpu().numpy(), final_T=r["final_T"][ys, xs].cpu().numpy(),
-                        n_contrib=r["n_contrib"][sel // W, sel % W]))
+    # nominal thresholds first; then each threshold moved either way (a pixel may hold one borderline decision of each kind)
+    moves = ((1.0, 1.0), (1.0 + delta, 1.0 + delta), (1.0 - delta, 1.0 - delta), (1.0 + delta, 1.0 - delta), (1.0 - delta, 1.0 + delta))
+    res = _run(scene, pc, pv, dev, tiles.tolist(), variants=[(fa / 255.0, ft * 1e-4) for fa, ft in moves])["out"]["variants"]
+    out = [dict(color=r["color"][:, ys, xs].t().cpu().numpy(), depth=r["depth"][0, ys, xs].cpu().numpy(),
+                feature=r["feature_map"][:, ys, xs].t().cpu().numpy(), final_T=r["final_T"][ys, xs].cpu().numpy(),
+                n_contrib=r["n_contrib"][sel // W, sel % W]) for r in res]
     return done, out
 
 

@@ -1,14 +1,25 @@
 """GPU parity PINNED TO THE REFERENCE ITSELF: the product's `_C` against the reference's own `_C`
-(`oracle/_ref/_refC<n>`, compiled for gfx950 from /root/reference by `oracle/build_ref.py`), both driven
+(`oracle/_ref/_refC<n>[s]`, compiled for gfx950 from /root/reference by `oracle/build_ref.py`), both driven
 through the same positional calls (`rasterize_points.h:18-72`) on the same seeded inputs.
 
-Bars (BASELINE.json north_star): RGB / feature / depth within 1e-4 absolute, gradients within 1e-3 relative,
-integer artefacts exact.  The blend has two hard thresholds (alpha < 1/255 skip, T < 1e-4 stop;
-`forward.cu:349-358`); a pixel where the two builds' `exp` roundings fall on different sides is a FLIP.  Flips
-are not hidden behind a blanket fraction: they are PROVEN per pixel from the two implementations' own
-n_contrib / final-T planes (`refutil.flip_pixels`), counted, bounded, and excluded EXACTLY from the gradient
-comparison by zeroing the upstream gradients of those pixels in both backward passes (every gradient term of
-a pixel is linear in that pixel's upstream gradients, `backward.cu:500-620`).
+The reference exists here in two builds of the same sources: the DEFAULT one (the compiler contracts a*b+c into FMAs, as
+nvcc does for the original) and the STRICT one (`-ffp-contract=off`, as the product's preprocess is built).  Every case
+runs a three-way comparison:
+
+  1. product vs STRICT reference - the north-star bars with nothing added: integer artefacts EXACT (radii, tiles_touched,
+     num_rendered), final transmittance <= 1e-5, RGB / feature / depth <= 1e-4 ABSOLUTE, every gradient element inside
+     1e-3 |g| + 1e-5 max|g|.  The blend has two hard thresholds (alpha < 1/255 skip, T < 1e-4 stop; `forward.cu:349-358`); a
+     pixel where two fp32 evaluations fall on different sides is a FLIP.  Flips are proven from the two implementations' own
+     n_contrib / final-T planes (`refutil.flip_pixels`), counted against a budget, and EVERY pixel above a bar - proven flip or
+     not - goes to the fp64 adjudicator (`tests/adjudicate.py`): it must be a borderline decision of the exact arithmetic
+     (the product's value is the exact one for a threshold moved by <= 2e-4 relative) or the product must be no further from
+     the exact value than the reference is.  Those pixels are excluded EXACTLY from the gradient comparison by zeroing their
+     upstream gradients in both backward passes (`backward.cu:500-620` is linear in them).
+  2. product vs DEFAULT reference and 3. STRICT reference vs DEFAULT reference, same statistics: what the product shows
+     against the contracted build beyond the bars of 1. (a radius off by one per 250k Gaussians, a projected mean off by one
+     ulp of a pixel coordinate -> final T up to 1e-4, depth up to 1.3e-4 at depth 8, a few more flips, a gradient element at
+     2x its bound on the rotated 2M-Gaussian views) the reference's OWN two builds show against each other to the same
+     extent.  Round 3 carried these as allowances with an explanation; here they are bounded by measurement 3.
 """
 import os
 
@@ -16,6 +27,7 @@ import numpy as np
 import pytest
 import torch
 
+import adjudicate as adj
 import refutil as ru
 from util import precompute_optionals, set_option
 
@@ -28,145 +40,177 @@ def _scene(**kw):
     return make_scene(**kw)
 
 
-# Threshold flips measured at full c3: 33 of 2,073,600 pixels (1.6e-5).  The budget is twice that rate (never below two
-# pixels): a build that flips more often than that has a different exponent or a different order of operations.
+# Threshold flips measured at full c3: 22 of 2,073,600 pixels against the strict build, 34 against the default one (1.6e-5).
+# The budget is twice that rate (never below two pixels): a build that flips more often than that has a different exponent
+# or a different order of operations.
 def flip_budget_for(npix: int) -> int:
     return max(2, npix // 31250)
 
 
-def _compare(scene, C_ref, pc=False, pv=False, flip_budget=None, check_state=True, report=None, strict_ints=False,
-             self_noise=True, return_grads=False, worst_bar=1.0):
-    """Forward + backward of both modules; returns a dict of measured errors (also asserted).
-    strict_ints: additionally run the `-ffp-contract=off` flavour of the reference (the product's preprocess is built
-    that way) and assert radii / tiles_touched / num_rendered EXACTLY equal to it.
-    Images and gradients are compared on the device (the full-size configs hold 10^9 elements)."""
-    W, H, P, C = scene["image_width"], scene["image_height"], scene["P"], scene["C"]
-    npix = W * H
-    ref, prod = ru.load_ref(C_ref), ru.product_module()
-    d_ref = ru.device_inputs(scene, C_ref, DEV, pc, pv)
-    d_prod = ru.device_inputs(scene, C, DEV, pc, pv) if C != C_ref else d_ref
-    f_ref = ru.raw_forward(ref, scene, d_ref)
-    f_prod = ru.raw_forward(prod, scene, d_prod)          # shipped configuration (tile culling on)
-    # n_contrib is a position in the PRIVATE instance list: it is comparable with the reference's only when the
-    # product keeps the reference's lists (option tile_cull = 0).  Both modes must give bit-identical images.
-    old = set_option("tile_cull", 0)
-    try:
-        f_prod0 = ru.raw_forward(prod, scene, d_prod)
-    finally:
-        set_option("tile_cull", old)
-    for i in (1, 2, 3, 4):
-        assert torch.equal(f_prod[i], f_prod0[i]), "tile culling changed an output"
-    stats = {}
+STRICT_BARS = dict(final_T=1e-5, color=1e-4, feature=1e-4, depth=1e-4)
 
-    # ---- integer artefacts
-    r_ref, r_prod = f_ref[4].cpu().numpy(), f_prod[4].cpu().numpy()
-    assert r_prod.dtype == r_ref.dtype and r_prod.shape == r_ref.shape
-    # num_rendered = sum of the 3-sigma rectangles' tile counts: equal whenever the radii are; a radius that differs by
-    # one (see below: only against the FMA-contracted flavour of the checker) moves its rectangle by at most one tile
-    # row and one tile column.  Against the strict flavour the count is asserted EXACTLY (strict_ints).
-    n_rad = int((r_ref != r_prod).sum())
-    gx, gy = (W + 15) // 16, (H + 15) // 16
-    # ... and a projected mean that sits on a tile boundary moves its rectangle's edge the same way (FMA contraction changes the
-    # last bit of the projection too): one edge per 100k Gaussians is allowed on top (seen: 7 of 2M on a view rotated by 30 degrees)
-    assert abs(int(f_ref[0]) - int(f_prod[0])) <= n_rad * (gx + gy + 1) + P // 100000, \
-        f"num_rendered {int(f_prod[0])} vs reference {int(f_ref[0])} with {n_rad} differing radii"
-    if strict_ints:
-        # same sources, no FMA contraction - as the product's preprocess: EXACT
-        f_s = ru.raw_forward(ru.load_ref(C_ref, strict=True), scene, d_ref)
-        assert int(f_s[0]) == int(f_prod[0])
-        assert torch.equal(f_s[4], f_prod[4]), f"{int((f_s[4] != f_prod[4]).sum())} radii differ from the strict reference build"
-        tt_s = ru.ref_geometry_state(f_s, P, C_ref, want={"tiles_touched"})["tiles_touched"]
-        tt_p = ru.product_read("tiles_touched", scene, f_prod0, np.uint32, P)
-        vis = r_prod > 0            # (the reference leaves tiles_touched of culled Gaussians unwritten)
-        assert np.array_equal(tt_s[vis], tt_p[vis]), "tiles_touched differs from the strict reference build"
-        stats["strict_radii_mismatch"] = 0
-        del f_s
-    # radii = ceil(3 sqrt(lambda_max)) (forward.cu:232): against the DEFAULT flavour of the checker (built with the
-    # compiler's FMA contraction, as nvcc builds the reference) a last-bit difference in lambda can move a value
-    # sitting on an integer across it.  A property of that build of the checker: counted, bounded to one per 250k
-    # Gaussians, never more than one pixel - and zero against the strict flavour above.
-    rad_bad = r_ref != r_prod
-    stats["radii_mismatch"] = int(rad_bad.sum())
-    assert stats["radii_mismatch"] <= P // 250000, f"{stats['radii_mismatch']} radii differ from the reference"
-    assert stats["radii_mismatch"] == 0 or int(np.abs(r_ref[rad_bad] - r_prod[rad_bad]).max()) == 1
 
-    img_ref = ru.ref_image_state(f_ref, W, H)
-    img_prod = ru.product_image_state(scene, f_prod0)
-    flips = ru.flip_pixels(img_ref, img_prod)
-    stats["flip_pixels"] = int(flips.sum())
-    budget = flip_budget_for(npix) if flip_budget is None else flip_budget
-    assert stats["flip_pixels"] <= budget, f"{stats['flip_pixels']} threshold-flip pixels (budget {budget})"
+class _Side:
+    """One implementation's forward pass of a scene: outputs, image state (final T, n_contrib on the reference's lists)."""
+
+    def __init__(self, kind, scene, C_mod, pc, pv, strict=False):
+        self.kind, self.scene = kind, scene
+        self.mod = ru.product_module() if kind == "prod" else ru.load_ref(C_mod, strict=strict)
+        self.d = ru.device_inputs(scene, C_mod, DEV, pc, pv)
+        self.C_mod = C_mod
+        self.f = ru.raw_forward(self.mod, scene, self.d)
+        W, H = scene["image_width"], scene["image_height"]
+        if kind == "prod":
+            # n_contrib is a position in the PRIVATE instance list: comparable with the reference's only when the product keeps
+            # the reference's lists (option tile_cull = 0).  Both modes must give bit-identical images.
+            old = set_option("tile_cull", 0)
+            try:
+                self.f0 = ru.raw_forward(self.mod, scene, self.d)
+            finally:
+                set_option("tile_cull", old)
+            for i in (1, 2, 3, 4):
+                assert torch.equal(self.f[i], self.f0[i]), "tile culling changed an output"
+            self.img = ru.product_image_state(scene, self.f0)
+        else:
+            self.f0 = self.f
+            self.img = ru.ref_image_state(self.f, W, H)
+
+    def backward(self, keep):
+        d = self.d
+        return ru.raw_backward(self.mod, self.scene, d, self.f, d["dL_dcolor"] * keep, d["dL_dfeature"] * keep, d["dL_ddepth"] * keep)
+
+    def tiles_touched(self):
+        P = self.scene["P"]
+        if self.kind == "prod":
+            return ru.product_read("tiles_touched", self.scene, self.f0, np.uint32, P)
+        return ru.ref_geometry_state(self.f, P, self.C_mod, want={"tiles_touched"})["tiles_touched"]
+
+
+def _forward_stats(A: _Side, B: _Side, same_width: bool):
+    """B against A: integer artefacts, flips, per-plane errors at the non-flip pixels, the pixels above the strict bars."""
+    sc = A.scene
+    W, H = sc["image_width"], sc["image_height"]
+    st = {}
+    rA, rB = A.f[4].cpu().numpy(), B.f[4].cpu().numpy()
+    assert rA.dtype == rB.dtype and rA.shape == rB.shape
+    st["radii_mismatch"] = int((rA != rB).sum())
+    st["radii_max_diff"] = int(np.abs(rA.astype(np.int64) - rB).max()) if rA.size else 0
+    st["num_rendered_diff"] = abs(int(A.f[0]) - int(B.f[0]))
+    flips = ru.flip_pixels(A.img, B.img)
+    st["flip_pixels"] = int(flips.sum())
     ok = ~flips
-    assert np.array_equal(img_ref["n_contrib"][ok], img_prod["n_contrib"][ok])
-    tr = img_ref["final_T"][ok]
-    # final transmittance = a product of (1 - alpha) over the whole list: a last-bit difference in an alpha near the 0.99 clamp is
-    # amplified by 1 / (1 - alpha), so the worst pixel grows with the depth of the lists: 1.3e-6 at c3, 1.6e-5 .. 5.6e-5 on the
-    # rotated 2M-Gaussian views.  Held to the bar of the images it feeds (bg * T, and every later blend weight): 1e-4
-    assert np.abs(tr - img_prod["final_T"][ok]).max() <= 1e-4
-
-    # ---- images: <= 1e-4 absolute at every pixel that is not a proven flip
-    keep = torch.from_numpy(ok.reshape(1, H, W)).to(DEV)
-    for i, k in ((1, "color"), (2, "feature_map"), (3, "depth")):
-        a, b = f_ref[i], f_prod[i]
-        if k == "feature_map" and C != C_ref:
-            assert tuple(b.shape) == (C, H, W)
+    dT = np.abs(A.img["final_T"].astype(np.float64) - B.img["final_T"])
+    st["final_T"] = float(dT[ok].max()) if ok.any() else 0.0
+    over = flips | (dT > STRICT_BARS["final_T"])
+    errs = {}
+    for i, k in ((1, "color"), (2, "feature"), (3, "depth")):
+        a, b = A.f[i], B.f[i]
+        if k == "feature" and not same_width:
             continue
         assert a.shape == b.shape, (k, a.shape, b.shape)
         if a.numel() == 0:
             continue
-        err = (a - b).abs().amax(dim=0, keepdim=True)
-        if k == "depth":
-            # depth is in scene units (up to 10 in the recipe), not in [0, 1] like the colour weights: the 1e-4 bar is taken
-            # relative to the value where it exceeds 1 (worst seen: 1.27e-4 at a depth of ~8 on a 2M-Gaussian view)
-            err = err / a.abs().amax(dim=0, keepdim=True).clamp(min=1.0)
-        stats[k] = float((err * keep).max())
-        if stats[k] > 1e-4:
-            # a threshold flip in the MIDDLE of a list at low transmittance changes neither n_contrib nor (measurably) final_T,
-            # so the planes cannot prove it; it moves the pixel by at most one alpha = 1/255 splat's worth of T x value.  Such
-            # pixels are charged to the same flip budget and bounded by that worth; every other pixel keeps the 1e-4 bar.
-            over = (err * keep) > 1e-4
-            n_over = int(over.sum())
-            stats[k + "_unproven_flips"] = n_over
-            assert stats["flip_pixels"] + n_over <= budget, f"{k}: {n_over} pixels above 1e-4 outside the {stats['flip_pixels']} proven flips (budget {budget})"
-            assert stats[k] <= 4e-3, f"{k}: max abs err {stats[k]:.3e} outside flip pixels"
-            stats[k] = float((err * keep * ~over).max())
-            keep = keep & ~over          # excluded from the gradient comparison like the proven flips
-        # a flip moves a pixel by at most one splat's worth of blend weight; it must stay small too
-        if flips.any():
-            stats[k + "_at_flips"] = float((err * ~keep).max())
-        del err
+        e = (a - b).abs().amax(dim=0).reshape(-1).cpu().numpy()
+        errs[k] = e
+        st[k] = float(e[ok].max()) if ok.any() else 0.0
+        over |= e > STRICT_BARS[k]
+    st["over_bar_pixels"] = int(over.sum())
+    if (ok & over).any():
+        sel = ok & over
+        st["over_bar_nonflip"] = int(sel.sum())
+        st["nonflip_worst"] = {k: float(e[sel].max()) for k, e in errs.items()}
+    st["n_contrib_equal_off_flips"] = bool(np.array_equal(A.img["n_contrib"][ok], B.img["n_contrib"][ok]))
+    return st, flips, over
 
-    # ---- gradients: upstream gradients zeroed at the (proven and unproven) flip pixels in BOTH passes
-    def masked(d):
-        return d["dL_dcolor"] * keep, d["dL_dfeature"] * keep, d["dL_ddepth"] * keep
 
-    g_ref = ru.raw_backward(ref, scene, d_ref, f_ref, *masked(d_ref))
-    g_prod = ru.raw_backward(prod, scene, d_prod, f_prod, *masked(d_prod))
-    # dL_dcolors (gradient w.r.t. the per-Gaussian RGB) is returned in SH mode too (rasterize_points.cu:199)
-    names = {"dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors"}
-    names |= set() if pc else {"dL_dsh"}
-    names |= {"dL_dcov3D"} if pv else {"dL_dscales", "dL_drotations"}
-    if C == C_ref:
-        names |= {"dL_dsemantic_feature"}
-    # the reference's own atomics noise (a second run of the same call), kept out of memory between tensors
-    g_ref2 = ru.raw_backward(ref, scene, d_ref, f_ref, *masked(d_ref)) if self_noise else None
+def _backward_stats(A: _Side, B: _Side, over, names, self_noise=False):
+    sc = A.scene
+    W, H = sc["image_width"], sc["image_height"]
+    keep = torch.from_numpy((~over).reshape(1, H, W)).to(DEV)
+    gA, gB = A.backward(keep), B.backward(keep)
+    gA2 = A.backward(keep) if self_noise else None      # the reference's own atomics noise (a second run of the same call)
+    st = {}
     for k in sorted(names):
-        a, b = g_ref[k], g_prod[k]
+        a, b = gA[k], gB[k]
         assert a.shape == b.shape, (k, a.shape, b.shape)
         if a.numel() == 0:
             continue
         mx, worst = ru.grad_errors(b, a)
-        mx_self, worst_self = ru.grad_errors(g_ref2[k], a) if self_noise else (float("nan"), float("nan"))
-        stats[k] = (mx, worst, mx_self, worst_self)
+        mx_self, worst_self = ru.grad_errors(gA2[k], a) if self_noise else (float("nan"), float("nan"))
+        st[k] = (mx, worst, mx_self, worst_self)
+    return st, gA, gB
+
+
+def _adjudicate(A: _Side, B: _Side, over, pc, pv, same_width, max_pixels=600):
+    """fp64 verdict on the pixels of `over` (B = the product).  Returns counts; asserts every adjudicated pixel."""
+    sc = A.scene
+    W = sc["image_width"]
+    pix = np.nonzero(over)[0][:max_pixels]
+    if len(pix) == 0:
+        return dict(adjudicated=0, borderline=0, not_worse_than_reference=0)
+    done, truths = adj.forward_truth(sc, pix, pc, pv, DEV)
+    sel = pix[done]
+    ys, xs = torch.from_numpy(sel // W).to(DEV), torch.from_numpy(sel % W).to(DEV)
+
+    def take(S):
+        v = dict(color=S.f[1][:, ys, xs].t().cpu().numpy(), depth=S.f[3][0, ys, xs].cpu().numpy(), final_T=S.img["final_T"][sel])
+        if same_width and S.f[2].numel():
+            v["feature"] = S.f[2][:, ys, xs].t().cpu().numpy()
+        return v
+    pv_, rv_ = take(B), take(A)
+    bars = {k: v for k, v in STRICT_BARS.items() if k in pv_}
+    ok, e_p, e_r, bl = adj.forward_verdict(truths, pv_, rv_, bars)
+    bad = np.nonzero(~ok)[0]
+    assert len(bad) == 0, (f"{len(bad)} of {len(sel)} pixels above the bars are neither borderline decisions of the exact arithmetic nor as "
+                           f"close to it as the reference: first pixel {int(sel[bad[0]])}, product {e_p[bad[0]]:.1f} bars and reference "
+                           f"{e_r[bad[0]]:.1f} bars from the fp64 value")
+    return dict(adjudicated=int(len(sel)), borderline=int(bl.sum()), not_worse_than_reference=int((ok & ~bl).sum()),
+                product_median_bars=float(np.median(e_p)), reference_median_bars=float(np.median(e_r)))
+
+
+def _grad_names(pc, pv, same_width):
+    # dL_dcolors (gradient w.r.t. the per-Gaussian RGB) is returned in SH mode too (rasterize_points.cu:199)
+    names = {"dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors"}
+    names |= set() if pc else {"dL_dsh"}
+    names |= {"dL_dcov3D"} if pv else {"dL_dscales", "dL_drotations"}
+    if same_width:
+        names |= {"dL_dsemantic_feature"}
+    return names
+
+
+def _compare(scene, C_ref, pc=False, pv=False, check_state=True, self_noise=True, return_grads=False, against_default=True):
+    """The three-way comparison of the module docstring; returns a dict of measured numbers (also asserted)."""
+    W, H, P, C = scene["image_width"], scene["image_height"], scene["P"], scene["C"]
+    npix = W * H
+    same = C == C_ref
+    names = _grad_names(pc, pv, same)
+    budget = flip_budget_for(npix)
+    prod = _Side("prod", scene, C, pc, pv)
+    strict = _Side("ref", scene, C_ref, pc, pv, strict=True)
+    stats = {}
+
+    # ---- 1. product vs the STRICT build: the bars as the north-star states them
+    st, flips, over = _forward_stats(strict, prod, same)
+    assert st["radii_mismatch"] == 0, f"{st['radii_mismatch']} radii differ from the strict reference build"
+    assert st["num_rendered_diff"] == 0
+    vis = prod.f[4].cpu().numpy() > 0            # (the reference leaves tiles_touched of culled Gaussians unwritten)
+    assert np.array_equal(strict.tiles_touched()[vis], prod.tiles_touched()[vis]), "tiles_touched differs from the strict reference build"
+    assert st["flip_pixels"] <= budget, f"{st['flip_pixels']} threshold-flip pixels (budget {budget})"
+    assert st["over_bar_pixels"] <= budget, f"{st['over_bar_pixels']} pixels above a bar (budget {budget})"
+    assert st["n_contrib_equal_off_flips"]
+    st["adjudication"] = _adjudicate(strict, prod, over, pc, pv, same)       # every pixel above a bar, flip or not
+    gst, g_ref, g_prod = _backward_stats(strict, prod, over, names, self_noise)
+    for k, (mx, worst, mx_self, worst_self) in gst.items():
         assert mx <= 1e-3, f"{k}: max err / max|g| = {mx:.2e} (reference run-to-run: {mx_self:.2e})"
-        assert worst <= worst_bar, (f"{k}: worst element is {worst:.2f}x outside 1e-3*|g| + 1e-5*max|g| "
-                              f"(reference run-to-run: {worst_self:.2f}x)")
-    del g_ref2
+        assert worst <= 1.0, (f"{k}: worst element is {worst:.2f}x outside 1e-3*|g| + 1e-5*max|g| (reference run-to-run: {worst_self:.2f}x)")
+    st["grads"] = gst
+    stats["vs_strict"] = st
+    if not return_grads:
+        del g_ref, g_prod
 
     if check_state:
-        geo = ru.ref_geometry_state(f_ref, P, C_ref, want={"means2D", "conic_opacity", "rgb", "depths"})
-        vis = (r_prod > 0) & ~rad_bad
-        rec = ru.product_read("rec", scene, f_prod, np.float32, P * 12).reshape(P, 12)
+        geo = ru.ref_geometry_state(strict.f, P, C_ref, want={"means2D", "conic_opacity", "rgb", "depths"})
+        rec = ru.product_read("rec", scene, prod.f, np.float32, P * 12).reshape(P, 12)
         for nm, got, want, tol in (("means2D", rec[:, 0:2], geo["means2D"].reshape(P, 2), 2e-3),
                                    ("conic", rec[:, 2:5], geo["conic_opacity"].reshape(P, 4)[:, :3], None),
                                    ("opacity", rec[:, 5], geo["conic_opacity"].reshape(P, 4)[:, 3], 0.0),
@@ -176,15 +220,42 @@ def _compare(scene, C_ref, pc=False, pv=False, flip_budget=None, check_state=Tru
                 continue
             g_, w_ = got[vis].astype(np.float64), want[vis].astype(np.float64)
             if tol is None:     # conics: relative (they span orders of magnitude)
-                e = (np.abs(g_ - w_) / (np.abs(w_).max(axis=1, keepdims=True) + 1e-30)).max()
-                stats["state_" + nm] = float(e)
+                e = (np.abs(g_ - w_) / (np.abs(w_).max(axis=1, keepdims=True) + 1e-30)).max() if g_.size else 0.0
                 assert e <= 1e-3, (nm, e)
             else:
                 e = np.abs(g_ - w_).max() if g_.size else 0.0
-                stats["state_" + nm] = float(e)
                 assert e <= tol, (nm, e)
-    if report is not None:
-        report.update(stats)
+            stats["state_" + nm] = float(e)
+            stats["state_" + nm + "_bit_equal"] = bool(np.array_equal(got[vis], want[vis]))
+        del geo, rec
+
+    # ---- 2. + 3. against the DEFAULT (FMA-contracted) build: the product, and the strict build of the same sources
+    if against_default:
+        dflt = _Side("ref", scene, C_ref, pc, pv, strict=False)
+        st_p, _f, over_p = _forward_stats(dflt, prod, same)
+        st_s, _f, over_s = _forward_stats(dflt, strict, same)
+        # a radius is ceil(3 sqrt(lambda_max)) (forward.cu:232): a last-bit difference in lambda can move a value sitting on an
+        # integer across it - by one, for at most one Gaussian in 250k; num_rendered follows the rectangles
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        assert st_p["radii_mismatch"] == st_s["radii_mismatch"] <= max(1, P // 250000) and st_p["radii_max_diff"] <= 1
+        assert st_p["num_rendered_diff"] == st_s["num_rendered_diff"] <= st_p["radii_mismatch"] * (gx + gy + 1) + P // 100000
+        # what the contracted build costs the PRODUCT it costs the reference's own strict build too (x 1.5 + the strict bar)
+        assert st_p["flip_pixels"] <= 1.5 * st_s["flip_pixels"] + budget
+        assert st_p["over_bar_pixels"] <= 1.5 * st_s["over_bar_pixels"] + budget
+        for k in ("final_T", "color", "feature", "depth"):
+            if k in st_p:
+                assert st_p[k] <= 1.5 * st_s[k] + STRICT_BARS[k], (k, st_p[k], st_s[k])
+        both = over_p | over_s
+        g_p, _a, _b = _backward_stats(dflt, prod, both, names)
+        g_s, _a, _b = _backward_stats(dflt, strict, both, names)
+        del _a, _b
+        for k in g_p:
+            assert g_p[k][0] <= 1e-3, (k, g_p[k])
+            assert g_p[k][1] <= max(1.0, 1.5 * g_s[k][1]), (f"{k}: worst element {g_p[k][1]:.2f}x its bound against the default build; the "
+                                                             f"reference's strict build shows {g_s[k][1]:.2f}x against it")
+        st_p["grads"], st_s["grads"] = g_p, g_s
+        stats["vs_default"], stats["strict_reference_vs_default"] = st_p, st_s
+        del dflt
     if return_grads:
         return stats, {k: g_ref[k] for k in names}, {k: g_prod[k] for k in names}
     return stats
@@ -234,7 +305,7 @@ def test_forward_backward_vs_reference(case, record_property):
     scene = _build(case)
     st = _compare(scene, case.get("Cref", case["C"]), case.get("pc", False), case.get("pv", False))
     for k, v in st.items():
-        record_property(k, v)
+        record_property(k, str(v))
     print(case["id"], st)
 
 
@@ -282,38 +353,37 @@ def test_mark_visible_vs_reference():
 
 @pytest.mark.parametrize("cfg", ["c2", "c3", "c4", "c5"])
 def test_full_size_config_vs_reference(cfg, record_property):
-    """BASELINE.json configs c2 (500k, 1080p, C=16), c3 (1M, 1080p, C=32), c4 (2M, 1080p, C=256: four 64-channel
-    windows over long lists) and c5 (5M, 3840x2160, C=128, depth gradients on: 240 x 135 tiles, ~140M instances) at
-    FULL size against the reference's kernels (`rasterizer_impl.cu:198-461`); integer artefacts EXACTLY equal to the
-    `-ffp-contract=off` flavour of the reference."""
+    """BASELINE.json configs c2 (500k, 1080p, C=16), c3 (1M, 1080p, C=32), c4 (2M, 1080p, C=256: 128-channel windows over
+    long lists) and c5 (5M, 3840x2160, C=128, depth gradients on: 240 x 135 tiles, ~140M instances) at FULL size against the
+    reference's kernels (`rasterizer_impl.cu:198-461`): the three-way comparison of the module docstring, strict bars
+    against the `-ffp-contract=off` build, fp64 adjudication of every pixel above a bar."""
     from synth import CONFIGS
     scene = _scene(seed=0, **CONFIGS[cfg])
     big = cfg in ("c4", "c5")
-    st = _compare(scene, scene["C"], check_state=True, strict_ints=True, self_noise=not big)
+    st = _compare(scene, scene["C"], check_state=True, self_noise=not big)
     for k, v in st.items():
-        record_property(k, v)
+        record_property(k, str(v))
     print(cfg, st)
     torch.cuda.empty_cache()
 
 
 def test_c4_eight_views_summed_gradients_vs_reference(record_property):
     """BASELINE.json config c4 as it is meant: 2M Gaussians, C = 256, EIGHT views per iteration (view i rotated by
-    i x 5 degrees) rendered one after the other; the per-Gaussian gradients summed over the eight
-    views (what the data-parallel step all-reduces) against the sum of eight reference backward calls."""
+    i x 5 degrees) rendered one after the other; every view against the strict reference build at the strict
+    bars (flips adjudicated in fp64), views 1 and 6 also against the default build (where the reference's own two builds are
+    furthest apart: 164 flips and a gradient element at 2x its bound between them on the view rotated by 30 degrees); the
+    per-Gaussian gradients summed over the eight views (what the data-parallel step all-reduces) against the sum of eight
+    reference backward calls."""
     from synth import CONFIGS, make_camera
     scene = _scene(seed=0, **CONFIGS["c4"])
-    tot_ref, tot_prod, flips = {}, {}, 0
+    tot_ref, tot_prod, flips, adjud = {}, {}, 0, 0
     for v in range(8):
         sc = dict(scene)
         sc.update(make_camera(scene["image_width"], scene["image_height"], yaw_deg=5.0 * v))
-        # threshold flips grow with the number of blending pairs and with the rotation of the view: 27, 75, 103, 75, 86, 83, 170, ...
-        # over the views of this 2M-Gaussian scene (c3, 1M Gaussians: 33); budget = a little over twice the worst
-        # per view the element-wise criterion is relaxed to 3x its bound (view 1 has ONE dL_dmeans2D element at 2.1x, with the
-        # instance-lane and the pixel-lane backward alike - a threshold decision the image planes cannot show); the SUMMED
-        # gradients below - what the data-parallel step exchanges - are held to the strict bound
-        st, g_ref, g_prod = _compare(sc, sc["C"], check_state=False, self_noise=False, return_grads=True, flip_budget=400, worst_bar=3.0)
-        flips += st["flip_pixels"]
-        print(f"c4 view {v}: {st['flip_pixels']} flip pixels")
+        st, g_ref, g_prod = _compare(sc, sc["C"], check_state=False, self_noise=False, return_grads=True, against_default=v in (1, 6))
+        flips += st["vs_strict"]["flip_pixels"]
+        adjud += st["vs_strict"]["adjudication"]["adjudicated"]
+        print(f"c4 view {v}: {st['vs_strict']['flip_pixels']} flip pixels, adjudication {st['vs_strict']['adjudication']}")
         for k in g_ref:
             tot_ref[k] = g_ref[k].double() if k not in tot_ref else tot_ref[k].add_(g_ref[k])
             tot_prod[k] = g_prod[k].double() if k not in tot_prod else tot_prod[k].add_(g_prod[k])
@@ -324,7 +394,8 @@ def test_c4_eight_views_summed_gradients_vs_reference(record_property):
         record_property(k, (mx, worst))
         assert mx <= 1e-3 and worst <= 1.0, (k, mx, worst)
     record_property("flip_pixels_8_views", flips)
-    print("c4 x 8 views", flips)
+    record_property("adjudicated_pixels_8_views", adjud)
+    print("c4 x 8 views", flips, adjud)
 
 
 def test_product_library_does_not_depend_on_the_checker():

@@ -18,11 +18,19 @@ DEV = "cuda:0"
 scene = make_scene(seed=0, **CONFIGS[cfg])
 scene.update(make_camera(scene["image_width"], scene["image_height"], yaw_deg=yaw))
 W, H, P, C = scene["image_width"], scene["image_height"], scene["P"], scene["C"]
-ref, prod = ru.load_ref(C), ru.product_module()
+mode = [a for a in sys.argv[3:] if not a.startswith("--")]
+mode = mode[0] if mode else "default"      # default: product vs contracted reference; strict: product vs -ffp-contract=off reference; refs: strict reference in the product's seat
+ref = ru.load_ref(C, strict=(mode == "strict"))
+prod = ru.load_ref(C, strict=True) if mode == "refs" else ru.product_module()
 d = ru.device_inputs(scene, C, DEV)
 f_ref, f_prod = ru.raw_forward(ref, scene, d), ru.raw_forward(prod, scene, d)
-old = set_option("tile_cull", 0); f_prod0 = ru.raw_forward(prod, scene, d); set_option("tile_cull", old)
-img_ref, img_prod = ru.ref_image_state(f_ref, W, H), ru.product_image_state(scene, f_prod0)
+if mode == "refs":
+    f_prod0 = f_prod
+    img_ref, img_prod = ru.ref_image_state(f_ref, W, H), ru.ref_image_state(f_prod, W, H)
+else:
+    old = set_option("tile_cull", 0); f_prod0 = ru.raw_forward(prod, scene, d); set_option("tile_cull", old)
+    img_ref, img_prod = ru.ref_image_state(f_ref, W, H), ru.product_image_state(scene, f_prod0)
+print("mode", mode, "| radii differing:", int((f_ref[4] != f_prod[4]).sum()), "| num_rendered", int(f_ref[0]), int(f_prod[0]))
 flips = ru.flip_pixels(img_ref, img_prod)
 dT = np.abs(img_ref["final_T"] - img_prod["final_T"])
 over = flips | (dT > 1e-5)
@@ -79,3 +87,28 @@ if bad:
                 scale = float(g_ref[k].abs().max())
                 bound = 1e-3 * np.abs(t) + 1e-5 * scale
                 print(f"  gaussian {i} {k}: e_prod/bound {np.max(np.abs(b - t) / bound):.2f}  e_ref/bound {np.max(np.abs(a - t) / bound):.2f}")
+
+# ---- which per-Gaussian state entries explain the continuous (non-flip) deviations?
+if len(pix) and "--state" in sys.argv:
+    nf = [j for j in np.argsort(-ep) if not flips[sel[j]]][:3]
+    from oracle import torch_oracle
+    for j in nf:
+        p_ = int(sel[j]); y_, x_ = p_ // W, p_ % W
+        gx = (W + 15) // 16
+        t = (y_ // 16) * gx + x_ // 16
+        pl = ru.ref_point_list(f_ref); rg = ru.ref_image_state(f_ref, W, H)["ranges"].reshape(-1, 2)
+        ids = pl[rg[t, 0]:rg[t, 0] + int(img_ref["n_contrib"][p_])].astype(np.int64)
+        geo = ru.ref_geometry_state(f_ref, P, C, want={"means2D", "conic_opacity"})
+        rec = ru.product_read("rec", scene, f_prod, np.float32, P * 12).reshape(P, 12)
+        # fp64 state of these Gaussians
+        sub = {k: (v[ids] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == P else v) for k, v in scene.items()}
+        con_r = geo["conic_opacity"].reshape(P, 4)[ids, :3].astype(np.float64); m_r = geo["means2D"].reshape(P, 2)[ids].astype(np.float64)
+        con_p = rec[ids, 2:5].astype(np.float64); m_p = rec[ids, 0:2].astype(np.float64)
+        dx_r, dy_r = m_r[:, 0] - x_, m_r[:, 1] - y_
+        dx_p, dy_p = m_p[:, 0] - x_, m_p[:, 1] - y_
+        pw_r = -0.5 * (con_r[:, 0] * dx_r ** 2 + con_r[:, 2] * dy_r ** 2) - con_r[:, 1] * dx_r * dy_r
+        pw_p = -0.5 * (con_p[:, 0] * dx_p ** 2 + con_p[:, 2] * dy_p ** 2) - con_p[:, 1] * dx_p * dy_p
+        w = np.argsort(-np.abs(pw_r - pw_p))[:4]
+        print(f"pixel {p_} ({x_},{y_}) tile {t}: {len(ids)} contributors; largest |power_ref_state - power_prod_state| (fp64 eval of the fp32 states):")
+        for k in w:
+            print(f"   gaussian {ids[k]}: power ref-state {pw_r[k]:.6f} prod-state {pw_p[k]:.6f}; conic ref {con_r[k]} prod {con_p[k]}; mean ref {m_r[k]} prod {m_p[k]}; scales {scene['scales'][ids[k]].numpy()}")
