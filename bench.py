@@ -49,6 +49,7 @@ for p in (ROOT, os.path.join(ROOT, "feature-3dgs_amd")):
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_ACHIEVABLE_GBS = 6290.0   # MI355X_MICROARCH.md "Chip-level parameters": what a float4 copy reaches
 FP32_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz, un-packed fp32 (157.3 with v_pk_fma)
 
 
@@ -64,6 +65,9 @@ def algorithmic_bytes(P, Pv, N, N_r, HW, tiles, C, M=16):
         "preprocess_bwd": (179 + 24 * M) * Pv,
     }
     a["total"] = sum(a.values())
+    # strict lower bound A_min: perfect cross-tile cache reuse - every visible Gaussian's record / feature
+    # row is read once by the blend forward and its gradient partial written once by the blend backward
+    a["total_min"] = a["total"] - (44 + 4 * C) * (N_r - Pv) - (40 + 4 * C) * (N_r - Pv)
     return a
 
 
@@ -113,7 +117,7 @@ def cpu_baseline(cfg_kw):
     o.backward(sc["dL_dcolor"], sc["dL_dfeature"], sc["dL_ddepth"])
     dt = time.perf_counter() - t0
     mpix = kw["width"] * kw["height"] / 1e6
-    return {"value": mpix / dt, "unit": "Mpix/s", "cores": 1, "kind": "port",
+    return {"value": mpix / dt, "unit": "Mpix/s", "cores": 1, "kind": "port", "workload_fraction": kw["P"] / cfg_kw["P"],
             "sample": f"1 fwd+bwd of the scalar C++ oracle on {kw['P']} Gaussians @{kw['width']}x{kw['height']}, "
                       f"feat_dim={kw['C']} (the workload with 1/5 of the Gaussians), {dt:.1f} s"}
 
@@ -179,6 +183,44 @@ def cpu_reference_path_c1(dev):
                     "rasterizer), median of up to 5 runs after 1 warm-up per thread count, best count reported; with "
                     "torch.set_num_threads(256) one step took 259 s on this host class (profiles/r02_notes.md). "
                     "GPU: this library, mean of 200 steps after 300 warm-up steps (launch-bound: ~30 launches and one host read-back per step)"}
+
+
+def cpu_reference_path_c3_reduced(P=100_000, threads=8):
+    """'additionally a reduced c3-shaped run (e.g. 100k Gaussians @1080p, C=32) if it completes in < 10 min,
+    otherwise state "did not complete"' - the PyTorch-CPU autograd restatement, one forward+backward (`--cpu-reduced-c3`;
+    minutes of host time, so not part of the default run: the default line quotes the committed result)."""
+    import torch
+    from oracle import torch_oracle
+    from synth import CONFIGS, make_scene
+    kw = dict(CONFIGS["c3"])
+    kw["P"] = P
+    sc = make_scene(seed=0, **kw)
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    try:
+        torch_oracle.forward_backward(sc, dtype=torch.float32)
+        dt = time.perf_counter() - t0
+        status = "completed"
+    except Exception as exc:      # noqa: BLE001
+        dt, status = time.perf_counter() - t0, f"failed: {exc!r}"
+    finally:
+        torch.set_num_threads(old)
+    mpix = kw["width"] * kw["height"] / 1e6
+    return {"config": f"c3 reduced: {P} Gaussians, {kw['width']}x{kw['height']}, SH degree 3, feat_dim={kw['C']}", "status": status,
+            "seconds": dt, "mpix_s": mpix / dt if status == "completed" else None, "threads": threads,
+            "did_not_complete_in_10_min": dt > 600.0}
+
+
+def _committed(name_candidates):
+    for name in name_candidates:
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            try:
+                return name, json.load(open(f))
+            except Exception:      # noqa: BLE001
+                pass
+    return None, None
 
 
 def make_step(scene, dev, pool=4, dist=None, overlap=True):
@@ -432,6 +474,8 @@ def main():
     ap.add_argument("--comm-only", action="store_true", help="time only the gradient exchange of the config (N > 1)")
     ap.add_argument("--no-overlap", action="store_true", help="exchange all gradients after the backward pass")
     ap.add_argument("--feat-dim", type=int, default=None, help="override the config's feature dim (development)")
+    ap.add_argument("--cpu-reduced-c3", action="store_true",
+                    help="only run the reduced c3-shaped PyTorch-CPU leg of SURVEY.md 8(d) (100k Gaussians @1080p, C=32; minutes) and print it")
     ap.add_argument("--views-per-iter", type=int, default=0,
                     help="V views of the same Gaussians per step over all GPUs (V / N per rank, pipelined over two streams, "
                          "gradients accumulated across the views): total work is fixed as N grows - the line says scaling: strong")
@@ -442,6 +486,9 @@ def main():
                          "densify.densify_and_prune between the timed iterations (N and the state buffers change)")
     args = ap.parse_args()
 
+    if args.cpu_reduced_c3:
+        print(json.dumps(cpu_reference_path_c3_reduced()), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "0"))
     if world == 0 and args.gpus > 1:
         import torch
@@ -632,7 +679,7 @@ def main():
             dom_ms = stage_ms.get(kernel_stage[dom], float("nan"))
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
         profiled = None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
             f = os.path.join(ROOT, "profiles", name)
             if os.path.exists(f):
                 try:
@@ -645,7 +692,7 @@ def main():
         # VALU-issue fraction of both blend kernels from the committed SQ counters (same caveat: a separate run)
         sq_names = {"render_bwd": "render_backward", "render_fwd": "render_forward", "preprocess": "preprocess_kernel",
                     "preprocess_bwd": "preprocess_backward_kernel"}
-        for sqf in ("r03_pmc_sq_counters.json", "r02_pmc_sq_counters.json"):
+        for sqf in ("r04_pmc_sq_counters.json", "r03_pmc_sq_counters.json", "r02_pmc_sq_counters.json"):
             f = os.path.join(ROOT, "profiles", sqf)
             if profiled is None or not os.path.exists(f):
                 continue
@@ -689,15 +736,23 @@ def main():
                         "ms_per_step_without_events": 1e3 * el_plain / args.steps,
                         "ms_per_step_with_all_stage_events": 1e3 * el_stages / args.steps},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable_6290": achieved / HBM_ACHIEVABLE_GBS,
+                         # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE with
+                         # the guide's corrections, tools/pmc_summary.py) of this config: counters cannot be read in-process
+                         "traffic": (profiled or {}).get(dom) if args.config == "c3" and not V else None,
+                         "traffic_source": (profiled or {}).get("source") if args.config == "c3" and not V else None,
                          "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": dom_ms,
                          "kernel_ms_source": "HIP events around the kernel on the op's stream, inside the timed region",
                          "note": "HBM is the roofline the contract names for this path; the kernel itself is bound by "
                                  "VALU issue and by the fp32 global-atomic rate (DESIGN.md 3.5, profiles/): see `profiled`"},
             "profiled": profiled,
-            "roofline_whole_step": {"algorithmic_bytes": alg["total"],
+            "roofline_whole_step": {"algorithmic_bytes": alg["total"], "algorithmic_bytes_min": alg["total_min"],
                                     "achieved": alg["total"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
-                                    "frac": alg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                    "frac": alg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "frac_of_achievable_6290": alg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS,
+                                    "frac_A_min": alg["total_min"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "A = SURVEY.md 8(d) algorithmic bytes of the REFERENCE's algorithm (152 B per instance of sort "
+                                            "traffic this design does not move); A_min = the same with perfect cross-tile reuse"},
             "dp_breakdown": dp_breakdown,
             "views_breakdown": views_breakdown,
             "stage_ms": stage_ms,
@@ -706,6 +761,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_kw)
             out["cpu_reference_path_c1"] = cpu_reference_path_c1(dev)
+            nm, red = _committed(("r04_cpu_c3_reduced.json",))
+            out["cpu_reference_path_c3_reduced"] = ({"source": f"profiles/{nm} (bench.py --cpu-reduced-c3 on a GPU box's host; minutes of "
+                                                               f"host time, not re-run here)", **red} if red else
+                                                    {"status": "not measured in this tree: run bench.py --cpu-reduced-c3"})
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

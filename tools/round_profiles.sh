@@ -1,17 +1,28 @@
 #!/bin/bash
 # GPU box: collect everything that goes under profiles/ for one round (run through gpurun; output in gpurun_out/<tag>).
-#   tools/round_profiles.sh r02
-TAG=${1:-r03}
+#   tools/round_profiles.sh r04 [quick]
+TAG=${1:-r04}
+QUICK=${2:-}
 export TMPDIR=/tmp
 ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 # 1. bench lines: c3 full (driver contract), the other BASELINE configs single-GPU
 timeout 300 python bench.py > $OUT/${TAG}_bench_c3.json 2> $OUT/bench_c3.err
 for c in c1 c2 c4 c5; do timeout 200 python bench.py --config $c --no-cpu-baseline --steps 20 --warmup 5 > $OUT/${TAG}_bench_$c.json 2> $OUT/bench_$c.err; done
-# 1b. the north-star-literal configuration (no matrix pipe anywhere) and config c5 with densification on
+# 1b. the north-star-literal configuration (no matrix pipe anywhere), config c5 with densification on, several views per GPU
 timeout 200 python bench.py --no-cpu-baseline --valu > $OUT/${TAG}_bench_c3_valu.json 2> $OUT/bench_c3_valu.err
 timeout 300 python bench.py --config c5 --densify-every 5 --steps 40 --warmup 10 > $OUT/${TAG}_bench_c5_densify.json 2> $OUT/bench_c5_densify.err
+timeout 300 python bench.py --config c4 --views-per-iter 8 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_c4_8views.json 2> $OUT/bench_c4_8views.err
+timeout 300 python bench.py --config c3 --views-per-iter 8 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_c3_8views.json 2> $OUT/bench_c3_8views.err
 timeout 200 python tools/adam_bench.py > $OUT/${TAG}_adam.txt 2>&1
 timeout 200 python tools/adam_bench.py 5000000 128 >> $OUT/${TAG}_adam.txt 2>&1
+timeout 200 python tools/feature_loss_bench.py > $OUT/${TAG}_feature_loss.txt 2>&1
+python tools/kernel_resources.py > $OUT/${TAG}_kernel_resources.txt 2>&1
+if [ -z "$QUICK" ]; then
+# 1c. SURVEY 8(d): the reduced c3-shaped PyTorch-CPU run (minutes of host time)
+timeout 700 python bench.py --cpu-reduced-c3 > $OUT/${TAG}_cpu_c3_reduced.json 2> $OUT/cpu_c3_reduced.err || echo '{"status": "did not complete in 10 min", "did_not_complete_in_10_min": true}' > $OUT/${TAG}_cpu_c3_reduced.json
+# 1d. the parity numbers the three-way comparison prints (flips, adjudication counts, the reference's two builds against each other)
+timeout 600 python -m pytest tests/test_gpu_vs_ref.py -q -s -k "full_size or eight_views" 2>&1 | grep -E "^(c[2-5] |c4 view|c4 x|[0-9]+ passed)" > $OUT/${TAG}_parity_adjudication.txt
+fi
 # 2. kernel trace of the SAME command as the bench (rocprofv3 --kernel-trace --stats)
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python $ROOT/bench.py --no-cpu-baseline > $OUT/kt_bench.json 2> $OUT/kt.err
