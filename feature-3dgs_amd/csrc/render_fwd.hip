@@ -272,8 +272,13 @@ static_assert(sizeof(FwdEntry) == 48, "FwdEntry layout");
 template <int CH, int CHK>
 struct FwdChunkMF {
     FwdEntry ent[CHK];
-    static constexpr int FT = (CHK * CH > 32 * 65) ? CHK * CH : 32 * 65;
-    float feat[FT];        // row-major [instance][channel]; reused as the epilogue transpose tile [channel][65]
+    // epilogue transpose tile: [channel][65] for all 64 pixels at once.  ([channel][33], one half of the pixels at a time,
+    // would cut the wave's LDS from 9.6 to 5.6 KB - and a fifth wave per SIMD fits the registers with 3-4 spilled - but the
+    // half-width output stores cost more than the occupancy buys: c3 forward 0.363 -> 0.378 ms at four waves, 0.377 at five;
+    // the code path stays for the record, TS = 33 selects it.)
+    static constexpr int TS = 65;
+    static constexpr int FT = (CHK * CH > 32 * TS) ? CHK * CH : 32 * TS;
+    float feat[FT];        // row-major [instance][channel]; reused as the epilogue transpose tile
 };
 
 // The next chunk's ids and splat records are prefetched into registers while the current chunk is blended.
@@ -361,12 +366,13 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     // software pipeline: the splat records of chunk k+1 and the list ids of chunk k+2 are requested while chunk k
     // is blended, so neither of the two dependent gathers (id, then record) is ever waited for on the spot
     uint32_t n_id = 0, f_id = 0;
-    float4 n_q0 = make_float4(0, 0, 0, 0), n_q1 = n_q0, n_q2 = n_q0;
+    float4 n_q0 = make_float4(0, 0, 0, 0), n_q1 = n_q0;
+    float2 n_q2 = make_float2(0, 0);          // blue, depth (the radius half of q2 is not needed here)
     if (lane < CHK && r_lo + lane < r_hi) n_id = a.point_list[r_lo + lane];
     if (lane < CHK && r_lo + CHK + lane < r_hi) f_id = a.point_list[r_lo + CHK + lane];
     if (lane < CHK && r_lo + lane < r_hi) {
         const SplatRec* rp = a.rec + n_id;
-        n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
+        n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = *reinterpret_cast<const float2*>(&rp->q2);
     }
 
     for (uint32_t base = r_lo; base < r_hi; base += CHK) {
@@ -395,7 +401,7 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
         n_id = f_id;
         if (lane < CHK && base + CHK + lane < r_hi) {
             const SplatRec* rp = a.rec + n_id;
-            n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = rp->q2;
+            n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = *reinterpret_cast<const float2*>(&rp->q2);
         }
         if (lane < CHK && base + 2 * CHK + lane < r_hi) f_id = a.point_list[base + 2 * CHK + lane];
 
@@ -552,33 +558,40 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
             a.out_depth[pid] = dep[p];
         }
         // D[i][n]: lane holds column n = lane & 31 (channel), register r holds row i = (r&3) + 8(r>>2) + 4(lane>>5)
-        // (pixel 32h + i of this slot).  Transpose through LDS ([channel][65]) so that lanes are pixels again.
+        // (pixel 32h + i of this slot).  Transpose through LDS so that lanes are pixels again: [channel][65] in one go, or
+        // (TS = 33) one half of the pixels at a time - the lanes of half h then write their own pixels.
+        constexpr int TS = FwdChunkMF<CH, CHK>::TS;
+        constexpr int NH = TS == 33 ? 2 : 1;          // transpose rounds per column block
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int h = 0; h < 2; h++)
+            for (int hr = 0; hr < NH; hr++) {
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int i = 32 * h + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    ck.feat[(lane & 31) * 65 + i] = acc[p][h][nb][r];
-                }
-            __builtin_amdgcn_wave_barrier();
-            if (inside[p]) {
+                for (int h = (NH == 2 ? hr : 0); h < (NH == 2 ? hr + 1 : 2); h++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int i = (NH == 2 ? 0 : 32 * h) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        ck.feat[(lane & 31) * TS + i] = acc[p][h][nb][r];
+                    }
+                __builtin_amdgcn_wave_barrier();
+                const int col = NH == 2 ? (lane & 31) : lane;
+                if (inside[p] && (NH == 1 || (lane >> 5) == hr)) {
 #pragma unroll 8
-                for (int n = 0; n < (CH < 32 ? CH : 32); n++)
-                    if (32 * nb + n < a.nc)
-                        a.out_feat[(size_t)(a.c0 + 32 * nb + n) * HW + (size_t)pix_id[p]] = ck.feat[n * 65 + lane];
-                if constexpr (CDB) {
-                    if (a.write_base) {      // columns 16..19 of the contraction: red, green, blue, depth
-                        const size_t pid = (size_t)pix_id[p];
-                        const float Tf = fabsf(T[p]);
-                        a.final_T[pid] = Tf;
-                        a.n_contrib[pid] = last[p];
-                        a.out_color[pid] = ck.feat[16 * 65 + lane] + Tf * a.bg[0];
-                        a.out_color[HW + pid] = ck.feat[17 * 65 + lane] + Tf * a.bg[1];
-                        a.out_color[2 * HW + pid] = ck.feat[18 * 65 + lane] + Tf * a.bg[2];
-                        a.out_depth[pid] = ck.feat[19 * 65 + lane];
+                    for (int n = 0; n < (CH < 32 ? CH : 32); n++)
+                        if (32 * nb + n < a.nc)
+                            a.out_feat[(size_t)(a.c0 + 32 * nb + n) * HW + (size_t)pix_id[p]] = ck.feat[n * TS + col];
+                    if constexpr (CDB) {
+                        if (a.write_base) {      // columns 16..19 of the contraction: red, green, blue, depth
+                            const size_t pid = (size_t)pix_id[p];
+                            const float Tf = fabsf(T[p]);
+                            a.final_T[pid] = Tf;
+                            a.n_contrib[pid] = last[p];
+                            a.out_color[pid] = ck.feat[16 * TS + col] + Tf * a.bg[0];
+                            a.out_color[HW + pid] = ck.feat[17 * TS + col] + Tf * a.bg[1];
+                            a.out_color[2 * HW + pid] = ck.feat[18 * TS + col] + Tf * a.bg[2];
+                            a.out_depth[pid] = ck.feat[19 * TS + col];
+                        }
                     }
                 }
             }
