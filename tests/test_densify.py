@@ -105,7 +105,16 @@ def _assert_same(a, b, exact=True, loose=()):
 
 @pytest.fixture(scope="module")
 def RefModel():
-    return ru.load_reference_gaussian_model()
+    cls = ru.load_reference_gaussian_model()
+    # First use of torch's multi-tensor Adam in a fresh process: run it once on throw-away models before anything is compared.
+    # (Seen once in round 4: this file's first test - two models built by the SAME torch.optim.Adam calls, compared before any
+    # product code had run - differed in `f_rest` on a cold GPU box; never again in later runs of the same tree.  The
+    # comparison below is between the reference's method and the product's, not a test of torch's determinism.)
+    tensors, stats = _tensors(2000, 4, seed=1)
+    _model(cls, tensors, stats, torch.optim.Adam)
+    _model(cls, tensors, stats, torch.optim.Adam)
+    torch.cuda.synchronize()
+    return cls
 
 
 CASES = [  # P, C, max_grad, min_opacity, extent, max_screen_size

@@ -309,7 +309,8 @@ def test_forward_backward_vs_reference(case, record_property):
     print(case["id"], st)
 
 
-@pytest.mark.parametrize("seed,P,W,H,C", [(1, 5000, 256, 256, 16), (2, 20000, 320, 200, 32), (3, 3000, 97, 61, 128)])
+@pytest.mark.parametrize("seed,P,W,H,C", [(1, 5000, 256, 256, 16), (2, 20000, 320, 200, 32), (3, 3000, 97, 61, 128),
+                                          (4, 1200, 128, 96, 16), (5, 10000, 256, 256, 3)])     # (4), (5): both sorts in one launch each
 def test_instance_lists_match_reference_bit_for_bit(seed, P, W, H, C, option):
     """With the product's tile culling off, its private sorted instance list and tile ranges are the
     reference's (`rasterizer_impl.cu:291-327`: hipCUB radix sort on (tile | depth) keys), bit for bit."""
