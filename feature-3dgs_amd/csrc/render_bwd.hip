@@ -186,9 +186,23 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
     F3DGS_PHASE_BEGIN();
 
     // the PARTS waves of one tile are scheduled back to back (L2 reuse of the tile's splat records)
-    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t tile = wg / PARTS;
-    const int part = wg % PARTS;
+    // a.order (option bwd_order): every XCD takes ITS contiguous run of tiles longest walk first (tile_order_kernel: the k-th
+    // tile of XCD x sits at order[8 k + x]); workgroup b runs on XCD b % 8, the j-th workgroup of an XCD is part j % 4 of its
+    // tile j / 4.  The grid is padded to 8 x 4 x ceil(tiles / 8): slots past an XCD's run have nothing to do.
+    uint32_t tile;
+    int part;
+    if (a.order) {
+        const uint32_t tiles = (uint32_t)(a.gx * a.gy);
+        const uint32_t xcd = blockIdx.x % 8u, j = blockIdx.x / 8u, k = j / PARTS;
+        const uint32_t mine = tiles / 8u + (xcd < tiles % 8u ? 1u : 0u);
+        if (k >= mine) return;
+        tile = a.order[8u * k + xcd];
+        part = (int)(j % PARTS);
+    } else {
+        const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+        tile = wg / PARTS;
+        part = (int)(wg % PARTS);
+    }
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 rg = a.ranges[tile];
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
@@ -649,7 +663,8 @@ template <int CH, bool MF>
 void launch_one(const BwdArgs& a, hipStream_t s) {
     constexpr int NPIX = 64;
     const size_t lds = a.half ? sizeof(BwdLds<CH, NPIX, MF, true>) : sizeof(BwdLds<CH, NPIX, MF, false>);
-    const dim3 grid(a.gx * a.gy * (256 / NPIX));
+    const int tiles = a.gx * a.gy;
+    const dim3 grid(a.order ? 8 * (256 / NPIX) * ((tiles + 7) / 8) : tiles * (256 / NPIX));
     // later channel windows skip the geometric half of the work
     if (a.half) {        // chunks of 32 instances against two pixel halves (default)
         if constexpr (CH <= 32) {
@@ -725,6 +740,13 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     }
     a.half = opt.bwd_half != 0;
     const bool mf = opt.feature_mfma != 0;
+    // longest walks first, as in the pixel-lane kernel: the launch is ~10 rounds of single-wave workgroups whose lifetimes
+    // differ by an order of magnitude (the order is built once per call, every channel window uses it)
+    // (c2: 0.677 -> 0.660 ms including the order launch; below ~1000 tiles the launch costs more than the tail it removes)
+    if (opt.bwd_order && tile_len && tile_order && (size_t)vp.gx * vp.gy >= 1024) {
+        launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, s);
+        a.order = tile_order;
+    }
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
         launch_one<0, false>(a, s);
