@@ -167,7 +167,8 @@ struct Options {
     int feature_mfma;    // 1: feature contraction on the matrix pipe where a kernel variant exists (default)
     int profile;         // 1: record per-stage HIP events (f3dgs_profile_read)
     int bwd_half;        // instance-lane blend backward: chunks of 32 instances against two pixel halves (default 1); 0: 64-lane chunks
-    int bwd_order;       // pixel-lane blend backward: workgroups take the tiles longest walk first (default 1)
+    int bwd_order;       // blend backward: workgroups take the tiles longest walk first (default 1)
+    int bwd_m44;         // pixel-lane blend backward: the colour / depth sums on 4 x 4 matrix blocks (default 1)
     int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 16; needs feature_mfma
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
     int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)

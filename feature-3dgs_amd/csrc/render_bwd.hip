@@ -286,7 +286,7 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
     }
     __builtin_amdgcn_wave_barrier();
     F3DGS_PHASE_END(cyc_stage);
-    const float ddelx_dx = uniform_f(0.5f * a.W), ddely_dy = uniform_f(0.5f * a.H);
+    // (the pixel scales 0.5 W, 0.5 H of dL/dmean2D are formed where the flush uses them, see sgpr_opaque)
 
     // ---- one (compacted) chunk of up to 64 splats against all live pixels of the wave ---------------------
     auto process = [&](const SplatLane& sl_in, const uint32_t gid_in, const uint32_t pos_min, const int n_inst) {
@@ -492,8 +492,8 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
             // (sl.ca.. are the staged, pre-scaled conic: undo the scale here, once per chunk)
             const float ca = sl.ca * CONIC_UNSCALE_AC, cb = sl.cb * CONIC_UNSCALE_B, cc = sl.cc * CONIC_UNSCALE_AC;
             const float m1 = acc[0], m2 = acc[1];
-            acc[0] = -ddelx_dx * fmaf(ca, m1, cb * m2);
-            acc[1] = -ddely_dy * fmaf(cc, m2, cb * m1);
+            acc[0] = -(0.5f * (float)sgpr_opaque(a.W)) * fmaf(ca, m1, cb * m2);
+            acc[1] = -(0.5f * (float)sgpr_opaque(a.H)) * fmaf(cc, m2, cb * m1);
             acc[5] *= __builtin_amdgcn_rcpf(sl.op);      // touched => alpha >= 1/255 somewhere => op > 0
             acc[2] *= -0.5f; acc[3] *= -0.5f; acc[4] *= -0.5f;
         }
@@ -556,8 +556,7 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
     // ---- walk the list back to front in windows of 64 positions; splats whose 1/255 footprint misses this
     // wave's pixel block are dropped (rect_hit, exact-safe) and the survivors of consecutive windows are packed
     // into full 64-lane chunks with ds_permute (lane 0 = farthest back stays true across windows) ----------------
-    const float wx0 = uniform_f((float)px0), wx1 = uniform_f((float)(px0 + PW - 1));
-    const float wy0 = uniform_f((float)py0), wy1 = uniform_f((float)(py0 + NPIX / PW - 1));
+
     SplatLane cur;
     cur.mx = cur.my = cur.ca = cur.cb = cur.cc = cur.op = cur.cr = cur.cg = cur.cbl = cur.dep = 0.f;
     cur.pos = 0; cur.have = false;
@@ -595,7 +594,9 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
         ngid = fgid;
         load_recs(k0 - 64, ngid, nf, nhave);
         fgid = load_ids(k0 - 128);
-        const bool hit = have && rect_hit(f[0], f[1], f[2], f[3], f[4], f[5], wx0, wx1, wy0, wy1);
+        // the wave's pixel rectangle, converted here from its scalar integers (sgpr_opaque)
+        const float wx0 = (float)sgpr_opaque(px0), wy0 = (float)sgpr_opaque(py0);
+        const bool hit = have && rect_hit(f[0], f[1], f[2], f[3], f[4], f[5], wx0, wx0 + (float)(PW - 1), wy0, wy0 + (float)(NPIX / PW - 1));
         const unsigned long long hmask = __ballot(hit);
         const int c2 = __popcll(hmask);
         if (c2 == 0) continue;
@@ -721,6 +722,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
             a.order = tile_order;
         }
         a.half = 0;
+        a.m44 = opt.bwd_m44;
         launch_render_backward_pl(a, C, s);
 #ifdef F3DGS_DEV
         if (a.dev & 8) {

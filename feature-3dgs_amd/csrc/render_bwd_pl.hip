@@ -105,7 +105,8 @@ static_assert(PL_STAGE_PLANES * PL_SP * 4 <= sizeof(PlShared), "staging image fi
 //              channels 0-15, 16-31, colour/depth, moments.
 // GEO = false: a later channel window of up to 64 channels: sixteen per wave.
 // P1_NE / P1_PREF: entries per phase-1 group, records of the next group prefetched.
-template <bool GEO, int P1_NE, bool P1_PREF>
+// M44: the colour wave of the first window contracts on sixteen 4 x 4 blocks (v_mfma_f32_4x4x1_16B_f32).
+template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false>
 __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     PlShared& L = *reinterpret_cast<PlShared*>(smem);
@@ -214,7 +215,20 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 mine = (q >> 1) == rd;
                 plane = 16 * (q & 1) + col;
             }
-            if (GEO && q == 3) {
+            if (GEO && M44 && q == 2) {
+                // the colour wave on sixteen 4 x 4 blocks (v_mfma_f32_4x4x1_16B_f32): lane = (block, i) with block = (entry group
+                // rg = block & 3, pixel class kc = block >> 2) and i = its row in A / its COLUMN in B (dL/dR, dL/dG, dL/dB,
+                // dL/ddepth).  A step (pixel block 4 t + kc of a quadrant tile, column m) contracts pixel (kc + 4 (m & 1),
+                // 2 t + (m >> 1)) of the quadrant: Bop[qd][4 t + m] holds column i of the operand at that pixel.
+                const int kc4 = lane >> 4, i4 = lane & 3;
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++)
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const int px = (qd & 1) * 8 + kc4 + 4 * (t & 1), py = (qd >> 1) * 8 + 2 * (t >> 2) + ((t >> 1) & 1);
+                        Bop[qd][t] = stage[(32 + i4) * PL_SP + py * 16 + px];
+                    }
+            } else if (GEO && q == 3) {
                 // the moment wave: monomials of the pixel offset from the QUADRANT centre (the moments of each quadrant are kept
                 // apart and re-centred on the splat mean one by one: |u|, |v| <= 3.5), columns 0..5: 1, u, v, u^2, uv, v^2 - the
                 // same operand for the four quadrants, evaluated as one polynomial with per-lane one-hot coefficients
@@ -240,6 +254,9 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     }
     PL_STAGE_MARK(2);
     float S = T * (a.bg[0] * dR + a.bg[1] * dG + a.bg[2] * dB);
+    // wave-uniform floats of the flush come in as kernel arguments (scalar registers): computed here, on the vector pipe, they would
+    // occupy vector registers across the whole walk
+    const float neg_half_w = a.neg_half_w, neg_half_h = a.neg_half_h;
     const float pxf = (float)(tx0 + qx + lx), pyf = (float)(ty0 + qy + ly);
     const uint32_t my_max = wave_max_u32(last);
     // does this wave hold a column block at all?
@@ -262,7 +279,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
         if (!PL_DEV_SKIP(32)) PL_PHASE_END(0);
 
     // ---- record loader (waves 0..2: one 16-byte third of every record; lane = entry, entry 0 = farthest back) -------
-    auto win_pos = [&](int w) -> uint32_t { return (uint32_t)(w * PL_WIN + PL_WIN - 1 - lane); };
+    auto win_pos = [&](int w) -> uint32_t { return (uint32_t)(w * PL_WIN + PL_WIN - 1 - fresh_lane()); };
     auto load_id = [&](int w) -> uint32_t {
         const uint32_t pos = win_pos(w);
         return (w >= 0 && q < 3 && pos < tile_max) ? a.point_list[r_lo + pos] : 0u;
@@ -403,7 +420,44 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 
             // ---- phase 2: this wave's sixteen columns of every sum of the chunk
             const uint32_t tt = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.touched[parity]);
-            if (active && (tt & 0xFFFFu) != 0) {
+            if (GEO && M44 && q == 2 && (tt & 0xFFFFu) != 0) {
+                // ---- colour wave, 4 x 4 blocks: 8 matrix-pipe cycles per step of 16 entries x 4 pixels x 4 columns instead of 32 for a
+                // 16-column step of which 4 are used (c3: 0.645 -> 0.630 ms; the moment wave - 6 columns, two blocks, 128
+                // instructions per chunk - was measured too and is slower in this form: 0.71 ms)
+                const int lane2 = fresh_lane();
+                const int i4 = lane2 & 3, rg = (lane2 >> 2) & 3, kc4 = lane2 >> 4;
+                const int row = 4 * rg + i4;
+                const float* abase = &L.wt[0][0];
+                f32x4 accA = f32x4{0.f, 0.f, 0.f, 0.f}, accB = accA;
+                // (pixel block 4 t + kc: the swizzle term (pb & 7) = (4 t + kc) & 7 alternates between kc and kc + 4 with t)
+                const int ofs_e = (kc4 * PL_ROW + 4 * (row ^ kc4)), ofs_o = ((4 + kc4) * PL_ROW + 4 * (row ^ (4 + kc4)));
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    if ((tt >> (16 + qd)) & 1u) {
+#pragma unroll
+                        for (int th = 0; th < 2; th++) {      // pixel blocks 4 t + kc, t = 2 th, 2 th + 1: two tile-row reads in flight
+                            const float4 av0 = *reinterpret_cast<const float4*>(abase + qd * PL_TILE + ofs_e + th * 8 * PL_ROW);
+                            const float4 av1 = *reinterpret_cast<const float4*>(abase + qd * PL_TILE + ofs_o + th * 8 * PL_ROW);
+                            accA = __builtin_amdgcn_mfma_f32_4x4x1f32(av0.x, Bop[qd][8 * th + 0], accA, 0, 0, 0);
+                            accB = __builtin_amdgcn_mfma_f32_4x4x1f32(av0.y, Bop[qd][8 * th + 1], accB, 0, 0, 0);
+                            accA = __builtin_amdgcn_mfma_f32_4x4x1f32(av0.z, Bop[qd][8 * th + 2], accA, 0, 0, 0);
+                            accB = __builtin_amdgcn_mfma_f32_4x4x1f32(av0.w, Bop[qd][8 * th + 3], accB, 0, 0, 0);
+                            accA = __builtin_amdgcn_mfma_f32_4x4x1f32(av1.x, Bop[qd][8 * th + 4], accA, 0, 0, 0);
+                            accB = __builtin_amdgcn_mfma_f32_4x4x1f32(av1.y, Bop[qd][8 * th + 5], accB, 0, 0, 0);
+                            accA = __builtin_amdgcn_mfma_f32_4x4x1f32(av1.z, Bop[qd][8 * th + 6], accA, 0, 0, 0);
+                            accB = __builtin_amdgcn_mfma_f32_4x4x1f32(av1.w, Bop[qd][8 * th + 7], accB, 0, 0, 0);
+                        }
+                    }
+                }
+                // the four pixel classes hold partial sums of the same (entry, column): add them up (lanes 16 / 32 apart)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = accA[r] + accB[r];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (kc4 == 0) L.ftile[(4 * rg + r) * PL_FS + 32 + i4] = v;
+                }
+            } else if (active && (tt & 0xFFFFu) != 0) {
                 f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
                 const float* abase = (use_s ? &L.st[0][0] : &L.wt[0][0]);
                 const int lane2 = fresh_lane();
@@ -478,8 +532,8 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                             const float ca = i0.z * CONIC_UNSCALE_AC, cb = i0.w * CONIC_UNSCALE_B, cc = i1.x * CONIC_UNSCALE_AC;
                             // dG/ddelx = -G (a dx + b dy),  dG/da = -G dx^2 / 2, ...;  dL/dopacity = sum G dL/dalpha = M0 / op
                             float4 o0, o1;
-                            o0.x = -(0.5f * a.W) * fmaf(ca, m1, cb * m2);
-                            o0.y = -(0.5f * a.H) * fmaf(cc, m2, cb * m1);
+                            o0.x = neg_half_w * fmaf(ca, m1, cb * m2);
+                            o0.y = neg_half_h * fmaf(cc, m2, cb * m1);
                             o0.z = -0.5f * sxx; o0.w = -0.5f * sxy;
                             o1.x = -0.5f * syy;
                             o1.y = M0 * __builtin_amdgcn_rcpf(fmaxf(i1.y, 1e-30f));
@@ -526,9 +580,9 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 #endif
 }
 
-template <bool GEO, int P1_NE, bool P1_PREF>
+template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel(BwdArgs a) {
-    render_backward_pl_body<GEO, P1_NE, P1_PREF>(a);
+    render_backward_pl_body<GEO, P1_NE, P1_PREF, M44>(a);
 }
 
 // Tiles by descending walk length, XCD by XCD: workgroup b runs on XCD b % 8 (xcd_remap) and every XCD keeps its contiguous
@@ -581,6 +635,9 @@ void launch_pl(const BwdArgs& a, hipStream_t s) {
     if (variant == 4) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
     if (variant == 5) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 2, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
 #endif
+    if constexpr (GEO) {
+        if (a.m44) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
+    }
     hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a);
 }
 
@@ -592,6 +649,7 @@ void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, 
 
 // Channel windows: the first carries the geometric sums and up to 32 channels, later ones up to 64 channels.
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s) {
+    a.neg_half_w = -(0.5f * a.W); a.neg_half_h = -(0.5f * a.H);
     a.c0 = 0; a.nc = min(32, C); a.write_base = 1;
     launch_pl<true>(a, s);
     for (int c0 = 32; c0 < C; c0 += 64) {

@@ -53,13 +53,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// A wave-uniform float pinned to a scalar register: float arithmetic is vector-pipe work on this chip, so a uniform value
-// computed in float otherwise occupies a vector register for as long as it lives (and is the first thing spilled).
-// (inline assembly: the compiler folds the builtin away for a value it already knows to be uniform and keeps the vector register)
-__device__ __forceinline__ float uniform_f(float v) {
-    float s;
-    asm("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v));
-    return s;
+// Wave-uniform floats without a vector register: float arithmetic is vector-pipe work on this chip, so a uniform value computed in
+// float (a tile's pixel rectangle, the pixel scales) occupies a vector register for as long as it lives - across the whole list
+// walk - and is the first thing spilled.  The INTEGER it is made from lives in a scalar register; it is converted where it is
+// used, and this empty asm makes the integer opaque there so that the conversion is not hoisted back out of the loop.  (A
+// v_readfirstlane in inline asm was tried first: the compiler may place or duplicate such an asm where it likes and knows
+// nothing of the hazards of the instruction inside - correct in two kernels, wrong in a third.)
+__device__ __forceinline__ int sgpr_opaque(int x) {
+    asm volatile("" : "+s"(x));
+    return x;
 }
 
 // Exact-safe footprint test of one splat against a pixel-centre rectangle [x0, x1] x [y0, y1]: the splat can
@@ -102,7 +104,9 @@ struct BwdArgs {
     int C, c0, nc;
     int write_base;  // 1: also accumulate the 10 geometric sums (first channel window only)
     int half;         // instance-lane kernel: chunks of 32 instances, the two halves of the wave take different pixels
-    const uint32_t* order;   // pixel-lane kernel: workgroup -> tile, longest walk first (null: XCD-contiguous tile order)
+    const uint32_t* order;   // workgroup -> tile, longest walk first (null: XCD-contiguous tile order)
+    int m44;                 // pixel-lane kernel, first window: the colour wave on 4 x 4 matrix blocks
+    float neg_half_w, neg_half_h;   // pixel-lane kernel: -W / 2, -H / 2 (the NDC scale of dL/dmean2D, Q8)
 #ifdef F3DGS_DEV
     int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs, bit3 phase timing
     unsigned long long* dev_cycles;   // [0] staging, [1] window walk, [2] pixel trips, [3] flush, [4] waves

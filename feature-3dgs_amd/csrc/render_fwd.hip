@@ -318,12 +318,10 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x), r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
 
     // pixel-centre rectangle covered by this wave (PPL quadrants): used by the wave-level footprint test
-    float wx0, wx1, wy0, wy1;
-    {
-        const int q0 = wave * PPL, q1 = wave * PPL + PPL - 1;
-        wx0 = uniform_f((float)(tx * TILE + (q0 & 1) * 8)); wx1 = uniform_f((float)(tx * TILE + (q1 & 1) * 8 + 7));
-        wy0 = uniform_f((float)(ty * TILE + (q0 >> 1) * 8)); wy1 = uniform_f((float)(ty * TILE + (q1 >> 1) * 8 + 7));
-    }
+    // (kept as scalar integers; converted where the test runs, see sgpr_opaque)
+    const int q0_ = wave * PPL, q1_ = wave * PPL + PPL - 1;
+    const int iwx0 = tx * TILE + (q0_ & 1) * 8, iwx1 = tx * TILE + (q1_ & 1) * 8 + 7;
+    const int iwy0 = ty * TILE + (q0_ >> 1) * 8, iwy1 = ty * TILE + (q1_ >> 1) * 8 + 7;
     const int lx = lane & 7, ly = lane >> 3;
     float pxf[PPL], pyf[PPL];
     int pix_id[PPL];
@@ -382,7 +380,8 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
         if (!__any(anylive)) break;
         const int cnt_in = (int)min((uint32_t)CHK, r_hi - base);
         // wave-level culling: drop splats whose 1/255 footprint misses this wave's pixel block, compact the rest
-        const bool hit = lane < cnt_in && rect_hit(n_q0.x, n_q0.y, n_q0.z, n_q0.w, n_q1.x, n_q1.y, wx0, wx1, wy0, wy1);
+        const bool hit = lane < cnt_in && rect_hit(n_q0.x, n_q0.y, n_q0.z, n_q0.w, n_q1.x, n_q1.y, (float)sgpr_opaque(iwx0),
+                                                   (float)sgpr_opaque(iwx1), (float)sgpr_opaque(iwy0), (float)sgpr_opaque(iwy1));
         const unsigned long long hmask = __ballot(hit);
         const int cnt = __popcll(hmask);
         const int slot = __popcll(hmask & ((1ull << lane) - 1ull));

@@ -304,11 +304,12 @@ def test_pixel_lane_and_instance_lane_backward_agree(C, option):
         assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
 
 
-@pytest.mark.parametrize("name", ["fwd_solo", "fwd_wide", "bwd_order"])
+@pytest.mark.parametrize("name", ["fwd_solo", "fwd_wide", "bwd_order", "bwd_m44"])
 @pytest.mark.parametrize("C", [16, 32, 200])
 def test_scheduling_options_keep_the_results(name, C, option):
-    """Options fwd_solo (one workgroup per quadrant wave), fwd_wide (128-channel forward windows) and bwd_order (tiles longest
-    walk first in the pixel-lane backward) select between complete code paths that do the same arithmetic: the forward images
+    """Options fwd_solo (one workgroup per quadrant wave), fwd_wide (128-channel forward windows), bwd_order (tiles longest
+    walk first in the backward) and bwd_m44 (colour sums of the pixel-lane backward on 4 x 4 matrix blocks) select between
+    complete code paths that do the same arithmetic: the forward images
     are bit-identical with the option off, the gradients equal up to the order of their atomic sums."""
     from synth import make_scene
     sc = make_scene(P=30000, C=C, width=333, height=208, seed=31)
