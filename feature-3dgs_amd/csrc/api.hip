@@ -27,6 +27,7 @@ thread_local f3dgs_rows_fn g_rows_ready_fn = nullptr;
 thread_local void* g_rows_ready_ctx = nullptr;
 thread_local int g_rows_ready_chunks = 1;
 thread_local int g_feature_accumulate = 0;
+thread_local LowresGrad g_lowres;      // consumed by the next f3dgs_backward of this thread
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -301,6 +302,13 @@ void f3dgs_set_feature_grad_ready_callback(f3dgs_stage_fn fn, void* ctx) {
 
 void f3dgs_set_feature_grad_accumulate(int on) { g_feature_accumulate = on ? 1 : 0; }
 
+int f3dgs_set_feature_grad_lowres(const float* gx, int Hg, int Wg, const float* scale) {
+    if (!gx) { g_lowres = LowresGrad(); return F3DGS_OK; }
+    if (Hg <= 0 || Wg <= 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "bad low-resolution size %d x %d", Hg, Wg);
+    g_lowres.gx = gx; g_lowres.scale = scale; g_lowres.Hg = Hg; g_lowres.Wg = Wg;
+    return F3DGS_OK;
+}
+
 void f3dgs_set_grad_rows_ready_callback(f3dgs_rows_fn fn, void* ctx, int chunks) {
     g_rows_ready_fn = fn;
     g_rows_ready_ctx = ctx;
@@ -475,7 +483,17 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
         return fail(F3DGS_ERR_INVALID_ARGUMENT, "null state buffer");
     if (!radii) return fail(F3DGS_ERR_INVALID_ARGUMENT, "radii is required");
-    if (!dL_dpix || !dL_depths || (C > 0 && !dL_dfeaturepix)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null upstream grad");
+    const LowresGrad lowres = g_lowres;      // one call only, whatever happens below
+    g_lowres = LowresGrad();
+    if (lowres.gx) {
+        if (C == 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "a low-resolution feature-map gradient was set but C = 0");
+        if (lowres.Hg > height || lowres.Wg > width)
+            return fail(F3DGS_ERR_UNSUPPORTED, "low-resolution feature-map gradient %d x %d is larger than the image %d x %d: "
+                        "apply the transposed resize outside (f3dgs_feature_l1 with d_feature_map)", lowres.Hg, lowres.Wg, height, width);
+        if (!options().feature_mfma)
+            return fail(F3DGS_ERR_UNSUPPORTED, "the low-resolution feature-map gradient is taken by the pixel-lane backward (option feature_mfma = 1)");
+    }
+    if (!dL_dpix || !dL_depths || (C > 0 && !dL_dfeaturepix && !lowres.gx)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null upstream grad");
     if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || (C > 0 && !dL_dsemantic_feature))
         return fail(F3DGS_ERR_INVALID_ARGUMENT, "null output");
     if (M > 0 && shs && !dL_dsh) return fail(F3DGS_ERR_INVALID_ARGUMENT, "dL_dsh is null");
@@ -500,7 +518,8 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     tm.mark("zero");
     if (R > 0)
         launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,
-                               dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, img.tile_len, img.tile_order, s);
+                               dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, img.tile_len, img.tile_order,
+                               lowres.gx ? &lowres : nullptr, s);
     if ((rc = check_debug(debug, s, "render backward"))) return rc;
     tm.mark("render_bwd");
     if (g_feature_ready_fn) g_feature_ready_fn(g_feature_ready_ctx, stream);   // dL_dsemantic_feature is final on `s` here
@@ -537,7 +556,7 @@ int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float*
                      const float* bias, const float* gt, float* loss, float* d_feature_map, float* d_weight,
                      float* d_bias, void* scratch, void* stream) {
     if (C <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Hg <= 0 || Wg <= 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "bad sizes");
-    if (!feature_map || !gt || !loss || !d_feature_map || !scratch) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
+    if (!feature_map || !gt || !loss || !scratch) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null pointer");
     if ((weight == nullptr) != (bias == nullptr)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "weight and bias go together");
     if (weight) {
         if (!d_weight || !d_bias) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null decoder gradient");
@@ -550,6 +569,11 @@ int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float*
     HIP_TRY(launch_feature_l1(C, H, W, Cout, Hg, Wg, feature_map, weight, bias, gt, loss, d_feature_map, d_weight, d_bias,
                               static_cast<char*>(scratch), static_cast<hipStream_t>(stream)));
     return F3DGS_OK;
+}
+
+const float* f3dgs_feature_l1_lowres_grad(int C, int Cout, int Hg, int Wg, int has_decoder, void* scratch) {
+    if (C <= 0 || Cout <= 0 || Hg <= 0 || Wg <= 0 || !scratch) return nullptr;
+    return feature_l1_lowres_grad(static_cast<char*>(scratch), C, Cout, Hg, Wg, has_decoder != 0);
 }
 
 size_t f3dgs_feature_decode_scratch_bytes(int C, int Hg, int Wg, int has_decoder) {

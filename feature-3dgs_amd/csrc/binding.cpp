@@ -99,6 +99,12 @@ torch::Tensor& feature_grad_accumulator() {
     static torch::Tensor* t = new torch::Tensor();
     return *t;
 }
+// set_feature_grad_lowres: (gx (Hg,Wg,C), scale (0-dim) or undefined), consumed by the next backward call
+std::pair<torch::Tensor, torch::Tensor>& feature_grad_lowres() {
+    static std::pair<torch::Tensor, torch::Tensor> t;
+    return t;
+}
+
 struct AccumulateGuard {
     bool armed;
     explicit AccumulateGuard(bool on) : armed(on) { if (armed) f3dgs_set_feature_grad_accumulate(1); }
@@ -240,8 +246,29 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     auto bg = dev_f32(background, "bg"), m3 = dev_f32(means3D, "means3D"), col = dev_f32(colors, "colors_precomp"),
          sf = dev_f32(semantic_feature, "semantic_feature"), cov = dev_f32(cov3D_precomp, "cov3D_precomp"),
          vm = dev_f32(viewmatrix, "viewmatrix"), pm = dev_f32(projmatrix, "projmatrix"), cp = dev_f32(campos, "campos"),
-         gc = dev_f32(dL_dout_color, "dL_dout_color"), gf = dev_f32(dL_dout_feature, "dL_dout_feature"),
-         gd = dev_f32(dL_dout_depth, "dL_dout_depth");
+         gc = dev_f32(dL_dout_color, "dL_dout_color"), gd = dev_f32(dL_dout_depth, "dL_dout_depth");
+    // The feature-map gradient at the loss's resolution (feature_loss.py, lowres_grad=True): one call only.  What autograd hands
+    // over as dL_dout_feature is then the loss's placeholder - a zero-stride expansion of one 0, never materialised - unless
+    // another consumer of the feature map contributed a dense gradient, which the kernel adds.
+    std::pair<torch::Tensor, torch::Tensor> low;
+    std::swap(low, feature_grad_lowres());
+    const bool lowres = low.first.defined() && P > 0 && C > 0;
+    bool dense_feature_grad = true;
+    if (lowres) {
+        const auto& gx = low.first;
+        TORCH_CHECK(gx.is_cuda() && gx.device() == means3D.device() && gx.scalar_type() == torch::kFloat32 && gx.is_contiguous() &&
+                    gx.dim() == 3 && gx.size(2) == C, "low-resolution feature-map gradient must be a contiguous float32 (Hg, Wg, ", C,
+                    ") tensor on the op's device");
+        TORCH_CHECK(gx.numel() < (1ll << 31), "low-resolution feature-map gradient too large");
+        if (low.second.defined())
+            TORCH_CHECK(low.second.is_cuda() && low.second.scalar_type() == torch::kFloat32 && low.second.numel() == 1,
+                        "the scale of the low-resolution gradient must be a float32 scalar on the device");
+        bool all_zero_stride = dL_dout_feature.dim() > 0;
+        for (int64_t d = 0; d < dL_dout_feature.dim(); d++) all_zero_stride = all_zero_stride && dL_dout_feature.stride(d) == 0;
+        dense_feature_grad = !(dL_dout_feature.numel() == 0 || all_zero_stride);
+    }
+    auto gf = dense_feature_grad ? dev_f32(dL_dout_feature, "dL_dout_feature") : torch::Tensor();
+    auto gfptr = [&]() -> const float* { return dense_feature_grad ? fptr(gf) : nullptr; };
     TORCH_CHECK(radii.is_cuda() || P == 0, "radii must live on a HIP device");
     auto rad = radii.contiguous();
 
@@ -253,11 +280,15 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     FeatureCallbackGuard guard_cb(notify, &dL_dsemantic_feature);
     RowsCallbackCtx rows_ctx = {&dL_dsh, &dL_dmeans3D, &dL_dscales, &dL_drotations, &dL_dopacity, &dL_dcolors, &dL_dmeans2D, &dL_dcov3D};
     RowsCallbackGuard guard_rows(!grad_rows_hook().is_none() && P > 0, &rows_ctx, grad_rows_chunks());
+    if (lowres)
+        check_status(f3dgs_set_feature_grad_lowres(low.first.data_ptr<float>(), (int)low.first.size(0), (int)low.first.size(1),
+                                                   low.second.defined() ? low.second.data_ptr<float>() : nullptr),
+                     "set_feature_grad_lowres");
     rc = f3dgs_backward(
         P, degree, M, C, R, fptr(bg), W, H, fptr(m3), fptr(shs), fptr(col), fptr(sf), fptr(sc), scale_modifier, fptr(rot),
         fptr(cov), fptr(vm), fptr(pm), fptr(cp), tan_fovx, tan_fovy, P ? rad.data_ptr<int>() : nullptr,
         reinterpret_cast<const char*>(geomBuffer.data_ptr()), reinterpret_cast<const char*>(binningBuffer.data_ptr()),
-        reinterpret_cast<const char*>(imageBuffer.data_ptr()), fptr(gc), fptr(gf), fptr(gd),
+        reinterpret_cast<const char*>(imageBuffer.data_ptr()), fptr(gc), gfptr(), fptr(gd),
         P ? dL_dmeans2D.data_ptr<float>() : nullptr, nullptr, P ? dL_dopacity.data_ptr<float>() : nullptr,
         P ? dL_dcolors.data_ptr<float>() : nullptr, (P && C) ? dL_dsemantic_feature.data_ptr<float>() : nullptr,
         P ? dL_dmeans3D.data_ptr<float>() : nullptr, P ? dL_dcov3D.data_ptr<float>() : nullptr,
@@ -290,9 +321,11 @@ torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, tor
     return present;
 }
 
-// fused resize -> 1x1 decoder -> L1 (include/f3dgs.h: f3dgs_feature_l1); returns (loss, d_feature_map, d_weight, d_bias)
-std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
-FeatureL1(const torch::Tensor& feature_map, const torch::Tensor& gt, const torch::Tensor& weight, const torch::Tensor& bias) {
+// fused resize -> 1x1 decoder -> L1 (include/f3dgs.h: f3dgs_feature_l1); returns (loss, d_feature_map, d_weight, d_bias, gx).
+// dense = false: d_feature_map is not produced (empty); gx = dL/d(resized map), (Hg, Wg, C), a view of the call's scratch,
+// is what set_feature_grad_lowres hands to the rasterizer's backward.
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+FeatureL1(const torch::Tensor& feature_map, const torch::Tensor& gt, const torch::Tensor& weight, const torch::Tensor& bias, bool dense) {
     TORCH_CHECK(feature_map.is_cuda() && gt.is_cuda(), "feature_l1: tensors must live on a HIP device (no CPU path)");
     TORCH_CHECK(feature_map.dim() == 3 && gt.dim() == 3, "feature_l1: feature_map (C,H,W) and gt (Cout,Hg,Wg) expected");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(feature_map.device());
@@ -307,16 +340,20 @@ FeatureL1(const torch::Tensor& feature_map, const torch::Tensor& gt, const torch
     }
     const int C = fm.size(0), H = fm.size(1), W = fm.size(2), Cout = g.size(0), Hg = g.size(1), Wg = g.size(2);
     auto o = fm.options();
-    torch::Tensor loss = torch::empty({}, o), d_fm = torch::empty_like(fm);
+    torch::Tensor loss = torch::empty({}, o), d_fm = dense ? torch::empty_like(fm) : torch::empty({0}, o);
     torch::Tensor d_w = dec ? torch::empty_like(w) : torch::empty({0}, o), d_b = dec ? torch::empty_like(b) : torch::empty({0}, o);
     torch::Tensor scratch = torch::empty({(long long)f3dgs_feature_l1_scratch_bytes(C, Cout, Hg, Wg, dec ? 1 : 0)},
                                          o.dtype(torch::kByte));
     const int rc = f3dgs_feature_l1(C, H, W, Cout, Hg, Wg, fm.data_ptr<float>(), dec ? w.data_ptr<float>() : nullptr,
                                     dec ? b.data_ptr<float>() : nullptr, g.data_ptr<float>(), loss.data_ptr<float>(),
-                                    d_fm.data_ptr<float>(), dec ? d_w.data_ptr<float>() : nullptr,
+                                    dense ? d_fm.data_ptr<float>() : nullptr, dec ? d_w.data_ptr<float>() : nullptr,
                                     dec ? d_b.data_ptr<float>() : nullptr, scratch.data_ptr(), current_stream(fm));
     check_status(rc, "feature_l1");
-    return std::make_tuple(loss, d_fm, d_w, d_b);
+    const float* gxp = f3dgs_feature_l1_lowres_grad(C, Cout, Hg, Wg, dec ? 1 : 0, scratch.data_ptr());
+    TORCH_CHECK(gxp != nullptr, "feature_l1: no low-resolution gradient");
+    const int64_t off = reinterpret_cast<const char*>(gxp) - reinterpret_cast<const char*>(scratch.data_ptr());
+    torch::Tensor gx = scratch.slice(0, off, off + (int64_t)Hg * Wg * C * 4).view(torch::kFloat32).view({Hg, Wg, C});
+    return std::make_tuple(loss, d_fm, d_w, d_b, gx);
 }
 
 // forward-only resize -> 1x1 decoder (include/f3dgs.h: f3dgs_feature_decode); returns the (Cout, Hg, Wg) map, fp32 or fp16
@@ -448,7 +485,15 @@ PYBIND11_MODULE(_C, m) {
     m.def("rasterize_gaussians", &RasterizeGaussians);
     m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
     m.def("mark_visible", &markVisible);
-    m.def("feature_l1", &FeatureL1);
+    m.def("feature_l1", &FeatureL1, py::arg("feature_map"), py::arg("gt"), py::arg("weight"), py::arg("bias"), py::arg("dense") = true);
+    m.def("set_feature_grad_lowres", [](py::object gx, py::object scale) {
+              auto& h = feature_grad_lowres();
+              h.first = gx.is_none() ? torch::Tensor() : gx.cast<torch::Tensor>();
+              h.second = (gx.is_none() || scale.is_none()) ? torch::Tensor() : scale.cast<torch::Tensor>();
+          },
+          py::arg("gx"), py::arg("scale") = py::none(),
+          "gx (Hg, Wg, C) float32 = dL/d(resized feature map) as feature_l1 returns it, scale = 0-dim device tensor or None: the NEXT "
+          "rasterize_gaussians_backward call takes its feature-map gradient from there (transposed resize applied per tile); None clears");
     m.def("feature_decode", &FeatureDecode);
     m.def("adam_step", &AdamStep, py::arg("param"), py::arg("grad"), py::arg("exp_avg"), py::arg("exp_avg_sq"), py::arg("lr"),
           py::arg("beta1"), py::arg("beta2"), py::arg("eps"), py::arg("step"), py::arg("row_mask") = py::none());

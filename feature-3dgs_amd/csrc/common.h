@@ -244,6 +244,7 @@ void launch_radix_sort_keys_to_order(const uint32_t* keys, uint32_t* key_a, uint
 // feature_loss.hip
 size_t feature_l1_scratch_bytes(int C, int Cout, int Hg, int Wg, bool decoder);
 bool feature_l1_decoder_supported(int C);
+const float* feature_l1_lowres_grad(char* scratch, int C, int Cout, int Hg, int Wg, bool decoder);   // (Hg Wg, C) pixel-major
 hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
                              const float* bias, const float* gt, float* loss, float* d_feature_map, float* d_weight,
                              float* d_bias, char* scratch, hipStream_t s);
@@ -276,11 +277,20 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
                            const SplatRec* rec, const float* feat, float* final_T,
                            uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, uint32_t* tile_len,
                            hipStream_t s);
+// The feature-map gradient at the resolution of the loss (f3dgs_set_feature_grad_lowres): (Hg Wg, C) pixel-major; the blend
+// backward applies the transposed bilinear resize while it stages a tile.  `scale`: device scalar multiplied in, or null.
+struct LowresGrad {
+    const float* gx = nullptr;
+    const float* scale = nullptr;
+    int Hg = 0, Wg = 0;
+};
 // `tile_len` / `tile_order`: the pixel-lane kernel takes its tiles longest walk first (order built here, one small launch)
+// `dL_dfeat` may be null when `lowres` carries the feature-map gradient (given both, the kernel adds them)
 void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
                             const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                             const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
-                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, hipStream_t s);
+                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
+                            hipStream_t s);
 struct BwdArgs;
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s);     // render_bwd_pl.hip
 void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, hipStream_t s);

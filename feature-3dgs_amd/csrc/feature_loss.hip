@@ -21,26 +21,13 @@
 #include <hip/hip_fp16.h>
 
 #include "common.h"
+#include "resize_taps.h"
 
 namespace f3dgs {
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ResizeGeom {
-    int H, W, Hg, Wg;
-    float sy, sx;      // (in - 1) / (out - 1), 0 when out == 1 (PyTorch: area_pixel_compute_scale, align_corners)
-};
-
-// source taps of output index o (PyTorch upsample_bilinear2d, align_corners = true)
-__device__ __forceinline__ void taps(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
-    const float src = scale * (float)o;
-    i0 = (int)src;
-    i1 = i0 + (i0 < in - 1 ? 1 : 0);
-    l1 = src - (float)i0;
-    l0 = 1.0f - l1;
-}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -451,27 +438,8 @@ fl_resize_backward_kernel(ResizeGeom g, int C, const float* __restrict__ GX, flo
     __shared__ float s_wx[64][RB_MAXT];
     __shared__ int s_nx[64];
     const int x0 = blockIdx.x * 64, y = blockIdx.y, cb = blockIdx.z * 32;
-    // candidate outputs of a source index i: outputs o whose taps can include i
-    auto cand = [](int i, float scale, int out, int& lo, int& hi) {
-        if (scale <= 0.f) { lo = 0; hi = (i == 0) ? 0 : -1; return; }
-        lo = max(0, (int)floorf((float)(i - 1) / scale) - 1);
-        hi = min(out - 1, (int)ceilf((float)(i + 1) / scale) + 1);
-    };
-    // (output, weight) list of source index i along one axis; returns the count, or -1 when it exceeds the capacity
-    auto build = [&](int i, float scale, int in, int out, int* oo, float* ww) {
-        int lo, hi, n = 0;
-        cand(i, scale, out, lo, hi);
-        for (int o = lo; o <= hi; o++) {
-            int a0, a1;
-            float l0, l1;
-            taps(o, scale, in, a0, a1, l0, l1);
-            const float wv = (a0 == i ? l0 : 0.f) + (a1 == i ? l1 : 0.f);
-            if (wv == 0.f) continue;
-            if (n == RB_MAXT) return -1;
-            oo[n] = o; ww[n] = wv; n++;
-        }
-        return n;
-    };
+    auto cand = [](int i, float scale, int out, int& lo, int& hi) { resize_cand(i, scale, out, lo, hi); };
+    auto build = [](int i, float scale, int in, int out, int* oo, float* ww) { return resize_build<RB_MAXT>(i, scale, in, out, oo, ww); };
     int yo[RB_MAXT];
     float wy[RB_MAXT];
     const int ny = build(y, g.sy, g.H, g.Hg, yo, wy);           // uniform over the workgroup
@@ -629,6 +597,10 @@ size_t feature_l1_scratch_bytes(int C, int Cout, int Hg, int Wg, bool decoder) {
 
 bool feature_l1_decoder_supported(int C) { return C == 32 || C == 64 || C == 128; }
 
+const float* feature_l1_lowres_grad(char* scratch, int C, int Cout, int Hg, int Wg, bool decoder) {
+    return Scratch::carve(scratch, C, Cout, Hg * Wg, decoder, nullptr).GX;
+}
+
 size_t feature_decode_scratch_bytes(int C, int Hg, int Wg, bool decoder) {
     return decoder ? (((size_t)Hg * Wg * C * sizeof(float) + ALIGN - 1) & ~(ALIGN - 1)) : 0;
 }
@@ -648,10 +620,7 @@ static hipError_t run_decode(int N, int Cout, const float* X, const float* Wd, c
 hipError_t launch_feature_decode(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
                                  const float* bias, void* out, bool half, char* scratch, hipStream_t s) {
     const int N = Hg * Wg;
-    ResizeGeom g;
-    g.H = H; g.W = W; g.Hg = Hg; g.Wg = Wg;
-    g.sy = Hg > 1 ? (float)(H - 1) / (float)(Hg - 1) : 0.f;
-    g.sx = Wg > 1 ? (float)(W - 1) / (float)(Wg - 1) : 0.f;
+    const ResizeGeom g = make_resize_geom(H, W, Hg, Wg);
     const dim3 grid1((N + 63) / 64, (C + 31) / 32);
     if (!weight) {
         if (half) hipLaunchKernelGGL(fl_resize_out_kernel<true>, grid1, dim3(256), 0, s, g, C, feature_map, out);
@@ -672,10 +641,7 @@ hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, cons
     const bool decoder = weight != nullptr;
     const int N = Hg * Wg;
     const Scratch sc = Scratch::carve(scratch, C, Cout, N, decoder, nullptr);
-    ResizeGeom g;
-    g.H = H; g.W = W; g.Hg = Hg; g.Wg = Wg;
-    g.sy = Hg > 1 ? (float)(H - 1) / (float)(Hg - 1) : 0.f;
-    g.sx = Wg > 1 ? (float)(W - 1) / (float)(Wg - 1) : 0.f;
+    const ResizeGeom g = make_resize_geom(H, W, Hg, Wg);
     const float inv_n = 1.0f / ((float)N * (float)Cout);
     const dim3 grid1((N + 63) / 64, (C + 31) / 32);
     hipLaunchKernelGGL(fl_resize_kernel, grid1, dim3(256), 0, s, g, C, feature_map, sc.X, decoder ? nullptr : gt, inv_n,
@@ -688,8 +654,11 @@ hipError_t launch_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, cons
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(fl_sum_kernel, dim3(1), dim3(256), 0, s, sc.loss_partial, (int)sc.n_partial, loss);
-    hipLaunchKernelGGL(fl_resize_backward_kernel, dim3((W + 63) / 64, H, (C + 31) / 32), dim3(256), 0, s, g, C, sc.GX,
-                       d_feature_map);
+    // d_feature_map == nullptr: the caller hands the gradient at the loss's resolution (feature_l1_lowres_grad) to the blend
+    // backward, which applies the transposed resize while it stages its tiles (f3dgs_set_feature_grad_lowres)
+    if (d_feature_map)
+        hipLaunchKernelGGL(fl_resize_backward_kernel, dim3((W + 63) / 64, H, (C + 31) / 32), dim3(256), 0, s, g, C, sc.GX,
+                           d_feature_map);
     return hipGetLastError();
 }
 

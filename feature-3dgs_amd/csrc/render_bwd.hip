@@ -686,9 +686,17 @@ void launch_one(const BwdArgs& a, hipStream_t s) {
 void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
                             const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                             const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
-                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, hipStream_t s) {
+                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
+                            hipStream_t s) {
     BwdArgs a;
     a.order = nullptr;
+    a.glow = nullptr; a.gscale = nullptr; a.gHg = a.gWg = 0; a.gsy = a.gsx = 0.f;
+    const bool low = lowres && lowres->gx && C > 0;
+    if (low) {
+        a.glow = lowres->gx; a.gscale = lowres->scale; a.gHg = lowres->Hg; a.gWg = lowres->Wg;
+        a.gsy = lowres->Hg > 1 ? (float)(vp.H - 1) / (float)(lowres->Hg - 1) : 0.f;
+        a.gsx = lowres->Wg > 1 ? (float)(vp.W - 1) / (float)(lowres->Wg - 1) : 0.f;
+    }
     a.ranges = ranges; a.point_list = point_list; a.rec = rec;
     a.bg = vp.bg;
     a.final_T = final_T; a.n_contrib = n_contrib; a.dL_dpix = dL_dpix; a.dL_dfeat = dL_dfeat;
@@ -716,7 +724,8 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
 #endif
     // pixel-lane formulation (render_bwd_pl.hip): option bwd_pl = 1 always, 0 never, -1 (default) from 17 channels on - with
     // 16 or fewer one of its four matrix-pipe waves has no columns and the instance-lane kernel is a few per cent faster
-    if ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > 16)) && opt.feature_mfma) {
+    // (a low-resolution feature-map gradient is taken by the pixel-lane kernel only: the caller has checked feature_mfma)
+    if (low || ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > 16)) && opt.feature_mfma)) {
         if (opt.bwd_order && tile_len && tile_order) {
             launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, s);
             a.order = tile_order;

@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "render_common.h"
+#include "resize_taps.h"
 
 namespace f3dgs {
 
@@ -100,6 +101,8 @@ struct PlShared {
 };
 static_assert(sizeof(PlShared) * 4 <= 160 * 1024, "four workgroups per CU");
 static_assert(PL_STAGE_PLANES * PL_SP * 4 <= sizeof(PlShared), "staging image fits the aliased area");
+constexpr int PL_TAPS_OFS = PL_STAGE_PLANES * PL_SP * 4;      // bytes: tap lists of the tile's rows and columns (low-resolution gradient)
+static_assert(PL_TAPS_OFS + 32 * sizeof(float4) + 34 * sizeof(int) <= sizeof(PlShared), "tap lists fit behind the staging image");
 
 // GEO = true:  first channel window (up to 32 channels) + the ten geometric sums; column blocks of the waves: feature
 //              channels 0-15, 16-31, colour/depth, moments.
@@ -125,8 +128,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     const size_t HW = (size_t)a.W * a.H;
     const int tx0 = tx * TILE, ty0 = ty * TILE;
     const int qx = (q & 1) * 8, qy = (q >> 1) * 8;
-    const int lx = lane & 7, ly = lane >> 3;
-    const int col = lane & 15, kk = lane >> 4;
+    // (lane-derived indices are rebuilt where they are used - staging read-out, walk set-up - instead of living across the staging)
 
     // ---- staging: every plane of the tile with full-row requests -> LDS [plane][16 rows][16 px]; then the per-pixel state
     // (lane = pixel of quadrant q) and the wave's B operand (lane = (column col, K index kk)) are read out of it.
@@ -145,6 +147,9 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             // GEO: dL/dR, dL/dG, dL/dB, dL/ddepth, final_T, n_contrib;  otherwise: final_T, n_contrib
             const int npix = rd == 0 ? (GEO ? 6 : 2) : 0;
             if (rd > 0) __syncthreads();
+            // the thread index, rebuilt per round: what the requests below derive from it (plane, row, column of ten elements) is
+            // then recomputed in the second round instead of living in registers across the first round's read-out
+            const int tid = fresh_lane() + 64 * q;
             // all requests of a thread first (branch-free: a lane that has nothing to fetch reads a valid address and drops the
             // value), then the LDS stores: one memory latency per round instead of one per plane
             constexpr int NIT = (38 * 64 + 255) / 256;
@@ -157,7 +162,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                     const int y = ty0 + row, x = tx0 + 4 * xq;
                     const int ch = 32 * rd + pl;
                     const int pp = pl - 32 + (GEO ? 0 : 4);
-                    const bool on = y < a.H && x < a.W && f < (32 + npix) * 64 && (pl >= 32 || ch < a.nc);
+                    const bool on = y < a.H && x < a.W && f < (32 + npix) * 64 && (pl >= 32 || (ch < a.nc && a.dL_dfeat));
                     const float* src = pl < 32 ? a.dL_dfeat + (size_t)(a.c0 + ch) * HW
                                      : pp < 3 ? a.dL_dpix + (size_t)pp * HW : pp == 3 ? a.dL_ddepth : pp == 4 ? a.final_T : reinterpret_cast<const float*>(a.n_contrib);
                     const float* p = on ? src + (size_t)y * a.W + x : a.final_T;
@@ -171,7 +176,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                     const int y = ty0 + row, x = tx0 + 4 * xq;
                     const int ch = 32 * rd + pl;
                     const int pp = pl - 32 + (GEO ? 0 : 4);
-                    const bool on = y < a.H && f < (32 + npix) * 64 && (pl >= 32 || ch < a.nc);
+                    const bool on = y < a.H && f < (32 + npix) * 64 && (pl >= 32 || (ch < a.nc && a.dL_dfeat));
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (on) {
                         const float* src = pl < 32 ? a.dL_dfeat + (size_t)(a.c0 + ch) * HW
@@ -191,11 +196,86 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 const int pl = f >> 6, row = (f >> 2) & 15, xq = f & 3;
                 if (f < (32 + npix) * 64) *reinterpret_cast<float4*>(&stage[pl * PL_SP + row * 16 + 4 * xq]) = sv[it];
             }
+            if (a.glow) {
+                // The feature-map gradient arrives at the resolution of the loss (f3dgs_set_feature_grad_lowres), (gHg gWg, C)
+                // pixel-major: apply the transposed bilinear resize to this tile - for every pixel the (at most 2 x 2: the image is
+                // not smaller than the loss's map) output samples that read it, in the order and with the products of the loss's
+                // own transposed-resize kernel (feature_loss.hip, fl_resize_backward_kernel), so the staged values are the ones the
+                // dense path would have loaded (given both, they are added).  The rows and the columns of the tile that are
+                // sampled at all (one in three at a 3x reduction) are compacted first; work item = (sampled row, sampled column),
+                // lane = channel (one 128-byte request per sample), two items per pass with their eight requests in flight
+                // together.  An absent second sample re-reads the first and is not added.
+                // (Measured against this plain order - lists and samples behind the stores of the round: requesting the first pass
+                // of samples beside the pixel planes, the lists built in front, is slower: c4 2.97 against 2.88 ms.)
+                float4* const tl = reinterpret_cast<float4*>(smem + PL_TAPS_OFS);     // [0..15] rows, [16..31] columns: {o0, o1 (bits), w0, w1}
+                int* const ti = reinterpret_cast<int*>(smem + PL_TAPS_OFS + 32 * sizeof(float4));   // their pixel row / column; [32], [33]: counts
+                if (rd == 0 && tid < 64) {
+                    const bool is_row = tid < 16;
+                    const int k = tid & 15;
+                    const int i = is_row ? ty0 + k : tx0 + k;
+                    const int in = is_row ? a.H : a.W, out = is_row ? a.gHg : a.gWg;
+                    int oo[2] = {0, 0};
+                    float ww[2] = {0.f, 0.f};
+                    int n = 0;
+                    if (tid < 32 && i < in) n = resize_build<2>(i, is_row ? a.gsy : a.gsx, in, out, oo, ww);
+                    const unsigned long long has = __ballot(n > 0);
+                    const unsigned int mine = is_row ? (unsigned int)(has & 0xFFFFu) : (unsigned int)((has >> 16) & 0xFFFFu);
+                    if (n > 0) {
+                        const int slot = (is_row ? 0 : 16) + __popc(mine & ((1u << k) - 1u));
+                        tl[slot] = make_float4(__int_as_float(oo[0]), __int_as_float(n > 1 ? oo[1] : oo[0]), ww[0], n > 1 ? ww[1] : 0.f);
+                        ti[slot] = k;
+                    }
+                    if (tid == 0) { ti[32] = __popc((unsigned int)(has & 0xFFFFu)); ti[33] = __popc((unsigned int)((has >> 16) & 0xFFFFu)); }
+                }
+                __syncthreads();
+                const int nr = ti[32], ncol = ti[33];
+                const int items = nr * ncol;
+                if (items > 0) {
+                    const float gsc = a.gscale ? *a.gscale : 1.0f;
+                    // (32-bit element offsets: the caller has checked gHg gWg C < 2^31)
+                    const uint32_t ch = (uint32_t)fresh_lane() & 31u;
+                    const bool ch_ok = 32 * rd + (int)ch < a.nc;
+                    const float* const gbase = a.glow + a.c0 + 32 * rd;
+                    const uint32_t C_ = (uint32_t)a.C, Wg_ = (uint32_t)a.gWg;
+                    const uint32_t inv = (65536u + (uint32_t)ncol - 1u) / (uint32_t)ncol;      // i / ncol = (i inv) >> 16 for i < 256
+#pragma unroll 1
+                    for (int i0 = tid >> 5; i0 < items; i0 += 16) {
+                        float v[2][4], wy0[2], wy1[2], wx0[2], wx1[2];
+                        int sp[2];
+                        bool live[2];
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            const int it = i0 + 8 * u;
+                            live[u] = it < items && ch_ok;
+                            const int itc = it < items ? it : i0;
+                            const int ri = (int)(((uint32_t)itc * inv) >> 16), ci = itc - ri * ncol;
+                            const float4 yl = tl[ri], xl = tl[16 + ci];
+                            sp[u] = ti[ri] * 16 + ti[16 + ci];
+                            const uint32_t y0o = (uint32_t)__float_as_int(yl.x) * Wg_, y1o = (uint32_t)__float_as_int(yl.y) * Wg_;
+                            const uint32_t x0o = (uint32_t)__float_as_int(xl.x), x1o = (uint32_t)__float_as_int(xl.y);
+                            wy0[u] = yl.z; wy1[u] = yl.w; wx0[u] = xl.z; wx1[u] = xl.w;
+                            v[u][0] = gbase[(y0o + x0o) * C_ + ch]; v[u][1] = gbase[(y0o + x1o) * C_ + ch];
+                            v[u][2] = gbase[(y1o + x0o) * C_ + ch]; v[u][3] = gbase[(y1o + x1o) * C_ + ch];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            float rr = fmaf(wx0[u], v[u][0], 0.f);
+                            rr = wx1[u] != 0.f ? fmaf(wx1[u], v[u][1], rr) : rr;
+                            float acc = fmaf(wy0[u], rr, 0.f);
+                            float r2 = fmaf(wx0[u], v[u][2], 0.f);
+                            r2 = wx1[u] != 0.f ? fmaf(wx1[u], v[u][3], r2) : r2;
+                            acc = wy1[u] != 0.f ? fmaf(wy1[u], r2, acc) : acc;
+                            if (live[u]) stage[ch * PL_SP + sp[u]] += a.gscale ? acc * gsc : acc;
+                        }
+                    }
+                }
+            }
             PL_STAGE_MARK(0);
             __syncthreads();
             PL_STAGE_MARK(1);
             if (rd == 0) {
-                const int sp = (qy + ly) * 16 + qx + lx;
+                const int ln = fresh_lane();
+                const int sp = (qy + (ln >> 3)) * 16 + qx + (ln & 7);
                 constexpr int pb = 32 - (GEO ? 0 : 4);        // plane of dL/dR (GEO); final_T at pb + 4, n_contrib at pb + 5
                 last = __float_as_uint(stage[(pb + 5) * PL_SP + sp]);     // 0 outside the image (zero-filled)
                 T = stage[(pb + 4) * PL_SP + sp];
@@ -205,6 +285,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 }
             }
             // which plane is this wave's column `col`?  (-1: a zero column)
+            const int col = fresh_lane() & 15, kk = fresh_lane() >> 4;
             int plane = -1;
             bool mine = false;          // does this round hold this wave's block
             if constexpr (GEO) {
@@ -257,6 +338,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     // wave-uniform floats of the flush come in as kernel arguments (scalar registers): computed here, on the vector pipe, they would
     // occupy vector registers across the whole walk
     const float neg_half_w = a.neg_half_w, neg_half_h = a.neg_half_h;
+    const int lx = fresh_lane() & 7, ly = fresh_lane() >> 3;
     const float pxf = (float)(tx0 + qx + lx), pyf = (float)(ty0 + qy + ly);
     const uint32_t my_max = wave_max_u32(last);
     // does this wave hold a column block at all?

@@ -107,6 +107,12 @@ struct BwdArgs {
     const uint32_t* order;   // workgroup -> tile, longest walk first (null: XCD-contiguous tile order)
     int m44;                 // pixel-lane kernel, first window: the colour wave on 4 x 4 matrix blocks
     float neg_half_w, neg_half_h;   // pixel-lane kernel: -W / 2, -H / 2 (the NDC scale of dL/dmean2D, Q8)
+    // pixel-lane kernel: feature-map gradient at the loss's resolution, (gHg gWg, C) pixel-major (null: none); dL_dfeat may
+    // then be null.  gsy / gsx: the resize scales (H - 1) / (gHg - 1), (W - 1) / (gWg - 1); gscale: device scalar or null
+    const float* glow;
+    const float* gscale;
+    int gHg, gWg;
+    float gsy, gsx;
 #ifdef F3DGS_DEV
     int dev;          // development builds only (make DEV=1): bit0 skip flush atomics, bit1 skip pixel trips, bit2 skip MFMAs, bit3 phase timing
     unsigned long long* dev_cycles;   // [0] staging, [1] window walk, [2] pixel trips, [3] flush, [4] waves

@@ -62,6 +62,17 @@ def set_feature_grad_accumulator(buffer: Optional[torch.Tensor]) -> None:
     _C.set_feature_grad_accumulator(buffer)
 
 
+_lowres_offers = {}     # storage address of a feature_map output -> (gx, scale): see feature_loss.py, lowres_grad=True
+
+
+def _offer_feature_grad_lowres(feature_map_ptr: int, gx: torch.Tensor, scale: Optional[torch.Tensor]) -> None:
+    """The fused feature loss leaves its gradient at the loss's resolution for the backward call of the rasterizer call whose
+    `feature_map` output lives at `feature_map_ptr` (feature_loss.fused_feature_l1, lowres_grad=True)."""
+    while len(_lowres_offers) >= 8:      # offers nobody came for (a backward pass that raised): drop the oldest
+        _lowres_offers.pop(next(iter(_lowres_offers)))
+    _lowres_offers[feature_map_ptr] = (gx, scale)
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -111,6 +122,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # undefined upstream gradients arrive as None instead of zero tensors: `radii` is an integer output, autograd would
         # otherwise fill a (P,) int32 zero tensor for it in front of every backward call (one launch for nothing)
         ctx.set_materialize_grads(False)
+        ctx.feature_map_ptr = feature_map.data_ptr()
         ctx.save_for_backward(colors_precomp, semantic_feature, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer)
         return color, feature_map, radii, depth
@@ -131,9 +143,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color,
                 grad_out_feature, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
                 binningBuffer, imgBuffer, rs.debug)
-        (grad_means2D, grad_colors_precomp, grad_semantic_feature, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
-         grad_sh, grad_scales, grad_rotations) = _call_with_snapshot(
-            _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        offer = _lowres_offers.pop(ctx.feature_map_ptr, None)
+        if offer is not None:       # this call's feature-map gradient (or part of it) waits at the loss's resolution
+            _C.set_feature_grad_lowres(offer[0], offer[1])
+        try:
+            (grad_means2D, grad_colors_precomp, grad_semantic_feature, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
+             grad_sh, grad_scales, grad_rotations) = _call_with_snapshot(
+                _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        finally:
+            if offer is not None:
+                _C.set_feature_grad_lowres(None)
         if grad_semantic_feature.numel() == 0 and semantic_feature.numel() != 0:
             grad_semantic_feature = None        # accumulated into the buffer of set_feature_grad_accumulator
         if _backward_done_hook is not None:

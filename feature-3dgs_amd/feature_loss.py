@@ -13,7 +13,9 @@ with
 
 The (C, H, W) rendered map is read once, the (4C, Hg, Wg) decoded map never exists in memory, and the gradient with
 respect to the rendered map - what the rasterizer's backward consumes as dL_dout_feature - is produced by the same
-call.  The decoder is the one dense contraction next to the rasterizer: it runs on the fp32 matrix pipe
+call.  With `lowres_grad=True` that gradient is not even written out at the image's resolution (where 8 of 9 values are
+zero when the ground truth is a third of the image): it stays at the LOSS's resolution and the rasterizer's backward
+applies the transposed resize tile by tile (include/f3dgs.h: f3dgs_set_feature_grad_lowres).  The decoder is the one dense contraction next to the rasterizer: it runs on the fp32 matrix pipe
 (v_mfma_f32_32x32x2_f32, exact fp32).  HIP only (csrc/feature_loss.hip behind include/f3dgs.h); no CPU fallback.
 """
 from __future__ import annotations
@@ -27,29 +29,56 @@ from diff_gaussian_rasterization import _C
 
 class _FusedFeatureL1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feature_map, gt, weight, bias):
-        loss, d_fm, d_w, d_b = _C.feature_l1(feature_map, gt, weight, bias)
-        ctx.save_for_backward(d_fm, d_w, d_b)
+    def forward(ctx, feature_map, gt, weight, bias, lowres):
+        loss, d_fm, d_w, d_b, gx = _C.feature_l1(feature_map, gt, weight, bias, not lowres)
         ctx.has_decoder = weight.numel() > 0
+        ctx.lowres = lowres
+        if lowres:
+            # gx: dL/d(resized map), (Hg, Wg, C); the placeholder stands in for the dense gradient on autograd's side
+            ctx.save_for_backward(gx, d_w, d_b, feature_map.new_zeros(()))
+            ctx.fm_shape, ctx.fm_ptr = tuple(feature_map.shape), feature_map.data_ptr()
+        else:
+            ctx.save_for_backward(d_fm, d_w, d_b)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        d_fm, d_w, d_b = ctx.saved_tensors
         # the gradients were produced for dL/dloss = 1; the loss is a scalar, so they scale linearly
-        return d_fm * g, None, (d_w * g) if ctx.has_decoder else None, (d_b * g) if ctx.has_decoder else None
+        if ctx.lowres:
+            import diff_gaussian_rasterization as dgr
+            gx, d_w, d_b, zero = ctx.saved_tensors
+            # handed to the backward call of the rasterizer call that produced feature_map (matched by its storage); autograd
+            # itself carries a zero-stride placeholder, to which any other consumer's dense gradient is simply added
+            dgr._offer_feature_grad_lowres(ctx.fm_ptr, gx, g.reshape(()).to(torch.float32))
+            d_fm = zero.expand(ctx.fm_shape)
+        else:
+            d_fm, d_w, d_b = ctx.saved_tensors
+            d_fm = d_fm * g
+        return d_fm, None, (d_w * g) if ctx.has_decoder else None, (d_b * g) if ctx.has_decoder else None, None
 
 
 def fused_feature_l1(feature_map: torch.Tensor, gt_feature_map: torch.Tensor, weight: Optional[torch.Tensor] = None,
-                     bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     bias: Optional[torch.Tensor] = None, lowres_grad: bool = False) -> torch.Tensor:
     """mean |decode(resize(feature_map)) - gt|.  feature_map (C, H, W), gt (Cout, Hg, Wg), weight (Cout, C) or
-    (Cout, C, 1, 1) and bias (Cout) of the 1x1 decoder, or None for no decoder (then Cout == C)."""
+    (Cout, C, 1, 1) and bias (Cout) of the 1x1 decoder, or None for no decoder (then Cout == C).
+
+    lowres_grad=True: `feature_map` must be the feature map exactly as `GaussianRasterizer` returned it (not a view or a copy:
+    the gradient reaches that call's backward beside autograd; ValueError otherwise).  Where the ground truth is larger than
+    the image along an axis the dense path is taken."""
     e = torch.Tensor([])
+    lowres = bool(lowres_grad)
+    if lowres:
+        fn = feature_map.grad_fn
+        if fn is None or "_RasterizeGaussians" not in fn.name():
+            raise ValueError("lowres_grad=True needs the feature map as returned by GaussianRasterizer (its gradient is handed to "
+                             "that call's backward at the loss's resolution); got a tensor produced by "
+                             f"{fn.name() if fn is not None else 'no autograd node'}")
+        lowres = gt_feature_map.shape[-2] <= feature_map.shape[-2] and gt_feature_map.shape[-1] <= feature_map.shape[-1]
     if weight is None:
-        return _FusedFeatureL1.apply(feature_map, gt_feature_map, e, e)
+        return _FusedFeatureL1.apply(feature_map, gt_feature_map, e, e, lowres)
     w2 = weight.reshape(weight.shape[0], -1)
     return _FusedFeatureL1.apply(feature_map, gt_feature_map, w2, bias if bias is not None else torch.zeros(
-        weight.shape[0], device=weight.device, dtype=weight.dtype))
+        weight.shape[0], device=weight.device, dtype=weight.dtype), lowres)
 
 
 @torch.no_grad()

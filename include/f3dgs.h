@@ -221,11 +221,30 @@ int f3dgs_backward(
  * d_feature_map (C,H,W), d_weight (Cout,C), d_bias (Cout): the gradients of that loss (upstream gradient 1; they
  * scale linearly).  With a decoder C must be 32, 64 or 128 (the contraction runs on the fp32 matrix pipe in
  * 32-channel blocks); other shapes return F3DGS_ERR_UNSUPPORTED.  `scratch`: f3dgs_feature_l1_scratch_bytes(...) bytes.
+ *
+ * d_feature_map may be NULL: the dense (C,H,W) gradient - zeros at every pixel the resize does not sample, 8 of 9 when the
+ * ground truth is a third of the image - is then not written.  The gradient at the LOSS's resolution stays in `scratch`
+ * ((Hg*Wg, C) floats, pixel-major, f3dgs_feature_l1_lowres_grad) for as long as the caller keeps `scratch`, and goes to the
+ * blend backward through f3dgs_set_feature_grad_lowres, which applies the transposed resize tile by tile.
  */
 size_t f3dgs_feature_l1_scratch_bytes(int C, int Cout, int Hg, int Wg, int has_decoder);
 int f3dgs_feature_l1(int C, int H, int W, int Cout, int Hg, int Wg, const float* feature_map, const float* weight,
                      const float* bias, const float* gt, float* loss, float* d_feature_map, float* d_weight,
                      float* d_bias, void* scratch, void* stream /* hipStream_t */);
+
+const float* f3dgs_feature_l1_lowres_grad(int C, int Cout, int Hg, int Wg, int has_decoder, void* scratch);
+
+/*
+ * The next f3dgs_backward call of THIS thread takes its feature-map gradient (the argument dL_dfeaturepix of
+ * rasterize_points.cu:121 `RasterizeGaussiansBackwardCUDA`) at the resolution of the loss: gx = (Hg*Wg, C) floats,
+ * pixel-major, dL/d(resized feature map) as f3dgs_feature_l1 leaves it; `scale`: device scalar multiplied in (the upstream
+ * gradient of the loss) or NULL.  The blend backward computes, per tile, what F.interpolate's backward would have written
+ * there (same products, same order: bit-identical to the dense path) - it reads Hg*Wg*C floats instead of H*W*C.
+ * dL_dfeaturepix of that call may be NULL; if it is not, the two are added.  Needs Hg <= H and Wg <= W (shrinking: at
+ * most two output samples per source row / column) and option feature_mfma = 1, else the call returns
+ * F3DGS_ERR_UNSUPPORTED.  The setting is consumed by that call whatever it returns; gx == NULL clears it.
+ */
+int f3dgs_set_feature_grad_lowres(const float* gx, int Hg, int Wg, const float* scale);
 
 /*
  * Forward-only counterpart (the inference side, render.py:169-171, :137-139, :294-296): the rendered feature map (C,H,W)

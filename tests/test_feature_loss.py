@@ -107,3 +107,129 @@ def test_fused_feature_decode_matches_reference_ops(C, H, W, Cout, Hg, Wg, decod
         assert float((err - x.abs() * 2.0 ** -11).max()) <= 2e-5 * scale + 2.0 ** -25      # round-to-nearest half + subnormal step
     else:
         assert float(err.max()) <= 1e-5 * scale
+
+
+# ---- the loss's gradient handed to the rasterizer's backward at the LOSS's resolution (lowres_grad=True) ------------------------
+
+def _render_and_loss(sc, gt, w, b, lowres, extra=None, dev="cuda:0", loss_scale=1.0):
+    """One training-style step: render, fused feature loss (+ optional second consumer of the feature map), backward.
+    Returns (loss value, leaf gradients)."""
+    import diff_gaussian_rasterization as dgr
+    from feature_loss import fused_feature_l1
+    t = lambda x: x.to(dev)
+    P = sc["means3D"].shape[0]
+    settings = dgr.GaussianRasterizationSettings(sc["image_height"], sc["image_width"], sc["tanfovx"], sc["tanfovy"], t(sc["bg"]),
+                                                 sc["scale_modifier"], t(sc["viewmatrix"]), t(sc["projmatrix"]), sc["sh_degree"],
+                                                 t(sc["campos"]), False, False)
+    leaf = lambda x: t(x).clone().requires_grad_(True)
+    L = dict(means3D=leaf(sc["means3D"]), means2D=leaf(torch.zeros(P, 3)), opacities=leaf(sc["opacities"]), shs=leaf(sc["shs"]),
+             semantic_feature=leaf(sc["semantic_feature"]), scales=leaf(sc["scales"]), rotations=leaf(sc["rotations"]))
+    color, feat, _radii, _depth = dgr.GaussianRasterizer(settings)(**L)
+    w_d = t(w).requires_grad_(True) if w is not None else None
+    b_d = t(b).requires_grad_(True) if b is not None else None
+    loss = loss_scale * fused_feature_l1(feat, t(gt), w_d, b_d, lowres_grad=lowres)
+    total = loss + (color * t(sc["dL_dcolor"])).sum()
+    if extra is not None:
+        total = total + (feat * t(extra)).sum()            # a second, dense consumer of the feature map
+    total.backward()
+    torch.cuda.synchronize()
+    g = {k: v.grad.detach().cpu().numpy() for k, v in L.items() if v.grad is not None}
+    if w_d is not None:
+        g["decoder_w"], g["decoder_b"] = w_d.grad.cpu().numpy(), b_d.grad.cpu().numpy()
+    return float(loss.detach()), g
+
+
+LOWRES_CASES = [
+    # (C, W, H, Hg, Wg, decoder Cout or 0, second consumer, loss scale)
+    (32, 333, 208, 70, 111, 128, False, 1.0),      # ~3x reduction, ragged image, decoder
+    (16, 333, 208, 69, 111, 0, False, 1.0),        # 16 channels: the pixel-lane kernel is taken for this call
+    (128, 160, 96, 32, 54, 0, False, 2.5),         # three channel windows (the later ones in two staging rounds), scaled loss
+    (32, 200, 120, 120, 200, 0, False, 1.0),       # identity resize: every pixel is a sample
+    (32, 200, 120, 87, 143, 0, True, 1.0),         # ~1.4x reduction: rows / columns with two samples; dense gradient added
+    (40, 96, 64, 1, 1, 0, False, 1.0),             # one output pixel (scale 0): only source pixel (0, 0) is sampled
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,W,H,Hg,Wg,Cout,second,loss_scale", LOWRES_CASES)
+def test_lowres_feature_gradient_equals_the_dense_path(C, W, H, Hg, Wg, Cout, second, loss_scale, monkeypatch):
+    """fused_feature_l1(lowres_grad=True): the dense (C,H,W) gradient is never written; the rasterizer's backward applies the
+    transposed resize per tile with the products and the order of the loss's own transposed-resize kernel.  Every leaf gradient
+    equals the dense path's up to the order of the atomic sums (the staged tiles are the same numbers)."""
+    from synth import make_scene
+    sc = make_scene(P=20000, C=C, width=W, height=H, seed=43)
+    g = torch.Generator().manual_seed(5)
+    co = Cout if Cout else C
+    gt = torch.randn(co, Hg, Wg, generator=g)
+    w = (torch.randn(co, C, generator=g) / C ** 0.5) if Cout else None
+    b = (torch.randn(co, generator=g) * 0.1) if Cout else None
+    extra = (torch.randn(C, H, W, generator=g) / (W * H)) if second else None
+    import diff_gaussian_rasterization as dgr
+    handed, real = [], dgr._C.set_feature_grad_lowres
+
+    def spy(gx, scale=None):            # the extension is handed the (Hg, Wg, C) gradient exactly once, by the lowres run
+        if gx is not None:
+            handed.append(tuple(gx.shape))
+        return real(gx, scale)
+    monkeypatch.setattr(dgr._C, "set_feature_grad_lowres", spy)
+    l0, g0 = _render_and_loss(sc, gt, w, b, False, extra, loss_scale=loss_scale)
+    assert handed == []
+    l1, g1 = _render_and_loss(sc, gt, w, b, True, extra, loss_scale=loss_scale)
+    assert handed == [(Hg, Wg, C)] and not dgr._lowres_offers
+    assert l0 == l1
+    assert set(g0) == set(g1)
+    for k, want in g0.items():
+        scale = float(np.abs(want).max()) + 1e-30
+        assert float(np.abs(g1[k] - want).max()) <= 2e-5 * scale, (k, float(np.abs(g1[k] - want).max()) / scale)
+    assert float(np.abs(g0["semantic_feature"]).max()) > 0
+
+
+@pytest.mark.gpu
+def test_lowres_feature_gradient_goes_to_the_call_that_rendered_the_map():
+    """Two renders in one graph, the loss on the first one's feature map: the gradient is matched to its rasterizer call by the
+    map's storage, whatever order autograd runs the two backward calls in.  A feature map that is not the rasterizer's own output
+    is refused; a ground truth larger than the image falls back to the dense path."""
+    import diff_gaussian_rasterization as dgr
+    from feature_loss import fused_feature_l1
+    from synth import make_scene
+    dev = "cuda:0"
+    t = lambda x: x.to(dev)
+    scA = make_scene(P=8000, C=32, width=160, height=96, seed=3)
+    scB = make_scene(P=8000, C=32, width=160, height=96, seed=4)
+    gt = torch.randn(32, 30, 50, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def render(sc, feat_leaf):
+        P = sc["means3D"].shape[0]
+        st = dgr.GaussianRasterizationSettings(sc["image_height"], sc["image_width"], sc["tanfovx"], sc["tanfovy"], t(sc["bg"]),
+                                               sc["scale_modifier"], t(sc["viewmatrix"]), t(sc["projmatrix"]), sc["sh_degree"],
+                                               t(sc["campos"]), False, False)
+        return dgr.GaussianRasterizer(st)(means3D=t(sc["means3D"]), means2D=torch.zeros(P, 3, device=dev), opacities=t(sc["opacities"]),
+                                          shs=t(sc["shs"]), semantic_feature=feat_leaf, scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+
+    grads = {}
+    for lowres in (False, True):
+        fa = t(scA["semantic_feature"]).clone().requires_grad_(True)
+        fb = t(scB["semantic_feature"]).clone().requires_grad_(True)
+        _ca, feat_a, _ra, _da = render(scA, fa)
+        cb, _feat_b, _rb, _db = render(scB, fb)          # rendered later: its backward node is the first autograd runs
+        (fused_feature_l1(feat_a, gt, lowres_grad=lowres) + cb.sum() * 1e-3).backward()
+        torch.cuda.synchronize()
+        grads[lowres] = (fa.grad.cpu().numpy(), None if fb.grad is None else fb.grad.cpu().numpy())
+    a0, b0 = grads[False]
+    a1, b1 = grads[True]
+    assert float(np.abs(a0).max()) > 0
+    assert float(np.abs(a1 - a0).max()) <= 2e-5 * float(np.abs(a0).max())
+    assert (b0 is None and b1 is None) or float(np.abs(b1 - b0).max()) <= 2e-5 * (float(np.abs(b0).max()) + 1e-30)
+
+    fa = t(scA["semantic_feature"]).clone().requires_grad_(True)
+    _c, feat_a, _r, _d = render(scA, fa)
+    with pytest.raises(ValueError):
+        fused_feature_l1(feat_a * 1.0, gt, lowres_grad=True)
+    big = torch.randn(32, 200, 300, device=dev)          # enlarging: dense path, still the right numbers
+    fused_feature_l1(feat_a, big, lowres_grad=True).backward()
+    g_low = fa.grad.clone()
+    fa.grad = None
+    _c, feat_a, _r, _d = render(scA, fa)
+    fused_feature_l1(feat_a, big, lowres_grad=False).backward()
+    torch.cuda.synchronize()
+    assert float((g_low - fa.grad).abs().max()) <= 2e-5 * float(fa.grad.abs().max())

@@ -112,7 +112,7 @@ def test_training_loop_tracks_the_reference_glue(reference_render):   # noqa: F8
         image = pkg["render"]
         Ll1 = lu.l1_loss(image, c.original_image)
         return ((1.0 - _Opt.lambda_dssim) * Ll1 + _Opt.lambda_dssim * (1.0 - lu.ssim(image, c.original_image))
-                + fused_feature_l1(pkg["feature_map"], c.semantic_feature, None, None))
+                + fused_feature_l1(pkg["feature_map"], c.semantic_feature, None, None, lowres_grad=True))   # gradient at 60 x 100
 
     ITER, DENSIFY = 14, (6, 12)
     a, b = _start(Model, sc), _start(Model, sc, FusedAdam)

@@ -27,7 +27,14 @@ for C, Cout in ((32, 128), (64, 256), (128, 512)):
         loss.backward()
         return loss
 
-    for name, fn in (("torch ops", ref), ("fused", fused)):
+    from diff_gaussian_rasterization import _C
+    w2 = conv.weight.detach().reshape(Cout, C).contiguous()
+    b2 = conv.bias.detach().contiguous()
+
+    def fused_lowres():      # the same call with the gradient left at the loss's resolution (fused_feature_l1(lowres_grad=True))
+        return _C.feature_l1(fm.detach(), gt, w2, b2, False)[0]
+
+    for name, fn in (("torch ops", ref), ("fused", fused), ("fused, gradient at the loss resolution", fused_lowres)):
         for _ in range(3):
             fn(); fm.grad = None; conv.zero_grad()
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -36,4 +43,4 @@ for C, Cout in ((32, 128), (64, 256), (128, 512)):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 100
         flops = 3 * 2.0 * Hg * Wg * C * Cout
-        print(f"C={C:3d} -> {Cout:3d}  {name:10s} {ms:7.3f} ms  ({flops / ms / 1e9:6.1f} TFLOP/s on the three contractions)", flush=True)
+        print(f"C={C:3d} -> {Cout:3d}  {name:40s} {ms:7.3f} ms  ({flops / ms / 1e9:6.1f} TFLOP/s on the three contractions)", flush=True)
