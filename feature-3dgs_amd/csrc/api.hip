@@ -266,7 +266,7 @@ CountReadback* count_readback(hipStream_t s) {
 
 extern "C" {
 
-int f3dgs_version(void) { return 30100; }   // 3.1.0 (major * 10000 + minor * 100 + patch): seven untested shape knobs removed, f3dgs_option_name
+int f3dgs_version(void) { return 30200; }   // 3.2.0 (major * 10000 + minor * 100 + patch): 3.1 seven untested shape knobs removed, f3dgs_option_name; 3.2 f3dgs_set_feature_grad_lowres
 
 int f3dgs_set_option(const char* name, int value) {
     if (!name) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null option name");

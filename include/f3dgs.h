@@ -54,7 +54,7 @@ extern "C" {
  * resizeFunctional() of rasterize_points.cu:27-33. */
 typedef char* (*f3dgs_resize_fn)(void* ctx, size_t nbytes);
 
-/* Library / ABI version: major*10000 + minor*100 + patch (3.1.0 -> 30100). */
+/* Library / ABI version: major*10000 + minor*100 + patch (3.2.0 -> 30200). */
 int f3dgs_version(void);
 
 /* Thread-local message of the last error raised on this host thread. */
