@@ -709,9 +709,17 @@ def main():
                         "frac": 4.0 * r["SQ_ACTIVE_INST_VALU"] / (r["SQ_BUSY_CYCLES"] / 32.0 * 1024.0),
                         "matrix_pipe_frac": r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (r["SQ_BUSY_CYCLES"] / 32.0 * 1024.0),
                         "valu_instructions_per_launch": r["SQ_INSTS_VALU"], "mfma_instructions_per_launch": r["SQ_INSTS_MFMA"]}
+                    # fp32 matrix instructions and vector instructions of a SIMD exclude each other on gfx950 (tools/pipe_probe.hip,
+                    # DESIGN.md 3.5): the kernel's issue roofline is the SUM of the two; plain vector instructions = SQ_INSTS_VALU
+                    # - SQ_INSTS_MFMA (the counter includes the matrix instructions), 4 cycles each
+                    cyc = r["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
+                    profiled["valu_issue"][stage]["vector_plus_matrix_frac"] = (
+                        4.0 * (r["SQ_INSTS_VALU"] - r["SQ_INSTS_MFMA"]) + r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)) / cyc
                 profiled["valu_issue_source"] = (f"profiles/{sqf} (rocprofv3 --pmc, a separate run of this config); frac = 4 x "
                                                  "SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs), matrix_pipe_frac = "
-                                                 "SQ_VALU_MFMA_BUSY_CYCLES / the same")
+                                                 "SQ_VALU_MFMA_BUSY_CYCLES / the same; vector_plus_matrix_frac = (4 x (SQ_INSTS_VALU - SQ_INSTS_MFMA) + "
+                                                 "SQ_VALU_MFMA_BUSY_CYCLES) / the same: the two exclude each other on a SIMD "
+                                                 "(profiles/r04_pipe_probe.txt), their sum is what the blend kernels are bound by")
                 break
             except Exception:
                 pass
@@ -744,7 +752,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": dom_ms,
                          "kernel_ms_source": "HIP events around the kernel on the op's stream, inside the timed region",
                          "note": "HBM is the roofline the contract names for this path; the kernel itself is bound by "
-                                 "VALU issue and by the fp32 global-atomic rate (DESIGN.md 3.5, profiles/): see `profiled`"},
+                                 "vector + fp32 matrix issue, which exclude each other on a SIMD (DESIGN.md 3.5, profiles/): see "
+                                 "`profiled.valu_issue.*.vector_plus_matrix_frac`"},
             "profiled": profiled,
             "roofline_whole_step": {"algorithmic_bytes": alg["total"], "algorithmic_bytes_min": alg["total_min"],
                                     "achieved": alg["total"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",

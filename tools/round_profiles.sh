@@ -16,6 +16,9 @@ timeout 300 python bench.py --config c3 --views-per-iter 8 --steps 10 --warmup 3
 timeout 200 python tools/adam_bench.py > $OUT/${TAG}_adam.txt 2>&1
 timeout 200 python tools/adam_bench.py 5000000 128 >> $OUT/${TAG}_adam.txt 2>&1
 timeout 200 python tools/feature_loss_bench.py > $OUT/${TAG}_feature_loss.txt 2>&1
+timeout 200 python tools/lowres_step_bench.py c4 20 > $OUT/${TAG}_lowres_step.txt 2>&1
+timeout 200 python tools/lowres_step_bench.py c3 20 >> $OUT/${TAG}_lowres_step.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -w tools/pipe_probe.hip -o /tmp/pipe_probe 2>/dev/null && timeout 60 /tmp/pipe_probe > $OUT/${TAG}_pipe_probe.txt 2>&1
 python tools/kernel_resources.py > $OUT/${TAG}_kernel_resources.txt 2>&1
 if [ -z "$QUICK" ]; then
 # 1c. SURVEY 8(d): the reduced c3-shaped PyTorch-CPU run (minutes of host time)
