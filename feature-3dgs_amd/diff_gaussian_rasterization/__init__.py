@@ -62,15 +62,16 @@ def set_feature_grad_accumulator(buffer: Optional[torch.Tensor]) -> None:
     _C.set_feature_grad_accumulator(buffer)
 
 
-_lowres_offers = {}     # storage address of a feature_map output -> (gx, scale): see feature_loss.py, lowres_grad=True
+_lowres_offers = {}     # serial number of a rasterizer call -> (gx, scale): see feature_loss.py, lowres_grad=True
+_call_serial = 0        # every forward call gets one; its feature_map output carries it as `_f3dgs_call`
 
 
-def _offer_feature_grad_lowres(feature_map_ptr: int, gx: torch.Tensor, scale: Optional[torch.Tensor]) -> None:
-    """The fused feature loss leaves its gradient at the loss's resolution for the backward call of the rasterizer call whose
-    `feature_map` output lives at `feature_map_ptr` (feature_loss.fused_feature_l1, lowres_grad=True)."""
+def _offer_feature_grad_lowres(call_serial: int, gx: torch.Tensor, scale: Optional[torch.Tensor]) -> None:
+    """The fused feature loss leaves its gradient at the loss's resolution for the backward call of rasterizer call
+    `call_serial` (the `_f3dgs_call` attribute of its feature_map output; feature_loss.fused_feature_l1, lowres_grad=True)."""
     while len(_lowres_offers) >= 8:      # offers nobody came for (a backward pass that raised): drop the oldest
         _lowres_offers.pop(next(iter(_lowres_offers)))
-    _lowres_offers[feature_map_ptr] = (gx, scale)
+    _lowres_offers[call_serial] = (gx, scale)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -122,7 +123,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         # undefined upstream gradients arrive as None instead of zero tensors: `radii` is an integer output, autograd would
         # otherwise fill a (P,) int32 zero tensor for it in front of every backward call (one launch for nothing)
         ctx.set_materialize_grads(False)
-        ctx.feature_map_ptr = feature_map.data_ptr()
+        global _call_serial
+        _call_serial += 1
+        ctx.call_serial = _call_serial
         ctx.save_for_backward(colors_precomp, semantic_feature, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer)
         return color, feature_map, radii, depth
@@ -143,7 +146,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color,
                 grad_out_feature, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
                 binningBuffer, imgBuffer, rs.debug)
-        offer = _lowres_offers.pop(ctx.feature_map_ptr, None)
+        offer = _lowres_offers.pop(ctx.call_serial, None)
         if offer is not None:       # this call's feature-map gradient (or part of it) waits at the loss's resolution
             _C.set_feature_grad_lowres(offer[0], offer[1])
         try:
@@ -166,8 +169,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantic_feature, opacities, scales, rotations,
                         cov3Ds_precomp, raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantic_feature, opacities, scales,
-                                     rotations, cov3Ds_precomp, raster_settings)
+    out = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantic_feature, opacities, scales,
+                                    rotations, cov3Ds_precomp, raster_settings)
+    out[1]._f3dgs_call = _call_serial       # which call rendered this feature map (fused_feature_l1, lowres_grad=True)
+    return out
 
 
 class GaussianRasterizer(nn.Module):

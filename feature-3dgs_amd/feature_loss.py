@@ -30,13 +30,14 @@ from diff_gaussian_rasterization import _C
 class _FusedFeatureL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feature_map, gt, weight, bias, lowres):
+        # lowres: 0 = dense gradient, otherwise the serial number of the rasterizer call that rendered feature_map
         loss, d_fm, d_w, d_b, gx = _C.feature_l1(feature_map, gt, weight, bias, not lowres)
         ctx.has_decoder = weight.numel() > 0
         ctx.lowres = lowres
         if lowres:
             # gx: dL/d(resized map), (Hg, Wg, C); the placeholder stands in for the dense gradient on autograd's side
             ctx.save_for_backward(gx, d_w, d_b, feature_map.new_zeros(()))
-            ctx.fm_shape, ctx.fm_ptr = tuple(feature_map.shape), feature_map.data_ptr()
+            ctx.fm_shape = tuple(feature_map.shape)
         else:
             ctx.save_for_backward(d_fm, d_w, d_b)
         return loss
@@ -47,9 +48,9 @@ class _FusedFeatureL1(torch.autograd.Function):
         if ctx.lowres:
             import diff_gaussian_rasterization as dgr
             gx, d_w, d_b, zero = ctx.saved_tensors
-            # handed to the backward call of the rasterizer call that produced feature_map (matched by its storage); autograd
+            # handed to the backward call of the rasterizer call that produced feature_map (matched by its serial number); autograd
             # itself carries a zero-stride placeholder, to which any other consumer's dense gradient is simply added
-            dgr._offer_feature_grad_lowres(ctx.fm_ptr, gx, g.reshape(()).to(torch.float32))
+            dgr._offer_feature_grad_lowres(ctx.lowres, gx, g.reshape(()).to(torch.float32))
             d_fm = zero.expand(ctx.fm_shape)
         else:
             d_fm, d_w, d_b = ctx.saved_tensors
@@ -66,14 +67,16 @@ def fused_feature_l1(feature_map: torch.Tensor, gt_feature_map: torch.Tensor, we
     the gradient reaches that call's backward beside autograd; ValueError otherwise).  Where the ground truth is larger than
     the image along an axis the dense path is taken."""
     e = torch.Tensor([])
-    lowres = bool(lowres_grad)
-    if lowres:
+    lowres = 0
+    if lowres_grad:
         fn = feature_map.grad_fn
-        if fn is None or "_RasterizeGaussians" not in fn.name():
+        lowres = getattr(feature_map, "_f3dgs_call", 0)
+        if fn is None or "_RasterizeGaussians" not in fn.name() or not lowres:
             raise ValueError("lowres_grad=True needs the feature map as returned by GaussianRasterizer (its gradient is handed to "
                              "that call's backward at the loss's resolution); got a tensor produced by "
                              f"{fn.name() if fn is not None else 'no autograd node'}")
-        lowres = gt_feature_map.shape[-2] <= feature_map.shape[-2] and gt_feature_map.shape[-1] <= feature_map.shape[-1]
+        if not (gt_feature_map.shape[-2] <= feature_map.shape[-2] and gt_feature_map.shape[-1] <= feature_map.shape[-1]):
+            lowres = 0
     if weight is None:
         return _FusedFeatureL1.apply(feature_map, gt_feature_map, e, e, lowres)
     w2 = weight.reshape(weight.shape[0], -1)

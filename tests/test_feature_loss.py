@@ -187,7 +187,7 @@ def test_lowres_feature_gradient_equals_the_dense_path(C, W, H, Hg, Wg, Cout, se
 @pytest.mark.gpu
 def test_lowres_feature_gradient_goes_to_the_call_that_rendered_the_map():
     """Two renders in one graph, the loss on the first one's feature map: the gradient is matched to its rasterizer call by the
-    map's storage, whatever order autograd runs the two backward calls in.  A feature map that is not the rasterizer's own output
+    call's serial number (carried by the feature map), whatever order autograd runs the two backward calls in.  A feature map that is not the rasterizer's own output
     is refused; a ground truth larger than the image falls back to the dense path."""
     import diff_gaussian_rasterization as dgr
     from feature_loss import fused_feature_l1
