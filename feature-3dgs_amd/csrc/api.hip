@@ -441,7 +441,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
             HIP_TRY(hipMemsetAsync(bin.ranges_enc, 0xFF, tiles * sizeof(uint2), s));
             HIP_TRY(hipMemsetAsync(img.tile_len, 0, tiles * sizeof(uint32_t), s));
         } else {
-            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, bin.ranges_enc, img.tile_len, (size_t)N, s);   // presets the ranges too
+            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, bin.ranges_enc, img.tile_len, s);   // presets the ranges too
             if ((rc = check_debug(debug, s, "emit"))) return rc;
             tm.mark("emit");
             // the final pass also records the tile ranges

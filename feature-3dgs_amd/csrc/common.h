@@ -218,8 +218,7 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
                              uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s);
 // also presets `ranges_enc` (all-ones = "no entry yet") for the final tile-sort pass and zeroes `tile_len`
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
-                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, size_t n_list,
-                           hipStream_t s);
+                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, hipStream_t s);
 // single-pass flavour (option sort_onesweep): offsets by decoupled look-back inside the emit kernel, which also
 // produces the tile digit histograms, presets `ranges` for the final sort pass and zero-fills b.tile_status
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,

@@ -397,32 +397,28 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
 // an exclusive scan in this very order), so the wave first lays them out in LDS and then copies the whole range out with
 // contiguous stores (a lane storing straight to its own run writes one dword to 64 different places per instruction:
 // 0.061 ms for 42 MB at c3).  Waves whose range exceeds the LDS slice (a few huge splats) store directly.
-// Two shapes: four waves with 1024 list entries each in LDS (8 KB per wave), or - where the splats cover tens of tiles each (4K
-// images: 33 per visible splat at config c5, 2100 per wave) - one wave per workgroup with 4096 entries (32 KB), so that the long
-// ranges are staged too (c5: 0.567 -> see profiles/r04_notes.md).
-template <int EMIT_CAP, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES)
+constexpr int EMIT_CAP = 1024;      // list entries per wave in LDS (8 KB)
+__global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_sums,
                       const uint32_t* __restrict__ sub, const uint32_t* __restrict__ tiles_touched,
                       const SplatRec* __restrict__ rec, int gx, int gy, int cull, uint32_t* __restrict__ inst_tile,
                       uint32_t* __restrict__ inst_id, uint2* __restrict__ ranges_enc, uint32_t* __restrict__ tile_len) {
-    constexpr int THREADS = 64 * WAVES;
-    __shared__ uint32_t s_tile[WAVES][EMIT_CAP];
-    __shared__ uint32_t s_id[WAVES][EMIT_CAP];
+    __shared__ uint32_t s_tile[4][EMIT_CAP];
+    __shared__ uint32_t s_id[4][EMIT_CAP];
     // all-ones = "no entry yet" for both halves of the encoded tile ranges (BinState::ranges_enc; the final sort pass,
     // two launches further on, lowers them with atomicMin); zero for the tiles' walk lengths (raised by the blend forward)
-    for (uint32_t t = blockIdx.x * THREADS + threadIdx.x; t < (uint32_t)(gx * gy); t += gridDim.x * THREADS) {
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (uint32_t)(gx * gy); t += gridDim.x * 256) {
         ranges_enc[t] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         tile_len[t] = 0u;
     }
-    const int i = blockIdx.x * THREADS + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool valid = i < P;
     const uint32_t g = valid ? order[i] : 0u;
     const uint32_t cnt = valid ? tiles_touched[g] : 0u;
     // the wave's range of the list starts behind the runs of 64 in front of its own inside its chunk of SCAN_CHUNK Gaussians
     // (binning.hip: scan_reduce_kernel); a lane's run starts behind the lanes in front of it
-    const uint32_t first = (uint32_t)(blockIdx.x * THREADS + 64 * w);          // the wave's first Gaussian (depth order)
+    const uint32_t first = (uint32_t)(blockIdx.x * 256 + 64 * w);              // the wave's first Gaussian (depth order)
     const uint32_t chunk = first / SCAN_CHUNK, run = (first % SCAN_CHUNK) / 64;
     uint32_t before = (uint32_t)lane < run ? sub[(size_t)chunk * 64 + lane] : 0u;
     // ... and the chunks in front of its own: their totals are summed here (a few coalesced reads) rather than scanned by a
@@ -886,16 +882,9 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
 }
 
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
-                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, size_t n_list,
-                           hipStream_t s) {
-    // list entries per wave of 64 Gaussians, averaged over ALL Gaussians (the invisible ones sort to the end of the depth order, so
-    // the waves that emit anything are denser than this): from ~500 on the 1024-entry slice overflows for most of them
-    if ((double)n_list * 64.0 > 500.0 * (double)P)
-        hipLaunchKernelGGL((emit_instances_kernel<4096, 1>), dim3((P + 63) / 64), dim3(64), 0, s, P, order, g.scan_tmp, g.scan_sub,
-                           g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc, tile_len);
-    else
-        hipLaunchKernelGGL((emit_instances_kernel<1024, 4>), dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.scan_tmp, g.scan_sub,
-                           g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc, tile_len);
+                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, hipStream_t s) {
+    hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.scan_tmp, g.scan_sub,
+                       g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc, tile_len);
 }
 
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,
