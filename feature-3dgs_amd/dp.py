@@ -440,6 +440,12 @@ _stream_pool: Dict[tuple, list] = {}
 def _side_streams(device, n: int) -> list:
     key = (device.type, device.index)
     pool = _stream_pool.setdefault(key, [])
+    if not pool:
+        # The leaves were created on the caller's stream and their gradients now arrive from these streams: intended (the
+        # backward passes are ordered among themselves with events, and the caller's stream waits for the last of them).
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
