@@ -691,6 +691,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     BwdArgs a;
     a.order = nullptr;
     a.glow = nullptr; a.gscale = nullptr; a.gHg = a.gWg = 0; a.gsy = a.gsx = 0.f;
+    a.m44 = 0; a.split16 = 0; a.neg_half_w = a.neg_half_h = 0.f;
     const bool low = lowres && lowres->gx && C > 0;
     if (low) {
         a.glow = lowres->gx; a.gscale = lowres->scale; a.gHg = lowres->Hg; a.gWg = lowres->Wg;
@@ -722,16 +723,18 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
         }
     } report{dev_cycles, s, (a.dev & 8) != 0};
 #endif
-    // pixel-lane formulation (render_bwd_pl.hip): option bwd_pl = 1 always, 0 never, -1 (default) from 17 channels on - with
-    // 16 or fewer one of its four matrix-pipe waves has no columns and the instance-lane kernel is a few per cent faster
+    // pixel-lane formulation (render_bwd_pl.hip): option bwd_pl = 1 always, 0 never, -1 (default) from 5 channels on (up to 16 its
+    // feature and moment blocks are split over the waves by quadrants, option bwd_split16).  c2-sized scenes, ms per launch,
+    // instance-lane / pixel-lane: C = 0 0.452 / 0.603, 3 0.568 / 0.603, 8 0.651 / 0.615, 12 0.66 / 0.619, 16 0.66 / 0.618
     // (a low-resolution feature-map gradient is taken by the pixel-lane kernel only: the caller has checked feature_mfma)
-    if (low || ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > 16)) && opt.feature_mfma)) {
+    if (low || ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > 4)) && opt.feature_mfma)) {
         if (opt.bwd_order && tile_len && tile_order) {
             launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, s);
             a.order = tile_order;
         }
         a.half = 0;
         a.m44 = opt.bwd_m44;
+        a.split16 = opt.bwd_split16;
         launch_render_backward_pl(a, C, s);
 #ifdef F3DGS_DEV
         if (a.dev & 8) {

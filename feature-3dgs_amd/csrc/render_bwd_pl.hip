@@ -117,6 +117,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: quadrant in phase 1, column block in phase 2
+    const bool split16 = GEO && a.split16 && a.nc <= 16;      // wave-uniform: see the operand read-out below
     PL_PHASE_BEGIN();     // [0] staging  [1] window + barriers  [2] phase 1  [3] phase 2  [4] flush  [5] chunks  [6] entries
 
     // longest walks first: the launch is ~8 rounds of workgroups whose lifetimes differ by an order of magnitude, and a long
@@ -309,6 +310,30 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                         const int px = (qd & 1) * 8 + kc4 + 4 * (t & 1), py = (qd >> 1) * 8 + 2 * (t >> 2) + ((t >> 1) & 1);
                         Bop[qd][t] = stage[(32 + i4) * PL_SP + py * 16 + px];
                     }
+            } else if (GEO && split16 && q != 2) {
+                // Up to 16 channels (BwdArgs::split16): one feature block only - it is split over waves 0 and 1 by QUADRANTS (0, 1 | 2, 3:
+                // two partial sums per entry, added in the flush), and the moment block over waves 0, 1 (quadrant 0 | 1) and 3
+                // (quadrants 2, 3): 1536 / 1536 / 512 / 1024 matrix cycles per chunk instead of 2048 / 0 / 512 / 2048.
+                // Operand rows: waves 0, 1: Bop[0], Bop[1] = the feature columns at their two quadrants, Bop[2] = the monomials;
+                // wave 3: Bop[0] = the monomials.
+                const float k0c = col == 0 ? 1.f : 0.f, k1c = col == 1 ? 1.f : 0.f, k2c = col == 2 ? 1.f : 0.f;
+                const float k3c = col == 3 ? 1.f : 0.f, k4c = col == 4 ? 1.f : 0.f, k5c = col == 5 ? 1.f : 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const float uu = (float)(4 * (t & 1) + kk) - 3.5f, vv = (float)(t >> 1) - 3.5f;
+                    const float v = fmaf(fmaf(k3c, uu, fmaf(k4c, vv, k1c)), uu, fmaf(fmaf(k5c, vv, k2c), vv, k0c));
+                    if (q == 3) Bop[0][t] = v; else Bop[2][t] = v;
+                }
+                if (q < 2) {
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+                        for (int t = 0; t < 16; t++) {
+                            const int qd = 2 * q + sl;
+                            const int px = (qd & 1) * 8 + 4 * (t & 1) + kk, py = (qd >> 1) * 8 + (t >> 1);
+                            Bop[sl][t] = col < a.nc ? stage[col * PL_SP + py * 16 + px] : 0.f;
+                        }
+                }
             } else if (GEO && q == 3) {
                 // the moment wave: monomials of the pixel offset from the QUADRANT centre (the moments of each quadrant are kept
                 // apart and re-centred on the splat mean one by one: |u|, |v| <= 3.5), columns 0..5: 1, u, v, u^2, uv, v^2 - the
@@ -539,6 +564,47 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                     v += __shfl_xor(v, 32, 64);
                     if (kc4 == 0) L.ftile[(4 * rg + r) * PL_FS + 32 + i4] = v;
                 }
+            } else if (GEO && split16 && q != 2 && (tt & 0xFFFFu) != 0) {
+                // ---- up to 16 channels: quadrant-split feature block and moment block (see the operand read-out)
+                const int lane2 = fresh_lane();
+                const int col = lane2 & 15, kk = lane2 >> 4;
+                const int rofs0 = kk * PL_ROW + (col ^ kk) * 4, rofs1 = rofs0 ^ 16;
+                const int fs_row0 = (4 * kk) * PL_FS;
+                const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto contract = [&](const float* abase, int qd, const float (&B)[16], f32x4& c0, f32x4& c1) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float4 av = *reinterpret_cast<const float4*>(abase + ((u & 1) ? rofs1 : rofs0) + qd * PL_TILE + u * 4 * PL_ROW);
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, B[4 * u + 0], c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, B[4 * u + 1], c1, 0, 0, 0);
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, B[4 * u + 2], c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, B[4 * u + 3], c1, 0, 0, 0);
+                    }
+                };
+                auto live = [&](int qd) { return ((tt >> (16 + qd)) & 1u) != 0; };
+                if (q < 2) {
+                    f32x4 acc0 = zero4, acc1 = zero4;
+                    if (live(2 * q)) contract(&L.wt[0][0], 2 * q, Bop[0], acc0, acc1);
+                    if (live(2 * q + 1)) contract(&L.wt[0][0], 2 * q + 1, Bop[1], acc0, acc1);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + 16 * q + col] = acc0[r] + acc1[r];     // partial sum q of 2
+                    acc0 = zero4; acc1 = zero4;
+                    if (live(q)) contract(&L.st[0][0], q, Bop[2], acc0, acc1);
+                    if (col < 6) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + 36 + 6 * q + col] = acc0[r] + acc1[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int qd = 2; qd < 4; qd++) {
+                        f32x4 acc0 = zero4, acc1 = zero4;
+                        if (live(qd)) contract(&L.st[0][0], qd, Bop[0], acc0, acc1);
+                        if (col < 6) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + 36 + 6 * qd + col] = acc0[r] + acc1[r];
+                        }
+                    }
+                }
             } else if (active && (tt & 0xFFFFu) != 0) {
                 f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
                 const float* abase = (use_s ? &L.st[0][0] : &L.wt[0][0]);
@@ -631,7 +697,8 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 #pragma unroll
                             for (int h = 0; h < 2; h++) {
                                 const int rw = 2 * h + rr;
-                                const float v = F[rw * PL_FS + ch];
+                                float v = F[rw * PL_FS + ch];
+                                if (split16) v += F[rw * PL_FS + 16 + (ch & 15)];       // the other pair of quadrants
                                 const uint32_t gg = __float_as_uint(F[rw * PL_FS + GID_SLOT]);
                                 if (((m4 >> rw) & 1u) && ch < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + ch, v);
                             }

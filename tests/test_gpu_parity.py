@@ -287,7 +287,7 @@ def test_chunk_shapes_of_the_blend_backward_agree(C, option):
 
 @pytest.mark.parametrize("C", [0, 3, 16, 32, 48, 96, 200])
 def test_pixel_lane_and_instance_lane_backward_agree(C, option):
-    """Option bwd_pl (1: pixel-lane pass + all sums on the matrix pipe, render_bwd_pl.hip - the default from 17 channels on;
+    """Option bwd_pl (1: pixel-lane pass + all sums on the matrix pipe, render_bwd_pl.hip - the default from 5 channels on;
     0: instance-lane kernel, render_bwd.hip) changes only the order of the float sums: same gradients for no features, ragged channel counts, one
     and several channel windows."""
     from synth import make_scene
@@ -302,6 +302,28 @@ def test_pixel_lane_and_instance_lane_backward_agree(C, option):
         b = g0[k]
         scale = float(np.abs(b).max()) + 1e-30
         assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
+
+
+@pytest.mark.parametrize("C", [0, 3, 8, 16])
+def test_pixel_lane_backward_quadrant_split_for_up_to_16_channels(C, option):
+    """Option bwd_split16 (pixel-lane backward, up to 16 channels: the feature block split over waves 0 and 1 by quadrants - two
+    partial sums added in the flush - and the moment block over waves 0, 1 and 3) against the column-only split and against the
+    instance-lane kernel: same gradients up to the order of the float sums."""
+    from synth import make_scene
+    sc = make_scene(P=30000, C=C, width=333, height=208, seed=53)
+    option("bwd_pl", 1)
+    _, g1 = run_hip(sc)
+    option("bwd_split16", 0)
+    _, g2 = run_hip(sc)
+    option("bwd_pl", 0)
+    _, g0 = run_hip(sc)
+    for got in (g1, g2):
+        for k, a in got.items():
+            if a is None or a.size == 0:
+                continue
+            b = g0[k]
+            scale = float(np.abs(b).max()) + 1e-30
+            assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
 
 
 @pytest.mark.parametrize("name", ["fwd_solo", "fwd_wide", "bwd_order", "bwd_m44"])

@@ -15,7 +15,10 @@ from diff_gaussian_rasterization import _C
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 settings = sys.argv[3:] or [""]
-sc = make_scene(seed=0, **CONFIGS[cfg])
+kw = dict(CONFIGS[cfg.split("@")[0]])
+if "@" in cfg:          # "c2@8": config c2 with 8 feature channels
+    kw["C"] = int(cfg.split("@")[1])
+sc = make_scene(seed=0, **kw)
 dev = "cuda:0"
 t = lambda x: x.to(dev)
 st = dgr.GaussianRasterizationSettings(sc["image_height"], sc["image_width"], sc["tanfovx"], sc["tanfovy"], t(sc["bg"]), 1.0,
