@@ -799,6 +799,8 @@ void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, 
 // Channel windows: the first carries the geometric sums and up to 32 channels, later ones up to 64 channels.
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s) {
     a.neg_half_w = -(0.5f * a.W); a.neg_half_h = -(0.5f * a.H);
+    // (a 16-channel first window in the quadrant-split shape, where that does not add a window, was measured: c4 2.675 -> 2.668 ms,
+    // c5 4.65 -> 4.59 - the later window grows from 32 to 48 channels and takes a second staging round)
     a.c0 = 0; a.nc = min(32, C); a.write_base = 1;
     launch_pl<true>(a, s);
     for (int c0 = 32; c0 < C; c0 += 64) {
