@@ -63,6 +63,32 @@ __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* __rest
 // `tj` (first pass of the depth sort only): workgroup 0 also adds up the per-workgroup instance counts of
 // preprocess_kernel - both totals are known right after that kernel - and stores them to the device counters and
 // straight into the host's pinned read-back words: no totals launch and no copy launch in front of the sort.
+// `tj`: the per-workgroup instance counts of preprocess_kernel added up by ONE workgroup (all its THREADS threads call this) and
+// stored to the device counters and straight into the host's pinned read-back words.
+template <int THREADS>
+__device__ __forceinline__ void run_totals_job(const TotalsJob& tj) {
+    __shared__ uint32_t shc[2][THREADS / 64];
+    uint32_t v = 0, u = 0;
+    for (int i = threadIdx.x; i < tj.n_partial; i += THREADS) { v += tj.partial[i]; u += tj.partial[tj.n_partial + i]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        v += (uint32_t)__shfl_xor((int)v, d, 64);
+        u += (uint32_t)__shfl_xor((int)u, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { shc[0][threadIdx.x >> 6] = v; shc[1][threadIdx.x >> 6] = u; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ref = 0, own = 0;
+        for (int k = 0; k < THREADS / 64; k++) { ref += shc[0][k]; own += shc[1][k]; }
+        tj.counters[0] = own; tj.counters[1] = ref;      // [0] entries of our lists, [1] the reference's count
+        if (tj.host) {
+            __hip_atomic_store(&tj.host[0], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&tj.host[1], ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+        }
+    }
+}
+
 template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
                                                                   int shift, uint32_t nb,
@@ -70,28 +96,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t
     constexpr int BINS = 1 << BITS;
     constexpr int CHUNK = SORT_THREADS * ITEMS;
     __shared__ uint32_t h[BINS];
-    if (tj.partial && blockIdx.x == 0) {
-        __shared__ uint32_t shc[2][SORT_THREADS / 64];
-        uint32_t v = 0, u = 0;
-        for (int i = threadIdx.x; i < tj.n_partial; i += SORT_THREADS) { v += tj.partial[i]; u += tj.partial[tj.n_partial + i]; }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            v += (uint32_t)__shfl_xor((int)v, d, 64);
-            u += (uint32_t)__shfl_xor((int)u, d, 64);
-        }
-        if ((threadIdx.x & 63) == 0) { shc[0][threadIdx.x >> 6] = v; shc[1][threadIdx.x >> 6] = u; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t ref = 0, own = 0;
-            for (int k = 0; k < SORT_THREADS / 64; k++) { ref += shc[0][k]; own += shc[1][k]; }
-            tj.counters[0] = own; tj.counters[1] = ref;      // [0] entries of our lists, [1] the reference's count
-            if (tj.host) {
-                __hip_atomic_store(&tj.host[0], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&tj.host[1], ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __threadfence_system();
-            }
-        }
-    }
+    if (tj.partial && blockIdx.x == 0) run_totals_job<SORT_THREADS>(tj);
     for (int d = threadIdx.x; d < BINS; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * CHUNK;
@@ -425,6 +430,146 @@ void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, ui
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, s, in, gather, n, chunk_sums, sub);
 }
 
+// =====================================================================================================
+// Small problems (up to SMALL_SORT_MAX pairs: config c1, early training, inference on small scenes): the WHOLE stable sort in
+// one launch of one workgroup, resident in LDS.  A multi-launch pass costs ~20 us of dependent launches whatever the size (c1:
+// nine launches = 0.060 ms for 10,000 depth keys, three = 0.024 ms for 16,076 instances); here every 8-bit pass is: rank the
+// thread's 16 items per wave (the ballot match of radix_scatter_kernel, wave-ordered LDS counters), turn the 16 x 256 counters
+// into offsets, scatter the pairs into the LDS image, read them back in the new order - three barriers, no global round trip.
+// The pairs live in registers between passes; the LDS image is written out once at the end (with the tile ranges, RANGES).
+// (A first version of this idea - round 4, removed - ping-ponged the pairs through global memory behind fences: slower than the
+// launches it replaced.)
+constexpr int SMALL_SORT_MAX = 16384;
+constexpr int SMALL_SORT_THREADS = 1024;
+constexpr int SMALL_SORT_ITEMS = SMALL_SORT_MAX / SMALL_SORT_THREADS;     // 16
+struct SmallSortLds {
+    uint32_t key[SMALL_SORT_MAX];
+    uint32_t val[SMALL_SORT_MAX];
+    uint32_t cnt[SMALL_SORT_THREADS / 64][256];
+    uint32_t wsum[4];
+};
+template <bool RANGES>
+__global__ void __launch_bounds__(SMALL_SORT_THREADS)
+small_sort_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+                  uint32_t* __restrict__ vals_out, uint32_t n, int passes, TotalsJob tj, uint2* __restrict__ ranges_enc) {
+    extern __shared__ __attribute__((aligned(16))) char small_sort_smem[];
+    SmallSortLds& L = *reinterpret_cast<SmallSortLds*>(small_sort_smem);
+    constexpr int ITEMS = SMALL_SORT_ITEMS, NW = SMALL_SORT_THREADS / 64;
+    if (tj.partial) run_totals_job<SMALL_SORT_THREADS>(tj);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    volatile uint32_t* vcnt = &L.cnt[w][0];
+    // item order: wave w owns [64 steps w, 64 steps (w + 1)), visited in `steps` <= 16 steps of 64 consecutive items (lane = item
+    // within the step): the items are spread evenly over the sixteen waves, the unused steps of a small problem are skipped
+    const int steps = (int)((n + SMALL_SORT_THREADS - 1) / SMALL_SORT_THREADS);
+    const uint32_t wbase = (uint32_t)(w * steps * 64 + lane);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t i = wbase + (uint32_t)(k * 64);
+        const bool mine = k < steps && i < n;
+        key[k] = mine ? keys_in[i] : 0xFFFFFFFFu;
+        val[k] = (vals_in && mine) ? vals_in[i] : i;
+    }
+    for (int pass = 0; pass < passes; pass++) {
+        const int shift = 8 * pass;
+        for (int d = tid; d < NW * 256; d += SMALL_SORT_THREADS) (&L.cnt[0][0])[d] = 0;
+        __syncthreads();       // counters cleared; the previous pass's read-back is complete
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            if (k >= steps) break;
+            const uint32_t i = wbase + (uint32_t)(k * 64);
+            const bool valid = i < n;
+            const uint32_t d = (key[k] >> shift) & 255u;
+            const unsigned long long vm = __ballot(valid);
+            uint32_t p_lo = (uint32_t)vm, p_hi = (uint32_t)(vm >> 32);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const uint32_t x = 0u - ((d >> b) & 1u);
+                const unsigned long long nm = ~__ballot(x != 0u);
+                p_lo &= (uint32_t)nm ^ x;
+                p_hi &= (uint32_t)(nm >> 32) ^ x;
+            }
+            const unsigned long long peers = ((unsigned long long)p_hi << 32) | p_lo;
+            const uint32_t before = __popcll(peers & lt_mask);
+            const uint32_t old = vcnt[d];
+            if (valid && before == 0) vcnt[d] = old + (uint32_t)__popcll(peers);
+            rank[k] = old + before;
+        }
+        __syncthreads();
+        // digit d = tid (first 256 threads): total over the waves, exclusive scan over the digits, then per-wave offsets
+        {
+            uint32_t tot = 0;
+            if (tid < 256) {
+#pragma unroll
+                for (int ww = 0; ww < NW; ww++) tot += L.cnt[ww][tid];
+            }
+            uint32_t inc = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)inc, d, 64);
+                if (lane >= d) inc += v;
+            }
+            if (tid < 256 && lane == 63) L.wsum[w] = inc;
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t base = inc - tot;
+                for (int ww = 0; ww < w; ww++) base += L.wsum[ww];
+#pragma unroll
+                for (int ww = 0; ww < NW; ww++) {
+                    const uint32_t c = L.cnt[ww][tid];
+                    L.cnt[ww][tid] = base;
+                    base += c;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t i = wbase + (uint32_t)(k * 64);
+            if (k < steps && i < n) {
+                const uint32_t pos = L.cnt[w][(key[k] >> shift) & 255u] + rank[k];
+                L.key[pos] = key[k];
+                L.val[pos] = val[k];
+            }
+        }
+        __syncthreads();
+        if (pass + 1 < passes) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const uint32_t i = wbase + (uint32_t)(k * 64);
+                if (k < steps && i < n) { key[k] = L.key[i]; val[k] = L.val[i]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t j = (uint32_t)(k * SMALL_SORT_THREADS + tid);
+        if (j < n) {
+            const uint32_t kk = L.key[j];
+            if (keys_out) keys_out[j] = kk;
+            vals_out[j] = L.val[j];
+            if (RANGES) record_range(ranges_enc, kk, j == 0 || L.key[j - 1] != kk, j + 1 == n || L.key[j + 1] != kk, j);
+        }
+    }
+}
+
+// The LDS image is 144 KB: above the default limit, raised once per device (refused: the multi-launch passes take over).
+template <bool RANGES>
+bool small_sort_usable() {
+    constexpr int MAX_DEV = 64;
+    static int state[MAX_DEV];      // 0: not asked yet, 1: usable, -1: refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_sort_kernel<RANGES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallSortLds));
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : -1;
+    }
+    return state[dev] > 0;
+}
+
 // ITEMS = keys per thread: 8 for the depth sort (2048-key workgroups: P = 1M gives 489 workgroups, about two per CU;
 // with 16 there are fewer workgroups than CUs and every pass is one latency chain: 0.116 -> 0.097 ms at c3), 16 for
 // the tile sort (twice the instances, and the LDS reorder pays more on longer runs: 0.119 vs 0.128 ms with 8).
@@ -455,6 +600,21 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
     const int passes = (nbits + RADIX_BITS - 1) / RADIX_BITS;
     if (n == 0 || passes == 0) return;
     bool in_a = (passes % 2 == 0) ? result_in_a : !result_in_a;
+    if (n <= (size_t)SMALL_SORT_MAX && (ranges_enc ? small_sort_usable<true>() : small_sort_usable<false>())) {
+        // input where the caller put it for `passes` hops, result on the side it asked for - in one launch
+        const uint32_t* ki = in_a ? key_a : key_b;
+        const uint32_t* vi = in_a ? val_a : val_b;
+        uint32_t* ko = result_in_a ? key_a : key_b;
+        uint32_t* vo = result_in_a ? val_a : val_b;
+        const TotalsJob none = {nullptr, 0, nullptr, nullptr};
+        if (ranges_enc)
+            hipLaunchKernelGGL(small_sort_kernel<true>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, ki, vi, ko, vo,
+                               (uint32_t)n, passes, none, ranges_enc);
+        else
+            hipLaunchKernelGGL(small_sort_kernel<false>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, ki, vi, ko, vo,
+                               (uint32_t)n, passes, none, (uint2*)nullptr);
+        return;
+    }
     for (int p = 0; p < passes; p++) {
         uint32_t* ki = in_a ? key_a : key_b;
         uint32_t* vi = in_a ? val_a : val_b;
@@ -470,6 +630,11 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
 hipError_t launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
                              uint32_t* hist, const TotalsJob* tj, hipStream_t s) {
     if (n == 0) return hipSuccess;
+    if (n <= (size_t)SMALL_SORT_MAX && small_sort_usable<false>()) {
+        hipLaunchKernelGGL(small_sort_kernel<false>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, keys, (const uint32_t*)nullptr,
+                           key_a, val_a, (uint32_t)n, 4, tj ? *tj : TotalsJob{nullptr, 0, nullptr, nullptr}, (uint2*)nullptr);
+        return (tj && tj->ready) ? hipEventRecord(tj->ready, s) : hipSuccess;
+    }
     if (n > 200000) {
         // large P: four 8-bit passes are faster than three 11-bit ones (measured at 1M: 0.105 vs 0.148 ms);
         // small P is launch-bound and prefers fewer passes.  Result must end in (key_a, val_a): A <- keys, then
