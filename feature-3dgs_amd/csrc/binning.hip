@@ -554,6 +554,8 @@ small_sort_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restri
     }
 }
 
+__global__ void __launch_bounds__(256) totals_kernel(TotalsJob tj) { run_totals_job<256>(tj); }
+
 // The LDS image is 144 KB: above the default limit, raised once per device (refused: the multi-launch passes take over).
 template <bool RANGES>
 bool small_sort_usable() {
@@ -631,9 +633,16 @@ hipError_t launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* va
                              uint32_t* hist, const TotalsJob* tj, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (n <= (size_t)SMALL_SORT_MAX && small_sort_usable<false>()) {
+        // the totals the host waits for go out in a launch of their own, in FRONT of the sort: behind it the host would sit out the
+        // whole sort (0.04 ms) before it can enqueue the emit - and small scenes are bound by the host's enqueue time
+        hipError_t rc = hipSuccess;
+        if (tj && tj->partial) {
+            hipLaunchKernelGGL(totals_kernel, dim3(1), dim3(256), 0, s, *tj);
+            if (tj->ready) rc = hipEventRecord(tj->ready, s);
+        }
         hipLaunchKernelGGL(small_sort_kernel<false>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, keys, (const uint32_t*)nullptr,
-                           key_a, val_a, (uint32_t)n, 4, tj ? *tj : TotalsJob{nullptr, 0, nullptr, nullptr}, (uint2*)nullptr);
-        return (tj && tj->ready) ? hipEventRecord(tj->ready, s) : hipSuccess;
+                           key_a, val_a, (uint32_t)n, 4, TotalsJob{nullptr, 0, nullptr, nullptr}, (uint2*)nullptr);
+        return rc;
     }
     if (n > 200000) {
         // large P: four 8-bit passes are faster than three 11-bit ones (measured at 1M: 0.105 vs 0.148 ms);
