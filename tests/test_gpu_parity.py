@@ -57,7 +57,9 @@ def _read(lib, what, scene, res, dtype, count):
 
 
 @pytest.mark.parametrize("onesweep", [0, 1], ids=["three-kernel-passes", "single-pass-lookback"])
-@pytest.mark.parametrize("seed,P,W,H,C", [(1, 5000, 256, 256, 3), (2, 20000, 320, 200, 16), (3, 3000, 97, 61, 32)])
+@pytest.mark.parametrize("seed,P,W,H,C", [(1, 5000, 256, 256, 3), (2, 20000, 320, 200, 16), (3, 3000, 97, 61, 32),
+                                          # 16384 pairs is the largest problem the one-launch LDS-resident sort takes (binning.hip)
+                                          (4, 16384, 160, 96, 0), (5, 16385, 160, 96, 0), (6, 1000, 64, 48, 8)])
 def test_binning_is_bit_exact(seed, P, W, H, C, onesweep, option):
     option("tile_cull", 0)   # reference-identical instance lists
     option("sort_onesweep", onesweep)
