@@ -74,8 +74,11 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 // instance lists get shorter.  The count and the emission run the same code in this translation unit
 // (no contraction), so they always agree.
 // conditioning of the conic, clamped to [1, 1e6] (a NaN from a degenerate conic falls back to 1)
+// (The culling test is this library's own - the reference has none - and only has to be conservative and identical between the count
+// and the emission: its logarithm, square roots and reciprocals are the one-instruction approximations, ~1 ulp, far inside the
+// margins below; the IEEE sequences cost ~130 instructions per visible Gaussian.)
 __device__ __forceinline__ float cull_kappa(float ca, float cb, float cc) {
-    return fminf(fmaxf((ca * cc) / (ca * cc - cb * cb), 1.0f), 1e6f);
+    return fminf(fmaxf((ca * cc) * __builtin_amdgcn_rcpf(ca * cc - cb * cb), 1.0f), 1e6f);
 }
 struct CullParams {
     float mx, my, a, b, c, thresh;   // thresh = 2 * (ln(255 o) + margin); negative => never visible
@@ -88,7 +91,7 @@ __device__ __forceinline__ CullParams make_cull(float mx, float my, float ca, fl
     // large as kappa * thresh with kappa = a c / det >= 1 (thin splats at an angle: the terms cancel), so their round-off
     // is ~ eps * kappa * thresh.  The threshold is inflated by 32 eps kappa on top of the fixed margin: a needle-shaped
     // splat keeps every tile it could blend in.
-    k.thresh = s > 1.0f ? 2.0f * (logf(s) * 1.0001f + 1e-3f) * (1.0f + 2e-6f * cull_kappa(ca, cb, cc)) : -1.0f;
+    k.thresh = s > 1.0f ? 2.0f * (__logf(s) * 1.0001f + 1e-3f) * (1.0f + 2e-6f * cull_kappa(ca, cb, cc)) : -1.0f;
     return k;
 }
 __device__ __forceinline__ float quad_form(const CullParams& k, float dx, float dy) {
@@ -104,13 +107,13 @@ __device__ __forceinline__ float quad_form(const CullParams& k, float dx, float 
 __device__ __forceinline__ bool row_span(const CullParams& k, float det_inv, int ty, int x0, int x1, int& xa, int& xb) {
     if (k.thresh < 0.0f) return false;
     const float ylo = k.my - (float)(ty * TILE + TILE - 1), yhi = k.my - (float)(ty * TILE);   // dy = mean - pixel
-    const float ymax = sqrtf(fmaxf(0.0f, k.thresh * k.a * det_inv));
+    const float ymax = __builtin_amdgcn_sqrtf(fmaxf(0.0f, k.thresh * k.a * det_inv));
     const float lo = fmaxf(ylo, -ymax), hi = fminf(yhi, ymax);
     if (lo > hi + 1e-3f) return false;
-    const float X = sqrtf(fmaxf(0.0f, k.thresh * k.c * det_inv));      // half-width of the whole ellipse
-    const float ic = 1.0f / k.c, ia = 1.0f / k.a;
-    const float det = 1.0f / det_inv;
-    auto root = [&](float dy) { return sqrtf(fmaxf(0.0f, k.thresh * k.a - det * dy * dy)); };
+    const float X = __builtin_amdgcn_sqrtf(fmaxf(0.0f, k.thresh * k.c * det_inv));      // half-width of the whole ellipse
+    const float ic = __builtin_amdgcn_rcpf(k.c), ia = __builtin_amdgcn_rcpf(k.a);
+    const float det = __builtin_amdgcn_rcpf(det_inv);
+    auto root = [&](float dy) { return __builtin_amdgcn_sqrtf(fmaxf(0.0f, k.thresh * k.a - det * dy * dy)); };
     // right end: maximiser dy_r = -(b/c) X ; left end: minimiser dy_l = +(b/c) X
     const float dyr = fminf(hi, fmaxf(lo, -(k.b * ic) * X));
     const float dyl = fminf(hi, fmaxf(lo, (k.b * ic) * X));
@@ -353,7 +356,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         bbox_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
         if (cull) {
             const CullParams ck = make_cull(px, py, ca, cb, cc, opacity);
-            const float cdet_inv = 1.0f / (ca * cc - cb * cb);
+            const float cdet_inv = __builtin_amdgcn_rcpf(ca * cc - cb * cb);
             for (int ty = y0; ty < y1; ty++) {
                 int xa, xb;
                 if (row_span(ck, cdet_inv, ty, x0, x1, xa, xb)) out_tiles += (uint32_t)(xb - xa + 1);
@@ -438,7 +441,7 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
         int x0, y0, x1, y1;
         tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
         const CullParams ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-        const float cdet_inv = 1.0f / (q0.z * q1.x - q0.w * q0.w);
+        const float cdet_inv = __builtin_amdgcn_rcpf(q0.z * q1.x - q0.w * q0.w);
         for (int y = y0; y < y1; y++) {
             int xa = x0, xb = x1 - 1;
             if (cull && !row_span(ck, cdet_inv, y, x0, x1, xa, xb)) continue;
@@ -511,7 +514,7 @@ emit_scan_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __re
         int x0, y0, x1, y1;
         tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
         const CullParams ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-        const float cdet_inv = 1.0f / (q0.z * q1.x - q0.w * q0.w);
+        const float cdet_inv = __builtin_amdgcn_rcpf(q0.z * q1.x - q0.w * q0.w);
         for (int y = y0; y < y1; y++) {
             int xa = x0, xb = x1 - 1;
             if (cull && !row_span(ck, cdet_inv, y, x0, x1, xa, xb)) continue;
