@@ -118,6 +118,9 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: quadrant in phase 1, column block in phase 2
     const bool split16 = GEO && a.split16 && a.nc <= 16;      // wave-uniform: see the operand read-out below
+    // later windows of up to 32 channels (the last window of 64 + 32 or 3 x 64 + 32 remaining channels: two waves would idle): wave q
+    // takes channel block q & 1 at the quadrants 2 (q >> 1), 2 (q >> 1) + 1 - two partial sums per entry, added in the flush
+    const bool split32 = !GEO && a.split16 && a.nc <= 32;
     PL_PHASE_BEGIN();     // [0] staging  [1] window + barriers  [2] phase 1  [3] phase 2  [4] flush  [5] chunks  [6] entries
 
     // longest walks first: the launch is ~8 rounds of workgroups whose lifetimes differ by an order of magnitude, and a long
@@ -347,6 +350,15 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 #pragma unroll
                     for (int qd = 0; qd < 4; qd++) Bop[qd][t] = v;
                 }
+            } else if (split32) {
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const int qd = 2 * (q >> 1) + sl;
+                        const int px = (qd & 1) * 8 + 4 * (t & 1) + kk, py = (qd >> 1) * 8 + (t >> 1);
+                        Bop[sl][t] = stage[plane * PL_SP + py * 16 + px];       // plane = 16 (q & 1) + col (zero-filled beyond nc)
+                    }
             } else if (mine) {
 #pragma unroll
                 for (int qd = 0; qd < 4; qd++)
@@ -605,6 +617,29 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                         }
                     }
                 }
+            } else if (split32 && (tt & 0xFFFFu) != 0) {
+                const int lane2 = fresh_lane();
+                const int col = lane2 & 15, kk = lane2 >> 4;
+                const int rofs0 = kk * PL_ROW + (col ^ kk) * 4, rofs1 = rofs0 ^ 16;
+                const int fs_row0 = (4 * kk) * PL_FS;
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    const int qd = 2 * (q >> 1) + sl;
+                    if ((tt >> (16 + qd)) & 1u) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const float4 av = *reinterpret_cast<const float4*>(&L.wt[0][0] + ((u & 1) ? rofs1 : rofs0) + qd * PL_TILE + u * 4 * PL_ROW);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Bop[sl][4 * u + 0], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Bop[sl][4 * u + 1], acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Bop[sl][4 * u + 2], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Bop[sl][4 * u + 3], acc1, 0, 0, 0);
+                        }
+                    }
+                }
+                // partial sum q >> 1 of 2: slots 32 (q >> 1) + 16 (q & 1) + col
+#pragma unroll
+                for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + 32 * (q >> 1) + 16 * (q & 1) + col] = acc0[r] + acc1[r];
             } else if (active && (tt & 0xFFFFu) != 0) {
                 f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
                 const float* abase = (use_s ? &L.st[0][0] : &L.wt[0][0]);
@@ -710,7 +745,8 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                     } else if (!PL_DEV_SKIP(1)) {
 #pragma unroll
                         for (int rw = 0; rw < 4; rw++) {
-                            const float v = F[rw * PL_FS + lane];
+                            float v = F[rw * PL_FS + lane];
+                            if (split32) v += F[rw * PL_FS + 32 + (lane & 31)];     // the other pair of quadrants
                             const uint32_t gg = __float_as_uint(F[rw * PL_FS + GID_SLOT]);
                             if (((m4 >> rw) & 1u) && lane < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + lane, v);
                         }

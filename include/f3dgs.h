@@ -80,8 +80,9 @@ const char* f3dgs_last_error(void);
  *   "bwd_order"      blend backward: 1 (default) workgroups take the tiles longest walk first
  *   "bwd_m44"        pixel-lane blend backward: 1 (default) the colour / depth sums contract on 4 x 4 matrix blocks
  *                    (v_mfma_f32_4x4x1_16B_f32) instead of a 16-column block of which four are used
- *   "bwd_split16"    pixel-lane blend backward with up to 16 feature channels: 1 (default) the feature block and the moment block
- *                    are split over the four waves by quadrants (no wave without matrix work), 0 by columns only
+ *   "bwd_split16"    pixel-lane blend backward with up to 16 feature channels, and its later channel windows of up to 32: 1 (default)
+ *                    the column blocks are split over the four waves by quadrants as well (no wave without matrix work, partial
+ *                    sums added in the flush), 0 by columns only
  *   "fwd_wide"       blend forward: 1 (default) 128-channel windows where more than 64 channels remain
  *   "fwd_solo"       blend forward: 1 (default) one 64-thread workgroup per quadrant wave
  * Unknown names return F3DGS_ERR_INVALID_ARGUMENT.

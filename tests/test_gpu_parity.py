@@ -306,11 +306,12 @@ def test_pixel_lane_and_instance_lane_backward_agree(C, option):
         assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
 
 
-@pytest.mark.parametrize("C", [0, 3, 8, 16])
+@pytest.mark.parametrize("C", [0, 3, 8, 16, 48, 64, 128])
 def test_pixel_lane_backward_quadrant_split_for_up_to_16_channels(C, option):
     """Option bwd_split16 (pixel-lane backward, up to 16 channels: the feature block split over waves 0 and 1 by quadrants - two
-    partial sums added in the flush - and the moment block over waves 0, 1 and 3) against the column-only split and against the
-    instance-lane kernel: same gradients up to the order of the float sums."""
+    partial sums added in the flush - and the moment block over waves 0, 1 and 3; later channel windows of up to 32 channels - the
+    last window at C = 48, 64, 128: two channel blocks x two quadrant pairs on the four waves) against the column-only split and
+    against the instance-lane kernel: same gradients up to the order of the float sums."""
     from synth import make_scene
     sc = make_scene(P=30000, C=C, width=333, height=208, seed=53)
     option("bwd_pl", 1)
