@@ -79,6 +79,19 @@ def test_argument_validation_without_gpu():
     assert rc < 0 and b"P < 0" in lib.f3dgs_last_error()
     assert lib.f3dgs_mark_visible(0, None, None, None, None, None) == 0
     assert lib.f3dgs_mark_visible(5, None, None, None, None, None) < 0
+    # the low-resolution feature-map gradient: a thread-local setting, validated when it is made
+    lib.f3dgs_set_feature_grad_lowres.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    dummy = (ctypes.c_float * 4)()
+    assert lib.f3dgs_set_feature_grad_lowres(ctypes.addressof(dummy), 0, 4, None) < 0 and b"low-resolution" in lib.f3dgs_last_error()
+    assert lib.f3dgs_set_feature_grad_lowres(ctypes.addressof(dummy), 2, 2, None) == 0
+    assert lib.f3dgs_set_feature_grad_lowres(None, 0, 0, None) == 0            # clears it
+    # the fused loss: sizes and pointers are checked before anything is launched
+    lib.f3dgs_feature_l1.argtypes = [ctypes.c_int] * 6 + [ctypes.c_void_p] * 10
+    assert lib.f3dgs_feature_l1(0, 8, 8, 4, 4, 4, *([None] * 10)) < 0
+    assert lib.f3dgs_feature_l1(4, 8, 8, 4, 4, 4, *([None] * 10)) < 0 and b"null" in lib.f3dgs_last_error()
+    lib.f3dgs_feature_l1_lowres_grad.restype = ctypes.c_void_p
+    lib.f3dgs_feature_l1_lowres_grad.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    assert lib.f3dgs_feature_l1_lowres_grad(4, 4, 4, 4, 0, None) is None
 
 
 def test_python_surface_matches_reference():
