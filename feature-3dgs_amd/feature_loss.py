@@ -68,7 +68,7 @@ def fused_feature_l1(feature_map: torch.Tensor, gt_feature_map: torch.Tensor, we
     the image along an axis the dense path is taken."""
     e = torch.Tensor([])
     lowres = 0
-    if lowres_grad:
+    if lowres_grad and feature_map.requires_grad:       # (nothing to hand over where no gradient is asked for: evaluation)
         fn = feature_map.grad_fn
         lowres = getattr(feature_map, "_f3dgs_call", 0)
         if fn is None or "_RasterizeGaussians" not in fn.name() or not lowres:
