@@ -225,6 +225,9 @@ def test_lowres_feature_gradient_goes_to_the_call_that_rendered_the_map():
     _c, feat_a, _r, _d = render(scA, fa)
     with pytest.raises(ValueError):
         fused_feature_l1(feat_a * 1.0, gt, lowres_grad=True)
+    # a map that needs no gradient (evaluation): nothing to hand over, the plain path, the same loss
+    l_eval = fused_feature_l1(feat_a.detach(), gt, lowres_grad=True)
+    assert float(l_eval) == float(fused_feature_l1(feat_a.detach(), gt))
     big = torch.randn(32, 200, 300, device=dev)          # enlarging: dense path, still the right numbers
     fused_feature_l1(feat_a, big, lowres_grad=True).backward()
     g_low = fa.grad.clone()
