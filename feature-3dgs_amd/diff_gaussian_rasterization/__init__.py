@@ -15,6 +15,8 @@ non-HIP tensors.
 """
 from __future__ import annotations
 
+import itertools
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -63,13 +65,14 @@ def set_feature_grad_accumulator(buffer: Optional[torch.Tensor]) -> None:
 
 
 _lowres_offers = {}     # serial number of a rasterizer call -> (gx, scale): see feature_loss.py, lowres_grad=True
-_call_serial = 0        # every forward call gets one; its feature_map output carries it as `_f3dgs_call`
+_call_serial = itertools.count(1)   # every forward call gets one; its feature_map output carries it as `_f3dgs_call`
+_tls = threading.local()            # .serial: the one the forward call of THIS thread just took
 
 
 def _offer_feature_grad_lowres(call_serial: int, gx: torch.Tensor, scale: Optional[torch.Tensor]) -> None:
     """The fused feature loss leaves its gradient at the loss's resolution for the backward call of rasterizer call
     `call_serial` (the `_f3dgs_call` attribute of its feature_map output; feature_loss.fused_feature_l1, lowres_grad=True)."""
-    while len(_lowres_offers) >= 8:      # offers nobody came for (a backward pass that raised): drop the oldest
+    while len(_lowres_offers) >= 4096:   # offers nobody came for (backward passes that raised): drop the oldest
         _lowres_offers.pop(next(iter(_lowres_offers)))
     _lowres_offers[call_serial] = (gx, scale)
 
@@ -123,9 +126,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # undefined upstream gradients arrive as None instead of zero tensors: `radii` is an integer output, autograd would
         # otherwise fill a (P,) int32 zero tensor for it in front of every backward call (one launch for nothing)
         ctx.set_materialize_grads(False)
-        global _call_serial
-        _call_serial += 1
-        ctx.call_serial = _call_serial
+        ctx.call_serial = _tls.serial = next(_call_serial)
         ctx.save_for_backward(colors_precomp, semantic_feature, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer)
         return color, feature_map, radii, depth
@@ -171,7 +172,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantic_feature, 
                         cov3Ds_precomp, raster_settings):
     out = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantic_feature, opacities, scales,
                                     rotations, cov3Ds_precomp, raster_settings)
-    out[1]._f3dgs_call = _call_serial       # which call rendered this feature map (fused_feature_l1, lowres_grad=True)
+    out[1]._f3dgs_call = _tls.serial        # which call rendered this feature map (fused_feature_l1, lowres_grad=True)
     return out
 
 
