@@ -113,3 +113,33 @@ def test_empty_input(oracle_lib):
     _, out, g = run_oracle(sc)
     assert out["num_rendered"] == 0 and out["color"].shape == (3, 32, 32) and float(np.abs(out["color"]).max()) == 0
     assert g["dL_dmeans3D"].shape == (0, 3)
+
+
+def test_adjudicator_tile_subset_and_threshold_variants_match_the_full_evaluation():
+    """tests/adjudicate.py asks the fp64 torch oracle about a handful of tiles under five positions of the two blend thresholds.
+    Pin that machinery on CPU: (1) restricted to a subset of tiles it returns, inside those tiles, exactly what the full-image
+    evaluation returns (and the gradients of a Gaussian whose footprint lies inside the subset are complete); (2) variant 0 of a
+    `variants` call is the nominal evaluation; (3) moving the thresholds by 2e-4 relative changes only a few pixels - by a lot at
+    a pixel that holds a borderline decision, by nothing elsewhere."""
+    from oracle import torch_oracle
+    from synth import make_scene
+    sc = make_scene(P=600, C=5, width=64, height=48, seed=17, scale_lo=0.02, scale_hi=0.2)
+    gx = (64 + 15) // 16
+    full = torch_oracle.forward_backward(sc, want_grads=False)["out"]
+    tiles = [1, 5, 6, 10]
+    sub = torch_oracle.forward_backward(sc, want_grads=False, tiles=tiles)["out"]
+    for t in tiles:
+        ty, tx = divmod(t, gx)
+        ys, xs = slice(16 * ty, min(48, 16 * ty + 16)), slice(16 * tx, min(64, 16 * tx + 16))
+        for k in ("color", "feature_map", "depth"):
+            assert torch.equal(sub[k][:, ys, xs], full[k][:, ys, xs]), (k, t)
+        assert torch.equal(sub["final_T"][ys, xs], full["final_T"][ys, xs])
+    nominal = (1.0 / 255.0, 1e-4)
+    moved = (1.0 / 255.0 * (1 + 2e-4), 1e-4 * (1 - 2e-4))
+    var = torch_oracle.forward_backward(sc, want_grads=False, tiles=tiles, variants=[nominal, moved])["out"]["variants"]
+    for k in ("color", "feature_map", "depth"):
+        assert torch.equal(var[0][k], sub[k]), k
+    changed = (var[1]["color"] != var[0]["color"]).any(0)
+    assert int(changed.sum()) <= 8            # a threshold moved by 2e-4 decides differently at a few pixels at most
+    same = ~changed
+    assert torch.equal(var[1]["feature_map"][:, same], var[0]["feature_map"][:, same])
