@@ -118,9 +118,10 @@ def test_empty_input(oracle_lib):
 def test_adjudicator_tile_subset_and_threshold_variants_match_the_full_evaluation():
     """tests/adjudicate.py asks the fp64 torch oracle about a handful of tiles under five positions of the two blend thresholds.
     Pin that machinery on CPU: (1) restricted to a subset of tiles it returns, inside those tiles, exactly what the full-image
-    evaluation returns (and the gradients of a Gaussian whose footprint lies inside the subset are complete); (2) variant 0 of a
+    evaluation returns; (2) variant 0 of a
     `variants` call is the nominal evaluation; (3) moving the thresholds by 2e-4 relative changes only a few pixels - by a lot at
-    a pixel that holds a borderline decision, by nothing elsewhere."""
+    a pixel that holds a borderline decision, by nothing elsewhere; (4) the gradients of a tile-restricted run are those of the
+    full image with the upstream gradients masked to the tiles."""
     from oracle import torch_oracle
     from synth import make_scene
     sc = make_scene(P=600, C=5, width=64, height=48, seed=17, scale_lo=0.02, scale_hi=0.2)
@@ -143,3 +144,12 @@ def test_adjudicator_tile_subset_and_threshold_variants_match_the_full_evaluatio
     assert int(changed.sum()) <= 8            # a threshold moved by 2e-4 decides differently at a few pixels at most
     same = ~changed
     assert torch.equal(var[1]["feature_map"][:, same], var[0]["feature_map"][:, same])
+    mask = torch.zeros(48, 64, dtype=torch.bool)
+    for t in tiles:
+        ty, tx = divmod(t, gx)
+        mask[16 * ty:16 * ty + 16, 16 * tx:16 * tx + 16] = True
+    up = (sc["dL_dcolor"], sc["dL_dfeature"], sc["dL_ddepth"])
+    g_sub = torch_oracle.forward_backward(sc, tiles=tiles, upstream=up)["grads"]
+    g_full = torch_oracle.forward_backward(sc, upstream=tuple(u * mask for u in up))["grads"]
+    for k, want in g_full.items():
+        assert torch.allclose(g_sub[k], want, rtol=1e-12, atol=1e-15 * float(want.abs().max() + 1)), k
