@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -202,6 +203,14 @@ const OptionDesc kOptions[] = {
 #endif
 };
 
+// The per-Gaussian kernels read rotations, SH rows and feature rows - and write their gradients - with 16-byte accesses
+// (include/f3dgs.h, "Alignment"): a base pointer off a 16-byte boundary is refused here instead of faulting in a kernel.
+bool misaligned16(std::initializer_list<const void*> ptrs) {
+    uintptr_t bits = 0;
+    for (const void* p : ptrs) bits |= reinterpret_cast<uintptr_t>(p);
+    return (bits & 15) != 0;
+}
+
 int tile_bits(int tiles) {
     int b = 0;
     while ((1 << b) < tiles) b++;
@@ -358,6 +367,8 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     if (C > 0 && !semantic_feature) return fail(F3DGS_ERR_INVALID_ARGUMENT, "semantic_feature is null but C > 0");
     if (shs && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
         return fail(F3DGS_ERR_INVALID_ARGUMENT, "SH degree %d needs %d coefficients, M = %d", D, (D + 1) * (D + 1), M);
+    if (misaligned16({shs, rotations, semantic_feature}))
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "shs, rotations and semantic_feature must be 16-byte aligned (f3dgs.h, Alignment)");
 
     int rc = F3DGS_OK;
     ViewParams vp;
@@ -479,13 +490,15 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)semantic_feature;  // Q3: never read by the reference's backward either
     (void)colors_precomp;    // colours were copied into the splat records by the forward pass
+    // f3dgs.h: a low-resolution gradient set by f3dgs_set_feature_grad_lowres is consumed by THIS call whatever it returns -
+    // taken before the first return, so that a pointer the caller may free after a failed or empty call never stays armed
+    const LowresGrad lowres = g_lowres;
+    g_lowres = LowresGrad();
     if (P < 0 || C < 0 || R < 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "bad sizes");
     if (P == 0) return F3DGS_OK;
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
         return fail(F3DGS_ERR_INVALID_ARGUMENT, "null state buffer");
     if (!radii) return fail(F3DGS_ERR_INVALID_ARGUMENT, "radii is required");
-    const LowresGrad lowres = g_lowres;      // one call only, whatever happens below
-    g_lowres = LowresGrad();
     if (lowres.gx) {
         if (C == 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "a low-resolution feature-map gradient was set but C = 0");
         if (lowres.Hg > height || lowres.Wg > width)
@@ -500,6 +513,9 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     if (M > 0 && shs && !dL_dsh) return fail(F3DGS_ERR_INVALID_ARGUMENT, "dL_dsh is null");
     if (scales && (!dL_dscale || !dL_drot || !rotations)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "scale/rot grads null");
     if (!scratch) return fail(F3DGS_ERR_INVALID_ARGUMENT, "scratch is null");
+    if (misaligned16({shs, rotations, dL_dsh, dL_drot, dL_dconic, dL_dsemantic_feature, scratch}))
+        return fail(F3DGS_ERR_INVALID_ARGUMENT, "shs, rotations, dL_dsh, dL_drot, dL_dconic, dL_dsemantic_feature and scratch must be "
+                    "16-byte aligned (f3dgs.h, Alignment)");
 
     int rc = F3DGS_OK;
     ViewParams vp;

@@ -46,7 +46,11 @@ torch::Tensor dev_f32(const torch::Tensor& t, const char* name) {
     if (t.numel() == 0) return t;
     TORCH_CHECK(t.is_cuda(), name, " must live on a HIP device (got ", t.device(), "): the MI355X rasterizer has no CPU path");
     TORCH_CHECK(t.scalar_type() == torch::kFloat32, name, " must be float32");
-    return t.contiguous();
+    torch::Tensor c = t.contiguous();
+    // the library reads rows with 16-byte accesses (f3dgs.h, Alignment): a view at an odd storage offset is copied into a fresh
+    // (allocator-aligned) tensor instead of being refused - the reference accepts such views
+    if (reinterpret_cast<uintptr_t>(c.data_ptr()) & 15) c = c.clone();
+    return c;
 }
 
 // The kernels index the feature tensor as (P, C): the reference's layout is (P, 1, C) (scene/gaussian_model.py:

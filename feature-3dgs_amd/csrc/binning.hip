@@ -16,6 +16,7 @@
 // Radix pass = 3 launches: per-workgroup digit histogram, per-digit row scan (grid = 256),
 // stable scatter (wave-level match with ballots, wave-ordered LDS counters).
 
+#include <atomic>
 #include "common.h"
 #include "lookback.h"
 
@@ -560,16 +561,16 @@ __global__ void __launch_bounds__(256) totals_kernel(TotalsJob tj) { run_totals_
 template <bool RANGES>
 bool small_sort_usable() {
     constexpr int MAX_DEV = 64;
-    static int state[MAX_DEV];      // 0: not asked yet, 1: usable, -1: refused
+    static std::atomic<int> state[MAX_DEV];      // 0: not asked yet, 1: usable, -1: refused (the ABI is re-entrant across threads)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
-    if (state[dev] == 0) {
+    if (state[dev].load(std::memory_order_acquire) == 0) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_sort_kernel<RANGES>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallSortLds));
         if (e != hipSuccess) (void)hipGetLastError();
-        state[dev] = e == hipSuccess ? 1 : -1;
+        state[dev].store(e == hipSuccess ? 1 : -1, std::memory_order_release);
     }
-    return state[dev] > 0;
+    return state[dev].load(std::memory_order_acquire) > 0;
 }
 
 // ITEMS = keys per thread: 8 for the depth sort (2048-key workgroups: P = 1M gives 489 workgroups, about two per CU;

@@ -237,8 +237,11 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 if (items > 0) {
                     const float gsc = a.gscale ? *a.gscale : 1.0f;
                     // (32-bit element offsets: the caller has checked gHg gWg C < 2^31)
-                    const uint32_t ch = (uint32_t)fresh_lane() & 31u;
-                    const bool ch_ok = 32 * rd + (int)ch < a.nc;
+                    const uint32_t ch_lane = (uint32_t)fresh_lane() & 31u;
+                    const bool ch_ok = 32 * rd + (int)ch_lane < a.nc;
+                    // a lane beyond the window's last channel re-reads channel 0 and drops the value: no read past the
+                    // documented Hg Wg C floats of the caller's buffer when the last window is not a multiple of 32 channels
+                    const uint32_t ch = ch_ok ? ch_lane : 0u;
                     const float* const gbase = a.glow + a.c0 + 32 * rd;
                     const uint32_t C_ = (uint32_t)a.C, Wg_ = (uint32_t)a.gWg;
                     const uint32_t inv = (65536u + (uint32_t)ncol - 1u) / (uint32_t)ncol;      // i / ncol = (i inv) >> 16 for i < 256
@@ -269,7 +272,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                             float r2 = fmaf(wx0[u], v[u][2], 0.f);
                             r2 = wx1[u] != 0.f ? fmaf(wx1[u], v[u][3], r2) : r2;
                             acc = wy1[u] != 0.f ? fmaf(wy1[u], r2, acc) : acc;
-                            if (live[u]) stage[ch * PL_SP + sp[u]] += a.gscale ? acc * gsc : acc;
+                            if (live[u]) stage[ch_lane * PL_SP + sp[u]] += a.gscale ? acc * gsc : acc;
                         }
                     }
                 }

@@ -15,6 +15,7 @@
 //     wave as soon as all of its pixels are saturated;
 //   * channels beyond CH are handled by re-walking the list per 64-channel window.
 
+#include <atomic>
 #include <cstddef>
 
 #include "render_common.h"
@@ -621,16 +622,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 template <bool BASE>
 bool wide_shape_usable() {
     constexpr int MAX_DEV = 64;
-    static int state[MAX_DEV];      // 0: not asked yet, 1: usable, -1: refused
+    static std::atomic<int> state[MAX_DEV];      // 0: not asked yet, 1: usable, -1: refused (the ABI is re-entrant across threads)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
-    if (state[dev] == 0) {
+    if (state[dev].load(std::memory_order_acquire) == 0) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_forward_mfma_kernel_w2<128, BASE>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(FwdChunkMF<128, 32>)));
         if (e != hipSuccess) (void)hipGetLastError();     // not sticky: the narrower windows take over
-        state[dev] = e == hipSuccess ? 1 : -1;
+        state[dev].store(e == hipSuccess ? 1 : -1, std::memory_order_release);
     }
-    return state[dev] > 0;
+    return state[dev].load(std::memory_order_acquire) > 0;
 }
 
 template <int CH, bool BASE>

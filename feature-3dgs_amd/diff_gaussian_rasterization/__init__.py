@@ -56,23 +56,51 @@ def set_grad_rows_hook(on_rows, chunks: int = 4, on_done=None) -> None:
     _rows_done_hook = on_done if on_rows is not None else None
 
 
-def set_feature_grad_accumulator(buffer: Optional[torch.Tensor]) -> None:
+_accum_leaf = None       # (data_ptr, numel) of the leaf whose .grad the accumulator is, or None: not checked
+
+
+def set_feature_grad_accumulator(buffer: Optional[torch.Tensor], leaf: Optional[torch.Tensor] = None) -> None:
     """Several views per optimiser step (not in the reference): while `buffer` - a contiguous float32 tensor with the P x C
     elements of `semantic_feature`, normally the leaf's zero-initialised `.grad` - is set, every backward call ADDS its
     feature gradient into it (no per-view gradient tensor, zero-fill or add) and reports no gradient for `semantic_feature`
-    to autograd.  The feature-gradient hook then sees the running sum.  `None` restores the default.  See dp.py: dp_step_views."""
+    to autograd.  The feature-gradient hook then sees the running sum.  `None` restores the default.  See dp.py: dp_step_views.
+
+    The op's gradient goes straight into `buffer`, past the autograd chain: that is only right when the op's
+    `semantic_feature` input IS the tensor `buffer` is the gradient of.  Pass that tensor as `leaf` and every backward call
+    checks it (same storage, and an autograd leaf at forward time); a transformed, masked or copied feature tensor then
+    raises instead of silently receiving nothing."""
+    global _accum_leaf
+    _accum_leaf = None if (buffer is None or leaf is None) else (leaf.data_ptr(), leaf.numel())
     _C.set_feature_grad_accumulator(buffer)
 
 
 _lowres_offers = {}     # serial number of a rasterizer call -> (gx, scale): see feature_loss.py, lowres_grad=True
+_lowres_claims = {}     # serial numbers of the rasterizer calls a lowres_grad loss has been attached to (at most ONE per call)
 _call_serial = itertools.count(1)   # every forward call gets one; its feature_map output carries it as `_f3dgs_call`
 _tls = threading.local()            # .serial: the one the forward call of THIS thread just took
+
+
+def _claim_feature_grad_lowres(call_serial: int) -> bool:
+    """The hand-over beside autograd has ONE slot per rasterizer call: the first lowres_grad loss on a feature map takes it
+    (True); a second loss on the same map (multi-scale, two ground truths) gets False and must take the dense path, whose
+    gradient autograd adds the normal way (the blend backward adds both)."""
+    if call_serial in _lowres_claims:
+        return False
+    while len(_lowres_claims) >= 4096:
+        _lowres_claims.pop(next(iter(_lowres_claims)))
+    _lowres_claims[call_serial] = True
+    return True
 
 
 def _offer_feature_grad_lowres(call_serial: int, gx: torch.Tensor, scale: Optional[torch.Tensor]) -> None:
     """The fused feature loss leaves its gradient at the loss's resolution for the backward call of rasterizer call
     `call_serial` (the `_f3dgs_call` attribute of its feature_map output; feature_loss.fused_feature_l1, lowres_grad=True)."""
-    while len(_lowres_offers) >= 4096:   # offers nobody came for (backward passes that raised): drop the oldest
+    if call_serial in _lowres_offers:
+        # (cannot happen through fused_feature_l1, which lets one loss per render claim the slot; a silent overwrite would
+        # lose the first loss's gradient without any error)
+        raise RuntimeError("a low-resolution feature-map gradient is already waiting for this rasterizer call: at most one "
+                           "lowres_grad loss per render")
+    while len(_lowres_offers) >= 64:   # offers nobody came for (backward passes that raised) pin their loss scratch: drop the oldest
         _lowres_offers.pop(next(iter(_lowres_offers)))
     _lowres_offers[call_serial] = (gx, scale)
 
@@ -127,6 +155,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # otherwise fill a (P,) int32 zero tensor for it in front of every backward call (one launch for nothing)
         ctx.set_materialize_grads(False)
         ctx.call_serial = _tls.serial = next(_call_serial)
+        ctx.feat_src = (semantic_feature.data_ptr(), semantic_feature.numel(), bool(semantic_feature.is_leaf))
         ctx.save_for_backward(colors_precomp, semantic_feature, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer)
         return color, feature_map, radii, depth
@@ -147,6 +176,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color,
                 grad_out_feature, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
                 binningBuffer, imgBuffer, rs.debug)
+        if _accum_leaf is not None and semantic_feature.numel() != 0 and (
+                ctx.feat_src[:2] != _accum_leaf or not ctx.feat_src[2]):
+            raise RuntimeError("set_feature_grad_accumulator(buffer, leaf): this op's semantic_feature input is not that leaf "
+                               "(a transformed, masked or copied tensor?) - adding the op's gradient into leaf.grad would skip "
+                               "the autograd chain between them; use accumulate=False / remove the accumulator")
         offer = _lowres_offers.pop(ctx.call_serial, None)
         if offer is not None:       # this call's feature-map gradient (or part of it) waits at the loss's resolution
             _C.set_feature_grad_lowres(offer[0], offer[1])

@@ -440,12 +440,6 @@ _stream_pool: Dict[tuple, list] = {}
 def _side_streams(device, n: int) -> list:
     key = (device.type, device.index)
     pool = _stream_pool.setdefault(key, [])
-    if not pool:
-        # The leaves were created on the caller's stream and their gradients now arrive from these streams: intended (the
-        # backward passes are ordered among themselves with events, and the caller's stream waits for the last of them).
-        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-        if quiet is not None:
-            quiet(False)
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
@@ -491,11 +485,21 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
         if not (have_feat and feat.is_contiguous()):
             raise ValueError("accumulate=True needs a contiguous feature leaf")
         feat.grad = torch.zeros_like(feat)
-        dgr.set_feature_grad_accumulator(feat.grad)
+        # (`leaf=feat`: every backward call checks that the op's feature input IS this leaf - a model that feeds the op a
+        # transformed / masked / copied feature tensor gets an error instead of a gradient that skipped its autograd chain)
+        dgr.set_feature_grad_accumulator(feat.grad, feat)
     active = _active(group)
     ov = None
+    # The leaves were created on the caller's stream and their gradients arrive from the side streams below: intended (the
+    # backward passes are ordered among themselves with events, and the caller's stream waits for the last of them) - the
+    # warning about it is silenced for the duration of this step only.
+    quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    pipelined = on_gpu and V > 1 and n_streams >= 2
+    if not pipelined:
+        quiet = None
     try:
-        pipelined = on_gpu and V > 1 and n_streams >= 2
+        if quiet is not None:
+            quiet(False)
         if pipelined:
             main = torch.cuda.current_stream(dev)
             pool = _side_streams(dev, n_streams)
@@ -533,6 +537,8 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
                 else:
                     backward(handle)
     finally:
+        if quiet is not None:
+            quiet(True)
         if accumulate:
             dgr.set_feature_grad_accumulator(None)
     # the SAME key list on every rank (see dp_step)

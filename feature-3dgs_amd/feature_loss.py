@@ -65,7 +65,11 @@ def fused_feature_l1(feature_map: torch.Tensor, gt_feature_map: torch.Tensor, we
 
     lowres_grad=True: `feature_map` must be the feature map exactly as `GaussianRasterizer` returned it (not a view or a copy:
     the gradient reaches that call's backward beside autograd; ValueError otherwise).  Where the ground truth is larger than
-    the image along an axis the dense path is taken."""
+    the image along an axis the dense path is taken.  The hand-over has ONE slot per render: the first lowres_grad loss on a
+    feature map takes it, any further loss on the same map (multi-scale, a second ground truth) takes the dense path by
+    itself - the sum of the gradients is the same.  Because the gradient travels beside autograd,
+    `torch.autograd.grad(loss, feature_map)` / `feature_map.retain_grad()` see a zero placeholder for a lowres_grad loss, not
+    the gradient: use lowres_grad=False where the feature map's own gradient is wanted."""
     e = torch.Tensor([])
     lowres = 0
     if lowres_grad and feature_map.requires_grad:       # (nothing to hand over where no gradient is asked for: evaluation)
@@ -77,6 +81,10 @@ def fused_feature_l1(feature_map: torch.Tensor, gt_feature_map: torch.Tensor, we
                              f"{fn.name() if fn is not None else 'no autograd node'}")
         if not (gt_feature_map.shape[-2] <= feature_map.shape[-2] and gt_feature_map.shape[-1] <= feature_map.shape[-1]):
             lowres = 0
+        if lowres:
+            import diff_gaussian_rasterization as dgr
+            if not dgr._claim_feature_grad_lowres(lowres):      # a second loss on this render: dense path
+                lowres = 0
     if weight is None:
         return _FusedFeatureL1.apply(feature_map, gt_feature_map, e, e, lowres)
     w2 = weight.reshape(weight.shape[0], -1)

@@ -29,6 +29,15 @@
  *     caller may pass uninitialised memory (the reference requires zeroed
  *     buffers, rasterize_points.cu:163-173).
  *
+ * Alignment: the per-Gaussian kernels read rotations, SH rows and feature
+ * rows, and write their gradients, with 16-byte accesses.  `shs`,
+ * `rotations`, `semantic_feature`, `dL_dsh`, `dL_drot`, `dL_dconic`,
+ * `dL_dsemantic_feature` and `scratch` must therefore be 16-byte aligned
+ * (hipMalloc and torch allocations are; a view at an odd storage offset is
+ * not).  f3dgs_forward / f3dgs_backward return F3DGS_ERR_INVALID_ARGUMENT for
+ * a misaligned pointer; the torch binding copies such a view first.  Image
+ * planes may have any alignment (aligned ones take the vector path).
+ *
  * Status codes: 0 = ok, negative = error; f3dgs_last_error() returns a
  * thread-local human-readable message for the last failing call.
  */
@@ -245,7 +254,8 @@ const float* f3dgs_feature_l1_lowres_grad(int C, int Cout, int Hg, int Wg, int h
  * there (same products, same order: bit-identical to the dense path) - it reads Hg*Wg*C floats instead of H*W*C.
  * dL_dfeaturepix of that call may be NULL; if it is not, the two are added.  Needs Hg <= H and Wg <= W (shrinking: at
  * most two output samples per source row / column) and option feature_mfma = 1, else the call returns
- * F3DGS_ERR_UNSUPPORTED.  The setting is consumed by that call whatever it returns; gx == NULL clears it.
+ * F3DGS_ERR_UNSUPPORTED.  The setting is consumed by that call whatever it returns - including its early returns (P == 0,
+ * an argument error) -; gx == NULL clears it.  The kernel reads exactly the Hg*Wg*C floats of `gx`, nothing beyond them.
  */
 int f3dgs_set_feature_grad_lowres(const float* gx, int Hg, int Wg, const float* scale);
 

@@ -36,13 +36,13 @@ REF = "/root/reference/submodules/diff-gaussian-rasterization-feature"
 OUT = os.path.join(HERE, "_ref")
 HIPIFY = "/opt/rocm/bin/hipify-perl"
 HIPCC = "/opt/rocm/bin/hipcc"
-DEFAULT_CHANNELS = (3, 16, 32, 64, 128, 256)
+DEFAULT_CHANNELS = (3, 16, 32, 64, 128, 256, 512)     # 512: the LSeg width of the reference's README (:330)
 # A second flavour `_refC<n>s` of the same sources built with `-ffp-contract=off`: the product's preprocess kernel is
 # built without FMA contraction (so that it agrees bit-for-bit with the C++ oracle), the default flavour above with the
 # compiler's default contraction, as nvcc builds the reference.  Integer artefacts (radii, tile counts, num_rendered)
 # are asserted EXACTLY equal against the strict flavour at the full BASELINE sizes (tests/test_gpu_vs_ref.py); what
 # is left against the contracted flavour is then a documented property of the checker's build, not of the product.
-STRICT_CHANNELS = (3, 16, 32, 64, 128, 256)
+STRICT_CHANNELS = (3, 16, 32, 64, 128, 256, 512)
 
 FILES = [
     "cuda_rasterizer/auxiliary.h", "cuda_rasterizer/backward.cu", "cuda_rasterizer/backward.h",

@@ -236,3 +236,51 @@ def test_lowres_feature_gradient_goes_to_the_call_that_rendered_the_map():
     fused_feature_l1(feat_a, big, lowres_grad=False).backward()
     torch.cuda.synchronize()
     assert float((g_low - fa.grad).abs().max()) <= 2e-5 * float(fa.grad.abs().max())
+
+
+@pytest.mark.gpu
+def test_two_lowres_losses_on_one_feature_map_add_up():
+    """two `fused_feature_l1(..., lowres_grad=True)` losses on the SAME rendered map (multi-scale, two
+    ground truths).  The hand-over beside autograd has one slot per render: the first loss takes it, the second takes the
+    dense path by itself and the blend backward adds both - the leaf gradient is the sum, as with two dense losses.  (Until
+    round 5 the second offer silently replaced the first.)  A direct second offer for one call raises."""
+    import diff_gaussian_rasterization as dgr
+    from feature_loss import fused_feature_l1
+    from synth import make_scene
+    dev = "cuda:0"
+    t = lambda x: x.to(dev)
+    sc = make_scene(P=8000, C=32, width=160, height=96, seed=5)
+    g = torch.Generator().manual_seed(2)
+    gt1, gt2 = torch.randn(32, 30, 50, generator=g).to(dev), torch.randn(32, 48, 80, generator=g).to(dev)
+
+    def render(feat_leaf):
+        P = sc["means3D"].shape[0]
+        st = dgr.GaussianRasterizationSettings(sc["image_height"], sc["image_width"], sc["tanfovx"], sc["tanfovy"], t(sc["bg"]),
+                                               sc["scale_modifier"], t(sc["viewmatrix"]), t(sc["projmatrix"]), sc["sh_degree"],
+                                               t(sc["campos"]), False, False)
+        return dgr.GaussianRasterizer(st)(means3D=t(sc["means3D"]), means2D=torch.zeros(P, 3, device=dev), opacities=t(sc["opacities"]),
+                                          shs=t(sc["shs"]), semantic_feature=feat_leaf, scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+
+    grads, losses = {}, {}
+    for lowres in (False, True):
+        f = t(sc["semantic_feature"]).clone().requires_grad_(True)
+        _c, feat, _r, _d = render(f)
+        loss = fused_feature_l1(feat, gt1, lowres_grad=lowres) + 0.5 * fused_feature_l1(feat, gt2, lowres_grad=lowres)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[lowres], losses[lowres] = f.grad.cpu().numpy(), float(loss)
+        assert not dgr._lowres_offers
+    assert losses[True] == losses[False]
+    scale = float(np.abs(grads[False]).max())
+    assert scale > 0 and float(np.abs(grads[True] - grads[False]).max()) <= 2e-5 * scale
+    # each loss alone gives a different gradient: the sum above really contains both
+    f = t(sc["semantic_feature"]).clone().requires_grad_(True)
+    _c, feat, _r, _d = render(f)
+    fused_feature_l1(feat, gt1, lowres_grad=True).backward()
+    assert float(np.abs(f.grad.cpu().numpy() - grads[False]).max()) > 1e-2 * scale
+    # the raw hand-over refuses a second offer for one call instead of overwriting the first
+    gx = torch.zeros(30, 50, 32, device=dev)
+    dgr._offer_feature_grad_lowres(10 ** 9, gx, None)
+    with pytest.raises(RuntimeError):
+        dgr._offer_feature_grad_lowres(10 ** 9, gx, None)
+    dgr._lowres_offers.pop(10 ** 9)

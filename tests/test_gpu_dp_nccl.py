@@ -205,6 +205,40 @@ def test_several_views_per_rank_pipelined_and_accumulated(n_streams, accumulate)
     assert leaves2["semantic_feature"].grad is not None and float(leaves2["semantic_feature"].grad.abs().max()) > 0
 
 
+def test_in_place_accumulation_refuses_a_transformed_feature_input():
+    """the in-place accumulation adds the op's feature gradient straight into `leaf.grad`, past the autograd chain.
+    That is only right when the op's `semantic_feature` input IS the leaf: a model that feeds the op a transformed tensor of
+    the same size (normalisation, mask) must get an error, not a gradient that skipped the chain."""
+    import diff_gaussian_rasterization as dgr
+    import dp
+    dev = torch.device("cuda", 0)
+    leaves = _leaves(dev)
+    t = lambda x: x.to(dev)
+    P = leaves["means3D"].shape[0]
+    means2D = torch.zeros(P, 3, device=dev)
+
+    def forward(view_id):
+        sc = _scene(view_id)
+        st = dgr.GaussianRasterizationSettings(sc["image_height"], sc["image_width"], sc["tanfovx"], sc["tanfovy"], t(sc["bg"]), 1.0,
+                                               t(sc["viewmatrix"]), t(sc["projmatrix"]), 3, t(sc["campos"]), False, False)
+        fed = dict(leaves)
+        fed["semantic_feature"] = leaves["semantic_feature"] * 2.0            # same numel, NOT the leaf
+        color, feat, radii, depth = dgr.GaussianRasterizer(st)(means2D=means2D, **fed)
+        return color, feat, t(sc["dL_dcolor"]), t(sc["dL_dfeature"])
+
+    def backward(h):
+        torch.autograd.backward([h[0], h[1]], [h[2], h[3]])
+    with pytest.raises(RuntimeError, match="not that leaf"):
+        dp.dp_step_views(forward, backward, leaves, [0, 1], accumulate=True)
+    torch.cuda.synchronize()
+    # opt out: the gradient takes the autograd chain (d(2 f) = 2) and equals twice the direct one
+    grads = dp.dp_step_views(forward, backward, leaves, [0, 1], accumulate=False)
+    torch.cuda.synchronize()
+    want = _want_sum([0, 1], dev)["semantic_feature"]
+    err = np.abs(grads["semantic_feature"].cpu().numpy() - 2.0 * want).max()
+    assert err <= 1e-4 * np.abs(want).max() * 2.0
+
+
 def _solo_views_worker(rank, port, out_dir):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "feature-3dgs_amd"), os.path.join(root, "tests")):

@@ -369,3 +369,34 @@ def test_instance_lane_backward_tile_order_keeps_the_results(C, W, H, option):
         b = g0[k]
         scale = float(np.abs(b).max()) + 1e-30
         assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
+
+
+@pytest.mark.gpu
+def test_inputs_at_odd_storage_offsets_are_accepted():
+    """the per-Gaussian kernels read SH rows / rotations with 16-byte accesses.  A tensor VIEW that starts 4 bytes
+    into its storage (the reference accepts it) is copied by the binding and gives bit-identical results; the raw C ABI refuses a
+    misaligned pointer with an error instead of faulting (include/f3dgs.h, "Alignment")."""
+    import refutil as ru
+    scene = _scene(P=3000, C=16, width=128, height=80, seed=31)
+    mod = ru.product_module()
+    d = ru.device_inputs(scene, 16, "cuda:0")
+    f = ru.raw_forward(mod, scene, d)
+    g = ru.raw_backward(mod, scene, d, f)
+    d2 = dict(d)
+    for k in ("shs", "rotations", "semantic_feature", "means3D", "scales", "opacities"):
+        flat = torch.empty(d[k].numel() + 1, device=d[k].device, dtype=torch.float32)
+        view = flat[1:].view(d[k].shape)
+        view.copy_(d[k])
+        assert view.data_ptr() % 16 == 4
+        d2[k] = view
+    f2 = ru.raw_forward(mod, scene, d2)
+    for i in (1, 2, 3, 4):
+        assert torch.equal(f[i], f2[i])
+    g2 = ru.raw_backward(mod, scene, d2, f2)
+    for k in g:
+        if k in ("dL_dsh", "dL_dscales", "dL_drotations"):           # no atomics behind these: bit-equal given equal blend sums
+            continue
+        assert g[k].shape == g2[k].shape
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dsemantic_feature"):
+        err = (g[k] - g2[k]).abs().max()
+        assert float(err) <= 1e-5 * float(g[k].abs().max()), k

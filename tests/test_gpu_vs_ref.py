@@ -284,11 +284,27 @@ CASES = [
     dict(id="c2-shaped-1080p-C16", seed=17, P=50000, W=1920, H=1080, C=16, lo=0.003, hi=0.03),
     dict(id="c3-shaped-1080p-C32", seed=18, P=100000, W=1920, H=1080, C=32, lo=0.003, hi=0.03),
     dict(id="c4-shaped-1080p-C256", seed=19, P=50000, W=1920, H=1080, C=256, lo=0.003, hi=0.03),
+    # C = 512: the width the reference's authors ran LSeg at (README.md:330, `NUM_SEMANTIC_CHANNELS 512`): four 128-channel
+    # forward windows, eight later windows of the blend backward
+    dict(id="C512-LSeg", seed=20, P=3000, W=160, H=96, C=512),
+    dict(id="C512-LSeg-ragged-depthgrad", seed=21, P=2500, W=113, H=75, C=512, depth=True),
+    dict(id="C512-1080p-120k", seed=22, P=120000, W=1920, H=1080, C=512, lo=0.003, hi=0.03),
+    # inputs outside the synthetic family (tests/util.py: harsh_scene)
+    dict(id="heavy-tail-1080p-C32", seed=23, P=200000, W=1920, H=1080, C=32, harsh="heavy_tail", noise=False),
+    dict(id="heavy-tail-small-C16-depthgrad", seed=24, P=3000, W=160, H=96, C=16, harsh="heavy_tail", depth=True),
+    dict(id="opacity-0-and-1-C16", seed=25, P=8000, W=256, H=144, C=16, harsh="opacity01"),
+    dict(id="opacity-0-and-1-1080p-C32", seed=26, P=100000, W=1920, H=1080, C=32, harsh="opacity01"),
+    dict(id="zero-and-denormal-scales-C16", seed=27, P=8000, W=256, H=144, C=16, harsh="zero_scales"),
+    dict(id="zero-and-denormal-scales-precomp-cov-C16", seed=28, P=4000, W=160, H=96, C=16, harsh="zero_scales", pv=True),
 ]
 
 
 def _build(case):
     big = case.get("big", False)
+    if "harsh" in case:
+        from util import harsh_scene
+        return precompute_optionals(harsh_scene(case["harsh"], P=case["P"], C=case["C"], width=case["W"], height=case["H"],
+                                                seed=case["seed"], with_depth_grad=case.get("depth", False)))
     scene = _scene(P=case["P"], C=case["C"], width=case["W"], height=case["H"], seed=case["seed"],
                    sh_degree=case.get("degree", 3), with_depth_grad=case.get("depth", False),
                    scale_lo=case.get("lo", 0.02 if big else 0.005), scale_hi=case.get("hi", 0.4 if big else 0.08),
@@ -303,7 +319,8 @@ def _build(case):
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["id"])
 def test_forward_backward_vs_reference(case, record_property):
     scene = _build(case)
-    st = _compare(scene, case.get("Cref", case["C"]), case.get("pc", False), case.get("pv", False))
+    st = _compare(scene, case.get("Cref", case["C"]), case.get("pc", False), case.get("pv", False), self_noise=case.get("noise", True))
+    torch.cuda.empty_cache()
     for k, v in st.items():
         record_property(k, str(v))
     print(case["id"], st)

@@ -97,3 +97,46 @@ def grad_report(name, got, want, rel=1e-3):
     err = np.abs(got - want)
     bad = err > rel * np.abs(want) + rel * 1e-2 * scale
     return float(err.max() / scale), float(bad.mean())
+
+
+def harsh_scene(kind: str, P: int, C: int, width: int, height: int, seed: int, with_depth_grad: bool = False) -> dict:
+    """Scenes OUTSIDE the synthetic family of SURVEY.md 8(d) (uniform depth, log-uniform scales), for the comparison against
+    the reference-compiled checker:
+
+      heavy_tail  log-normal scales (median 0.04, sigma_log 1.3, up to 4 world units: splats larger than the image), half of
+                  the Gaussians nearly transparent (opacity 0.004 .. 0.03: just above the 1/255 cut, so that pixels do NOT
+                  saturate early and the deep tile lists - tens of thousands of entries at 1080p - are actually walked)
+      opacity01   a third of the opacities exactly 0, a third exactly 1 (the 0.99 clamp, Q1; alpha = 0 < 1/255)
+      zero_scales scales exactly 0 on all three axes (cov2D = the 0.3 low-pass alone), on one axis (flat splats), denormal
+                  scales, and a few all-zero quaternions (the kernels do not normalise: R = I)
+    """
+    import math
+    from synth import make_scene
+    sc = make_scene(P=P, C=C, width=width, height=height, seed=seed, with_depth_grad=with_depth_grad)
+    g = torch.Generator().manual_seed(seed * 7919 + 13)
+    if kind == "heavy_tail":
+        sc["scales"] = torch.exp(math.log(0.04) + 1.3 * torch.randn(P, 3, generator=g)).clamp(1e-5, 4.0).contiguous()
+        low = torch.rand(P, generator=g) < 0.5
+        faint = 0.004 + 0.026 * torch.rand(P, 1, generator=g)
+        sc["opacities"] = torch.where(low[:, None], faint, sc["opacities"]).contiguous()
+    elif kind == "opacity01":
+        r = torch.rand(P, generator=g)
+        op = sc["opacities"].clone()
+        op[r < 1 / 3] = 0.0
+        op[r > 2 / 3] = 1.0
+        sc["opacities"] = op.contiguous()
+    elif kind == "zero_scales":
+        r = torch.rand(P, generator=g)
+        s = sc["scales"].clone()
+        s[r < 0.10] = 0.0
+        flat = (r >= 0.10) & (r < 0.20)
+        axis = torch.randint(0, 3, (P,), generator=g)
+        s[flat, axis[flat]] = 0.0
+        s[(r >= 0.20) & (r < 0.25)] = 1e-40           # denormal
+        sc["scales"] = s.contiguous()
+        q = sc["rotations"].clone()
+        q[(r >= 0.25) & (r < 0.27)] = 0.0
+        sc["rotations"] = q.contiguous()
+    else:
+        raise ValueError(kind)
+    return sc
