@@ -195,6 +195,7 @@ const OptionDesc kOptions[] = {
     {"bwd_order", "F3DGS_BWD_ORDER", &Options::bwd_order, 1},
     {"bwd_m44", "F3DGS_BWD_M44", &Options::bwd_m44, 1},
     {"bwd_split16", "F3DGS_BWD_SPLIT16", &Options::bwd_split16, 1},
+    {"bwd_bf16", "F3DGS_BWD_BF16", &Options::bwd_bf16, 1},
     {"fwd_wide", "F3DGS_FWD_WIDE", &Options::fwd_wide, 1},
     {"fwd_solo", "F3DGS_FWD_SOLO", &Options::fwd_solo, 1},
     {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},

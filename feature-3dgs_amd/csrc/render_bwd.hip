@@ -691,7 +691,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     BwdArgs a;
     a.order = nullptr;
     a.glow = nullptr; a.gscale = nullptr; a.gHg = a.gWg = 0; a.gsy = a.gsx = 0.f;
-    a.m44 = 0; a.split16 = 0; a.neg_half_w = a.neg_half_h = 0.f;
+    a.m44 = 0; a.split16 = 0; a.bf16 = 0; a.neg_half_w = a.neg_half_h = 0.f;
     const bool low = lowres && lowres->gx && C > 0;
     if (low) {
         a.glow = lowres->gx; a.gscale = lowres->scale; a.gHg = lowres->Hg; a.gWg = lowres->Wg;
@@ -735,6 +735,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
         a.half = 0;
         a.m44 = opt.bwd_m44;
         a.split16 = opt.bwd_split16;
+        a.bf16 = opt.bwd_bf16;
         launch_render_backward_pl(a, C, s);
 #ifdef F3DGS_DEV
         if (a.dev & 8) {

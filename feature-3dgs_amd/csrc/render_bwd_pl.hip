@@ -42,6 +42,41 @@ namespace f3dgs {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- bf16 split operands (template parameter BF; option bwd_bf16) -------------------------------------------------------------
+// An fp32 matrix instruction occupies its SIMD for its whole duration (it excludes the vector instructions of the other
+// waves, tools/pipe_probe.hip) and runs at 1/16 of the bf16 rate.  With BF every contraction of phase 2 runs on
+// v_mfma_f32_16x16x32_bf16 instead, fp32 accumulation, each fp32 operand split into TWO bf16 terms by round-to-nearest:
+//     x = hi + mid + e,  hi = bf16(x),  mid = bf16(x - hi)  (x - hi is exact),  |e| <= 2^-18 |x|
+// and a product w g evaluated as  w_hi g_hi + w_hi g_mid + w_mid g_hi  (the dropped w_mid g_mid is <= 2^-18 |w g| too): every
+// term of a gradient sum carries a relative error of a few 1e-6 with random sign, against a bar of 1e-3 - the gradients'
+// tolerance is what allows the two-term split (the forward's 1e-4 ABSOLUTE bar on O(1) features would not).  The monomials of
+// the moment block (1, u, v, u^2, uv, v^2 with |u|, |v| <= 3.5 in steps of 1) have at most six significant bits: exact in bf16,
+// one term.  Per chunk a wave issues 24 (moment wave: 16) matrix instructions of 16 cycles instead of 64 of 32 cycles.
+// One v_cvt_pk_bf16_f32 converts two values (round to nearest even); the halves are stored with ds_write_b16 /
+// ds_write_b16_d16_hi as they stand.
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+// (lo, hi) -> packed high terms `h` and packed middle terms `m`
+__device__ __forceinline__ void split_bf16(float lo, float hi, uint32_t& h, uint32_t& m) {
+    h = pack_bf16(lo, hi);
+    m = pack_bf16(lo - __uint_as_float(h << 16), hi - __uint_as_float(h & 0xFFFF0000u));
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const uint32_t (&a)[4], const uint32_t (&b)[4], f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u32x4{a[0], a[1], a[2], a[3]}),
+                                                   __builtin_bit_cast(bf16x8, u32x4{b[0], b[1], b[2], b[3]}), c, 0, 0, 0);
+}
+// BF tile layout (aliases PlShared::wt and ::st, 32 KB): quadrant q at byte 8192 q; term t (0: w high, 1: w middle, 2: s high,
+// 3: s middle) at + 2048 t; row (entry) i at + 128 i; the row's eight 16-byte units = the eight pixel rows of the quadrant, unit
+// y stored at slot y ^ (i >> 1); pixel x of the row at + 2 x.  Operand lane (i, kg) of K span ks reads unit 4 ks + kg of row i -
+// sixteen bytes = the K slots 8 kg .. 8 kg + 7 - and the sixteen lanes of a ds_read_b128 service group meet sixteen different
+// 16-byte slots of the 256-byte bank row (two rows per bank row x eight slots).
+constexpr int BF_QUAD = 8192, BF_TERM = 2048, BF_ROWB = 128;
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access of the
 // wave - here the fire-and-forget atomics of the flush, microseconds under load - which nothing in the workgroup reads.
@@ -109,18 +144,19 @@ static_assert(PL_TAPS_OFS + 32 * sizeof(float4) + 34 * sizeof(int) <= sizeof(PlS
 // GEO = false: a later channel window of up to 64 channels: sixteen per wave.
 // P1_NE / P1_PREF: entries per phase-1 group, records of the next group prefetched.
 // M44: the colour wave of the first window contracts on sixteen 4 x 4 blocks (v_mfma_f32_4x4x1_16B_f32).
-template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false>
+template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false, bool BF = false>
 __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
+    static_assert(!BF || (P1_NE == 1 && !M44), "the bf16 shape takes its entries one at a time and has no 4 x 4 colour path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     PlShared& L = *reinterpret_cast<PlShared*>(smem);
     float* const stage = reinterpret_cast<float*>(smem);      // staging image: aliases everything, used before the walk only
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: quadrant in phase 1, column block in phase 2
-    const bool split16 = GEO && a.split16 && a.nc <= 16;      // wave-uniform: see the operand read-out below
+    const bool split16 = !BF && GEO && a.split16 && a.nc <= 16;      // wave-uniform: see the operand read-out below
     // later windows of up to 32 channels (the last window of 64 + 32 or 3 x 64 + 32 remaining channels: two waves would idle): wave q
     // takes channel block q & 1 at the quadrants 2 (q >> 1), 2 (q >> 1) + 1 - two partial sums per entry, added in the flush
-    const bool split32 = !GEO && a.split16 && a.nc <= 32;
+    const bool split32 = !BF && !GEO && a.split16 && a.nc <= 32;
     PL_PHASE_BEGIN();     // [0] staging  [1] window + barriers  [2] phase 1  [3] phase 2  [4] flush  [5] chunks  [6] entries
 
     // longest walks first: the launch is ~8 rounds of workgroups whose lifetimes differ by an order of magnitude, and a long
@@ -138,7 +174,10 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     // (lane = pixel of quadrant q) and the wave's B operand (lane = (column col, K index kk)) are read out of it.
     // B operand, resident for the life of the wave: Bop[qd][t] = column `col` of this wave's block at the pixel that step t
     // of quadrant qd contracts at K index kk, i.e. pixel (4 (t & 1) + kk, t >> 1) of the quadrant.
-    float Bop[4][16];
+    // (BF: the same 64 registers hold the operand as bf16 pairs - Bbf[qd][ks][0..3] the high terms, [4..7] the middle terms
+    // of this wave's column at the eight pixels (x = 0..7, y = 4 ks + kg) of quadrant qd, i.e. K slots 8 kg .. 8 kg + 7 of span ks)
+    float Bop[BF ? 1 : 4][16];
+    uint32_t Bbf[BF ? 4 : 1][2][8];
     uint32_t last = 0;
     float T = 0.f, dR = 0.f, dG = 0.f, dB = 0.f, dD = 0.f;
     {
@@ -303,7 +342,43 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 mine = (q >> 1) == rd;
                 plane = 16 * (q & 1) + col;
             }
-            if (GEO && M44 && q == 2) {
+            if constexpr (BF) {
+                if (GEO && q == 3) {
+                    // the moment wave: monomials of the pixel offset from the quadrant centre, columns 0..5: 1, u, v, u^2, uv, v^2
+                    // (at most six significant bits: exact in bf16); one operand for the four quadrants, kept in Bbf[0]
+                    const float k0c = col == 0 ? 1.f : 0.f, k1c = col == 1 ? 1.f : 0.f, k2c = col == 2 ? 1.f : 0.f;
+                    const float k3c = col == 3 ? 1.f : 0.f, k4c = col == 4 ? 1.f : 0.f, k5c = col == 5 ? 1.f : 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) {
+                        const float vv = (float)(4 * ks + kk) - 3.5f;
+                        float m[8];
+#pragma unroll
+                        for (int x = 0; x < 8; x++) {
+                            const float uu = (float)x - 3.5f;
+                            m[x] = fmaf(fmaf(k3c, uu, fmaf(k4c, vv, k1c)), uu, fmaf(fmaf(k5c, vv, k2c), vv, k0c));
+                        }
+#pragma unroll
+                        for (int d2 = 0; d2 < 4; d2++) { Bbf[0][ks][d2] = pack_bf16(m[2 * d2], m[2 * d2 + 1]); Bbf[0][ks][4 + d2] = 0u; }
+                    }
+                } else if (mine) {
+                    // feature-like blocks (GEO: channels 0-15, 16-31, colour / depth; later windows: sixteen channels per wave)
+#pragma unroll
+                    for (int qd = 0; qd < 4; qd++)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ks++) {
+                            const int py = (qd >> 1) * 8 + 4 * ks + kk, px0 = (qd & 1) * 8;
+                            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                            if (plane >= 0) {
+                                v0 = *reinterpret_cast<const float4*>(&stage[plane * PL_SP + py * 16 + px0]);
+                                v1 = *reinterpret_cast<const float4*>(&stage[plane * PL_SP + py * 16 + px0 + 4]);
+                            }
+                            split_bf16(v0.x, v0.y, Bbf[qd][ks][0], Bbf[qd][ks][4]);
+                            split_bf16(v0.z, v0.w, Bbf[qd][ks][1], Bbf[qd][ks][5]);
+                            split_bf16(v1.x, v1.y, Bbf[qd][ks][2], Bbf[qd][ks][6]);
+                            split_bf16(v1.z, v1.w, Bbf[qd][ks][3], Bbf[qd][ks][7]);
+                        }
+                }
+            } else if (GEO && M44 && q == 2) {
                 // the colour wave on sixteen 4 x 4 blocks (v_mfma_f32_4x4x1_16B_f32): lane = (block, i) with block = (entry group
                 // rg = block & 3, pixel class kc = block >> 2) and i = its row in A / its COLUMN in B (dL/dR, dL/dG, dL/dB,
                 // dL/ddepth).  A step (pixel block 4 t + kc of a quadrant tile, column m) contracts pixel (kc + 4 (m & 1),
@@ -398,6 +473,9 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     const uint32_t wofs_b = (uint32_t)(((ccol >> 2) * PL_ROW + ((ccol >> 2) & 7) * 4 + (ccol & 3)) * 4);     // bytes, row 0
     char* const my_wt = reinterpret_cast<char*>(&L.wt[q][0]);
     constexpr int ST_OFS = 4 * PL_TILE;             // st[q] - wt[q], dwords
+    // BF: the bf16 tiles alias wt / st (32 KB); this lane's pixel in its quadrant's rows: unit ly (XOR-ed per row), element lx
+    char* const bf_tiles = reinterpret_cast<char*>(&L.wt[0][0]);
+    const uint32_t bf_sofs = (uint32_t)(q * BF_QUAD + ly * 16 + lx * 2);
         if (!PL_DEV_SKIP(32)) PL_PHASE_END(0);
 
     // ---- record loader (waves 0..2: one 16-byte third of every record; lane = entry, entry 0 = farthest back) -------
@@ -467,6 +545,8 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                     constexpr bool PREF = decltype(prefc)::value;
                     float4 n0[NE], n1[NE];
                     float2 n2[NE];
+                    float w_even = 0.f;       // BF, later windows: the even entry's weight waits for its odd neighbour
+                    (void)w_even;
                     if constexpr (PREF) {
 #pragma unroll
                         for (int k = 0; k < NE; k++) {
@@ -516,12 +596,37 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                         for (int k = 0; k < NE; k++) {
                             const float Tb = T * f[k];              // transmittance in front of this splat
                             const float wv = al[k] * Tb;
+                            if constexpr (BF) {
+                                // two bf16 terms per value; row e of the quadrant's tiles, this lane's pixel (see BF_QUAD)
+                                const int e = NE * p + k;
+                                char* const bp = bf_tiles + (bf_sofs ^ (uint32_t)(16 * (e >> 1))) + e * BF_ROWB;
+                                if constexpr (GEO) {
+                                    const float dL_dalpha = fmaf(Tb, qd[k], -(S * f[k]));
+                                    S = fmaf(wv, qd[k], S);
+                                    uint32_t h, m;
+                                    split_bf16(wv, au[k] * dL_dalpha, h, m);      // low halves: w, high halves: s
+                                    *reinterpret_cast<uint16_t*>(bp) = (uint16_t)h;
+                                    *reinterpret_cast<uint16_t*>(bp + BF_TERM) = (uint16_t)m;
+                                    *reinterpret_cast<uint16_t*>(bp + 2 * BF_TERM) = (uint16_t)(h >> 16);
+                                    *reinterpret_cast<uint16_t*>(bp + 3 * BF_TERM) = (uint16_t)(m >> 16);
+                                } else if ((e & 1) == 0) {
+                                    w_even = wv;                                     // converted together with the next entry's
+                                } else {
+                                    uint32_t h, m;
+                                    split_bf16(w_even, wv, h, m);                    // rows e - 1 and e share their XOR term
+                                    *reinterpret_cast<uint16_t*>(bp - BF_ROWB) = (uint16_t)h;
+                                    *reinterpret_cast<uint16_t*>(bp - BF_ROWB + BF_TERM) = (uint16_t)m;
+                                    *reinterpret_cast<uint16_t*>(bp) = (uint16_t)(h >> 16);
+                                    *reinterpret_cast<uint16_t*>(bp + BF_TERM) = (uint16_t)(m >> 16);
+                                }
+                            } else {
                             float* const wp = reinterpret_cast<float*>(my_wt + (wofs_b ^ (uint32_t)(16 * (NE * p + k))));
                             wp[0] = wv;
                             if constexpr (GEO) {
                                 const float dL_dalpha = fmaf(Tb, qd[k], -(S * f[k]));
                                 S = fmaf(wv, qd[k], S);
                                 wp[ST_OFS] = au[k] * dL_dalpha;
+                            }
                             }
                             T = Tb;
                         }
@@ -542,7 +647,64 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 
             // ---- phase 2: this wave's sixteen columns of every sum of the chunk
             const uint32_t tt = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.touched[parity]);
-            if (GEO && M44 && q == 2 && (tt & 0xFFFFu) != 0) {
+            if constexpr (BF) {
+                if (active && (tt & 0xFFFFu) != 0) {
+                    const int lane2 = fresh_lane();
+                    const int col = lane2 & 15, kk = lane2 >> 4;
+                    // operand read base of lane (row col, K group kk): unit 4 ks + kk at slot (4 ks + kk) ^ (row >> 1)
+                    const uint32_t r0 = (uint32_t)(col * BF_ROWB + ((kk ^ (col >> 1)) & 7) * 16), r1 = r0 ^ 64u;
+                    const int fs_row0 = (4 * kk) * PL_FS;
+                    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    auto a_read = [&](int qd, int term, int ks, uint32_t (&dst)[4]) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(bf_tiles + qd * BF_QUAD + term * BF_TERM + (ks ? r1 : r0));
+                        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                    };
+                    if (use_s) {
+                        // the moment wave: s = s_hi + s_mid against the exact monomials, the four quadrants kept apart
+#pragma unroll
+                        for (int qd = 0; qd < 4; qd++) {
+                            f32x4 acc0 = zero4, acc1 = zero4;
+                            if ((tt >> (16 + qd)) & 1u) {
+#pragma unroll
+                                for (int ks = 0; ks < 2; ks++) {
+                                    uint32_t ah[4], am[4];
+                                    a_read(qd, 2, ks, ah); a_read(qd, 3, ks, am);
+                                    const uint32_t (&bm)[4] = reinterpret_cast<const uint32_t (&)[4]>(Bbf[0][ks][0]);
+                                    acc0 = mfma_bf16(ah, bm, acc0);
+                                    acc1 = mfma_bf16(am, bm, acc1);
+                                }
+                            }
+                            if (col < 6) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + 36 + 6 * qd + col] = acc0[r] + acc1[r];
+                            }
+                        }
+                    } else {
+                        // w g = w_hi g_hi + w_hi g_mid + w_mid g_hi: three accumulators, no back-to-back dependent instructions
+                        f32x4 acc0 = zero4, acc1 = zero4, acc2 = zero4;
+#pragma unroll
+                        for (int qd = 0; qd < 4; qd++) {
+                            if ((tt >> (16 + qd)) & 1u) {
+#pragma unroll
+                                for (int ks = 0; ks < 2; ks++) {
+                                    uint32_t ah[4], am[4];
+                                    a_read(qd, 0, ks, ah); a_read(qd, 1, ks, am);
+                                    const uint32_t (&bh)[4] = reinterpret_cast<const uint32_t (&)[4]>(Bbf[qd][ks][0]);
+                                    const uint32_t (&bm)[4] = reinterpret_cast<const uint32_t (&)[4]>(Bbf[qd][ks][4]);
+                                    acc0 = mfma_bf16(ah, bh, acc0);
+                                    acc1 = mfma_bf16(ah, bm, acc1);
+                                    acc2 = mfma_bf16(am, bh, acc2);
+                                }
+                            }
+                        }
+                        const int slot = (GEO && q == 2) ? 32 + col : 16 * q + col;
+                        if (!(GEO && q == 2) || col < 4) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + slot] = acc0[r] + (acc1[r] + acc2[r]);
+                        }
+                    }
+                }
+            } else if (GEO && M44 && q == 2 && (tt & 0xFFFFu) != 0) {
                 // ---- colour wave, 4 x 4 blocks: 8 matrix-pipe cycles per step of 16 entries x 4 pixels x 4 columns instead of 32 for a
                 // 16-column step of which 4 are used (c3: 0.645 -> 0.630 ms; the moment wave - 6 columns, two blocks, 128
                 // instructions per chunk - was measured too and is slower in this form: 0.71 ms)
@@ -768,9 +930,9 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 #endif
 }
 
-template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false>
+template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false, bool BF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel(BwdArgs a) {
-    render_backward_pl_body<GEO, P1_NE, P1_PREF, M44>(a);
+    render_backward_pl_body<GEO, P1_NE, P1_PREF, M44, BF>(a);
 }
 
 // Tiles by descending walk length, XCD by XCD: workgroup b runs on XCD b % 8 (xcd_remap) and every XCD keeps its contiguous
@@ -823,6 +985,7 @@ void launch_pl(const BwdArgs& a, hipStream_t s) {
     if (variant == 4) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
     if (variant == 5) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 2, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
 #endif
+    if (a.bf16) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true, false, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
     if constexpr (GEO) {
         if (a.m44) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
     }

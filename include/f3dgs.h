@@ -87,9 +87,13 @@ const char* f3dgs_last_error(void);
  *   "bwd_half"       instance-lane blend backward: 1 (default) chunks of 32 instances against two pixel halves,
  *                    0 chunks of 64
  *   "bwd_order"      blend backward: 1 (default) workgroups take the tiles longest walk first
- *   "bwd_m44"        pixel-lane blend backward: 1 (default) the colour / depth sums contract on 4 x 4 matrix blocks
+ *   "bwd_bf16"       pixel-lane blend backward: 1 (default) every per-Gaussian sum contracts on bf16 matrix instructions
+ *                    (v_mfma_f32_16x16x32_bf16, fp32 accumulation) with each fp32 operand split into two bf16 terms -
+ *                    a relative error of a few 1e-6 per product against the 1e-3 tolerance of the gradients; 0: exact-fp32
+ *                    matrix instructions (16x slower per multiply-add, and they block the vector pipe of their SIMD)
+ *   "bwd_m44"        fp32 shape of the pixel-lane blend backward (bwd_bf16 = 0): 1 (default) the colour / depth sums contract on 4 x 4 matrix blocks
  *                    (v_mfma_f32_4x4x1_16B_f32) instead of a 16-column block of which four are used
- *   "bwd_split16"    pixel-lane blend backward with up to 16 feature channels, and its later channel windows of up to 32: 1 (default)
+ *   "bwd_split16"    fp32 shape of the pixel-lane blend backward (bwd_bf16 = 0) with up to 16 feature channels, and its later channel windows of up to 32: 1 (default)
  *                    the column blocks are split over the four waves by quadrants as well (no wave without matrix work, partial
  *                    sums added in the flush), 0 by columns only
  *   "fwd_wide"       blend forward: 1 (default) 128-channel windows where more than 64 channels remain

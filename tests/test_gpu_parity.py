@@ -314,6 +314,7 @@ def test_pixel_lane_backward_quadrant_split_for_up_to_16_channels(C, option):
     against the instance-lane kernel: same gradients up to the order of the float sums."""
     from synth import make_scene
     sc = make_scene(P=30000, C=C, width=333, height=208, seed=53)
+    option("bwd_bf16", 0)            # the quadrant split belongs to the fp32 shape of the kernel
     option("bwd_pl", 1)
     _, g1 = run_hip(sc)
     option("bwd_split16", 0)
@@ -329,6 +330,31 @@ def test_pixel_lane_backward_quadrant_split_for_up_to_16_channels(C, option):
             assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
 
 
+@pytest.mark.parametrize("C", [5, 16, 32, 48, 96, 200, 512])
+def test_bf16_and_fp32_contractions_of_the_pixel_lane_backward_agree(C, option):
+    """Option bwd_bf16 (default 1): every per-Gaussian sum of the pixel-lane blend backward contracted on
+    v_mfma_f32_16x16x32_bf16 with each fp32 operand split into two bf16 terms (x = hi + mid, |rest| <= 2^-18 |x|; products
+    hi hi + hi mid + mid hi; the moment block's monomials are exact in bf16) against 0: exact-fp32 matrix instructions.  The
+    forward pass is untouched (bit-identical images); every gradient element agrees to 1e-4 |g| + 1e-5 max|g| - a tenth of the
+    north-star's relative bar (what the split costs is measured here; the bars against the reference are test_gpu_vs_ref.py's)."""
+    from synth import make_scene
+    sc = make_scene(P=30000, C=C, width=333, height=208, seed=59, with_depth_grad=True)
+    out1, g1 = run_hip(sc)
+    option("bwd_bf16", 0)
+    out0, g0 = run_hip(sc)
+    for k in ("color", "feature_map", "depth", "radii"):
+        assert np.array_equal(out1[k], out0[k]), k
+    worst = {}
+    for k, a in g1.items():
+        if a is None or a.size == 0:
+            continue
+        b = g0[k].astype(np.float64)
+        scale = float(np.abs(b).max()) + 1e-30
+        worst[k] = float((np.abs(a - b) / (1e-4 * np.abs(b) + 1e-5 * scale)).max())
+    print("bf16 vs fp32 contractions, worst element / (1e-4 |g| + 1e-5 max|g|):", {k: round(v, 3) for k, v in worst.items()})
+    assert max(worst.values()) <= 1.0, worst
+
+
 @pytest.mark.parametrize("name", ["fwd_solo", "fwd_wide", "bwd_order", "bwd_m44"])
 @pytest.mark.parametrize("C", [16, 32, 200])
 def test_scheduling_options_keep_the_results(name, C, option):
@@ -338,6 +364,8 @@ def test_scheduling_options_keep_the_results(name, C, option):
     are bit-identical with the option off, the gradients equal up to the order of their atomic sums."""
     from synth import make_scene
     sc = make_scene(P=30000, C=C, width=333, height=208, seed=31)
+    if name == "bwd_m44":
+        option("bwd_bf16", 0)        # the 4 x 4 colour blocks belong to the fp32 shape of the pixel-lane kernel
     out1, g1 = run_hip(sc)
     option(name, 0)
     out0, g0 = run_hip(sc)

@@ -15,8 +15,13 @@ from util import set_option
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 yaw = float(sys.argv[2]) * 5.0 if len(sys.argv) > 2 else 0.0
 DEV = "cuda:0"
-scene = make_scene(seed=0, **CONFIGS[cfg])
-scene.update(make_camera(scene["image_width"], scene["image_height"], yaw_deg=yaw))
+if cfg.startswith("harsh:"):      # harsh:<kind>:<P>:<W>:<H>:<C>:<seed>[:depth]   (tests/util.py: harsh_scene)
+    from util import harsh_scene
+    f_ = cfg.split(":")
+    scene = harsh_scene(f_[1], P=int(f_[2]), width=int(f_[3]), height=int(f_[4]), C=int(f_[5]), seed=int(f_[6]), with_depth_grad=len(f_) > 7)
+else:
+    scene = make_scene(seed=0, **CONFIGS[cfg])
+    scene.update(make_camera(scene["image_width"], scene["image_height"], yaw_deg=yaw))
 W, H, P, C = scene["image_width"], scene["image_height"], scene["P"], scene["C"]
 mode = [a for a in sys.argv[3:] if not a.startswith("--")]
 mode = mode[0] if mode else "default"      # default: product vs contracted reference; strict: product vs -ffp-contract=off reference; refs: strict reference in the product's seat
@@ -54,6 +59,11 @@ if len(pix):
     print(f"adjudicated {len(sel)} pixels: ok {int(ok.sum())}, borderline {int(bl.sum())}; e_prod/bar: median {np.median(ep):.2f} max {ep.max():.2f}; "
           f"e_ref/bar: median {np.median(er):.2f} max {er.max():.2f}")
     for j in np.argsort(-ep)[:12]:
+        for k_ in bars:
+            dp_ = np.abs(np.asarray(pv_[k_], np.float64)[j] - truths[0][k_][j]).max() / bars[k_]
+            dr_ = np.abs(np.asarray(rv_[k_], np.float64)[j] - truths[0][k_][j]).max() / bars[k_]
+            if max(dp_, dr_) > 0.3:
+                print(f"      {k_}: prod {dp_:.2f} ref {dr_:.2f} bars from the fp64 value")
         print(f"  pixel {sel[j]} flip={bool(flips[sel[j]])} nc ref/prod/truth {img_ref['n_contrib'][sel[j]]}/{img_prod['n_contrib'][sel[j]]}/{truths[0]['n_contrib'][j]} "
               f"e_prod {ep[j]:.2f} e_ref {er[j]:.2f} ok={bool(ok[j])} borderline={bool(bl[j])} T ref/prod/truth {rv_['final_T'][j]:.6g}/{pv_['final_T'][j]:.6g}/{truths[0]['final_T'][j]:.6g}")
 # gradients
@@ -86,7 +96,16 @@ if bad:
                     t = np.concatenate([t[:2], [0.0]])[:len(a)]
                 scale = float(g_ref[k].abs().max())
                 bound = 1e-3 * np.abs(t) + 1e-5 * scale
-                print(f"  gaussian {i} {k}: e_prod/bound {np.max(np.abs(b - t) / bound):.2f}  e_ref/bound {np.max(np.abs(a - t) / bound):.2f}")
+                print(f"  gaussian {i} {k}: e_prod/bound {np.max(np.abs(b - t) / bound):.2f}  e_ref/bound {np.max(np.abs(a - t) / bound):.2f}  "
+                      f"prod-ref/bound {np.max(np.abs(b - a) / bound):.2f} | radius {int(f_ref[4][i])} scales {scene['scales'][i].numpy()} opacity {float(scene['opacities'][i]):.4f} "
+                      f"truth {t} ref {a} prod {b}")
+        # the pieces: dL_dmeans2D (blend backward) and dL_dcov3D (cov2D backward, rasterize_points.cu:199) of the same Gaussians
+        for k in ("dL_dmeans2D", "dL_dcov3D", "dL_dopacity"):
+            a, b = g_ref[k].double(), g_prod[k].double()
+            scale = float(a.abs().max()) + 1e-30
+            for i in ids[:8]:
+                r_ = ((b[i] - a[i]).abs() / (1e-3 * a[i].abs() + 1e-5 * scale)).max()
+                print(f"    gaussian {i} {k}: prod-ref/bound {float(r_):.2f}  ref {a[i].cpu().numpy().reshape(-1)} prod {b[i].cpu().numpy().reshape(-1)}")
 
 # ---- which per-Gaussian state entries explain the continuous (non-flip) deviations?
 if len(pix) and "--state" in sys.argv:
