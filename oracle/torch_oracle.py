@@ -183,6 +183,7 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
     # ---- blend, one tile at a time -------------------------------------------------------------------
     # `variants`: several positions of the two thresholds evaluated on the SAME projection, lists and alphas (the adjudicator
     # asks for five); the returned top-level outputs are those of the first
+    # a variant is (alpha_min, t_min) or (alpha_min, t_min, k): see the conditioning-aware alpha test below
     thresholds = list(variants) if variants else [(alpha_min, t_min)]
     vals_t = torch.from_numpy(vals).to(dev)
     depth_all = p_view[:, 2]
@@ -205,9 +206,17 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
         a_raw = opacities[g, 0][None, :] * Gv
         alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()        # Q1 straight-through
         py_n, px_n = py.reshape(-1).cpu().numpy(), px.reshape(-1).cpu().numpy()
-        for (a_min, T_min), A in zip(thresholds, acc):
+        for thr, A in zip(thresholds, acc):
+            a_min, T_min = thr[0], thr[1]
             with torch.no_grad():
-                valid = (power <= 0) & (alpha >= a_min)
+                if len(thr) > 2 and thr[2] != 0.0:
+                    # conditioning-aware move of the alpha test: ANY fp32 evaluation of the quadratic form carries an absolute
+                    # error of up to ~k u S in `power`, S = the sum of the magnitudes of its three terms, u = 2^-24 (needle-shaped
+                    # splats at an angle: terms of 1e3..1e4 cancelling to a power of -5) - alpha is tested as alpha exp(k u S)
+                    S = 0.5 * (con[None, :, 0].abs() * dx * dx + con[None, :, 2].abs() * dy * dy) + (con[None, :, 1] * dx * dy).abs()
+                    valid = (power <= 0) & (alpha * torch.exp(thr[2] * (2.0 ** -24) * S) >= a_min)
+                else:
+                    valid = (power <= 0) & (alpha >= a_min)
             a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
             cum = torch.cumprod(1.0 - a_eff, dim=1)
             with torch.no_grad():
@@ -240,9 +249,12 @@ def rasterize(*, bg, means3D, means2D, opacities, semantic_feature, viewmatrix, 
             final_T[PY, PX] = torch.cat([s_[2] for s_ in A["slots"]])
         results.append(dict(color=out_color, feature_map=out_feat, depth=out_depth, final_T=final_T, n_contrib=A["n_contrib"]))
     first = results[0]
+    # per-Gaussian projected state (differentiable): what the blend consumes.  tests/adjudicate.py uses it to evaluate the
+    # per-Gaussian gradient chain in fp64 from given upstream gradients (local_chain_truth)
+    state = dict(ndc=ndc, cov2=torch.stack([cov2[:, 0, 0], cov2[:, 1, 0], cov2[:, 1, 1]], 1), JW=JW, conic=conic, rgb=rgb, depth=p_view[:, 2])
     return dict(color=first["color"], feature_map=first["feature_map"], depth=first["depth"], radii=radii, num_rendered=int(len(vals)),
                 n_contrib=first["n_contrib"], final_T=first["final_T"], point_list=vals, ranges=np.stack([starts, ends], 1),
-                variants=results if variants else None)
+                variants=results if variants else None, state=state)
 
 
 def forward_backward(scene: dict, dtype=torch.float64, use_precomp_color=False, use_precomp_cov=False,

@@ -29,6 +29,7 @@ import torch
 
 TILE = 16
 DELTA = 2e-4          # relative move of the blend thresholds that fp32 evaluation of alpha / T can explain
+COND_K = 8.0          # roundings of an fp32 evaluation of the quadratic form (products, sums, the conic's own rounding): |d power| <= COND_K u S
 
 
 def _tiles_of_pixels(pix: np.ndarray, W: int, H: int) -> np.ndarray:
@@ -57,9 +58,15 @@ def forward_truth(scene: dict, pix: np.ndarray, pc=False, pv=False, dev="cuda:0"
     done = np.isin(t_of, tiles)
     sel = pix[done]
     ys, xs = torch.from_numpy(sel // W), torch.from_numpy(sel % W)
-    # nominal thresholds first; then each threshold moved either way (a pixel may hold one borderline decision of each kind)
-    moves = ((1.0, 1.0), (1.0 + delta, 1.0 + delta), (1.0 - delta, 1.0 - delta), (1.0 + delta, 1.0 - delta), (1.0 - delta, 1.0 + delta))
-    res = _run(scene, pc, pv, dev, tiles.tolist(), variants=[(fa / 255.0, ft * 1e-4) for fa, ft in moves])["out"]["variants"]
+    # nominal thresholds first; then each threshold moved either way (a pixel may hold one borderline decision of each kind);
+    # then the alpha test moved by what ANY fp32 evaluation of the quadratic form may be off by (COND_K u S, S = the sum of the
+    # magnitudes of its terms: needle-shaped splats at an angle, whose terms of 1e3 .. 1e4 cancel to a power of -5, carry an
+    # absolute error of 1e-3 in the exponent whatever the order of operations - the product and the reference both do; which
+    # of them lands on the exact side at a given pixel is luck), combined with the transmittance threshold moved either way
+    moves = ((1.0, 1.0, 0.0), (1.0 + delta, 1.0 + delta, 0.0), (1.0 - delta, 1.0 - delta, 0.0), (1.0 + delta, 1.0 - delta, 0.0),
+             (1.0 - delta, 1.0 + delta, 0.0), (1.0, 1.0, COND_K), (1.0, 1.0, -COND_K), (1.0, 1.0 + delta, COND_K), (1.0, 1.0 - delta, COND_K),
+             (1.0, 1.0 + delta, -COND_K), (1.0, 1.0 - delta, -COND_K))
+    res = _run(scene, pc, pv, dev, tiles.tolist(), variants=[(fa / 255.0, ft * 1e-4, kc) for fa, ft, kc in moves])["out"]["variants"]
     out = [dict(color=r["color"][:, ys, xs].t().cpu().numpy(), depth=r["depth"][0, ys, xs].cpu().numpy(),
                 feature=r["feature_map"][:, ys, xs].t().cpu().numpy(), final_T=r["final_T"][ys, xs].cpu().numpy(),
                 n_contrib=r["n_contrib"][sel // W, sel % W]) for r in res]
@@ -115,3 +122,61 @@ def gradient_truth(scene: dict, gaussians: np.ndarray, upstream, pc=False, pv=Fa
     res = _run(scene, pc, pv, dev, sorted(tiles), want_grads=True, upstream=upstream)
     idt = torch.from_numpy(ids).to(dev)
     return {k: v[idt].cpu().numpy() for k, v in res["grads"].items()}
+
+
+# ---------------------------------------------------------------- the per-Gaussian gradient chain in fp64 -----
+def _cov3d_to_cov2d_jacobian(JW: torch.Tensor) -> torch.Tensor:
+    """M (n, 6, 3): d(cov2D a, b, c) / d(cov3D six-vector [s00, s01, s02, s11, s12, s22]) for cov2D = T S T^T, T = JW (n, 2, 3);
+    an off-diagonal parameter sits in two matrix entries (backward.cu:225-227: "off-diagonals doubled")."""
+    T0, T1 = JW[:, 0, :], JW[:, 1, :]
+    pairs = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+    cols_a = [T0[:, i] * T0[:, j] * (1.0 if i == j else 2.0) for i, j in pairs]
+    cols_b = [T0[:, i] * T1[:, j] if i == j else T0[:, i] * T1[:, j] + T0[:, j] * T1[:, i] for i, j in pairs]
+    cols_c = [T1[:, i] * T1[:, j] * (1.0 if i == j else 2.0) for i, j in pairs]
+    return torch.stack([torch.stack(cols_a, 1), torch.stack(cols_b, 1), torch.stack(cols_c, 1)], 2)
+
+
+def local_chain_truth(scene: dict, gaussians: np.ndarray, dL_dmeans2D, dL_dcolors, dL_dcov3D, pc=False, pv=False, dev="cuda:0"):
+    """fp64 evaluation of the PER-GAUSSIAN part of the backward pass (backward.cu:144-404: cov2D, projection, SH colour, cov3D)
+    for the given Gaussians, from the blend-level gradients an implementation itself produced: dL_dmeans2D (n, 3; NDC units,
+    Q8), dL_dcolors (n, 3) and dL_dcov3D (n, 6) - the last is the cov2D stage's own output (rasterize_points.cu:199 returns it),
+    from which the gradient with respect to the 2D covariance is recovered by least squares over the Jacobian (6 equations,
+    3 unknowns; exact up to the fp32 rounding of the given values).  No blending, no tiles: this is what adjudicates the leaf
+    gradients of splats whose rectangles cover the whole image.  Needs dL_ddepth == 0 (the depth gradient per Gaussian is not
+    returned by either implementation).  Returns {means3D, scales, rotations, shs | cov3D_precomp | colors_precomp: (n, ...)}."""
+    from oracle import torch_oracle
+    ids = torch.as_tensor(np.asarray(gaussians, np.int64))
+    n = len(ids)
+    f64 = lambda t: t.detach().to("cpu")[ids].to(device=dev, dtype=torch.float64)
+    leaf = lambda t: f64(t).requires_grad_(True)
+    L = dict(means3D=leaf(scene["means3D"]), means2D=torch.zeros(n, 3, dtype=torch.float64, device=dev),
+             opacities=f64(scene["opacities"]), semantic_feature=torch.zeros(n, 1, 0, dtype=torch.float64, device=dev))
+    if pc:
+        L["colors_precomp"] = leaf(scene["colors_precomp"])
+    else:
+        L["shs"] = leaf(scene["shs"])
+    if pv:
+        L["cov3D_precomp"] = leaf(scene["cov3D_precomp"])
+    else:
+        L["scales"], L["rotations"] = leaf(scene["scales"]), leaf(scene["rotations"])
+    st = torch_oracle.rasterize(**L, bg=scene["bg"], viewmatrix=scene["viewmatrix"], projmatrix=scene["projmatrix"], campos=scene["campos"],
+                                tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], image_height=scene["image_height"],
+                                image_width=scene["image_width"], sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"],
+                                dtype=torch.float64, tiles=[])["state"]
+    up = lambda t: torch.as_tensor(t).detach().to(device=dev, dtype=torch.float64)
+    M = _cov3d_to_cov2d_jacobian(st["JW"].detach())
+    g2 = torch.linalg.lstsq(M, up(dL_dcov3D).reshape(n, 6, 1)).solution.reshape(n, 3)
+    loss = (st["ndc"] * up(dL_dmeans2D).reshape(n, -1)[:, :2]).sum() + (st["cov2"] * g2).sum() + (st["rgb"] * up(dL_dcolors).reshape(n, 3)).sum()
+    loss.backward()
+    return {k: (v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy() for k, v in L.items() if v.requires_grad}
+
+
+def gradient_verdict(truth_prod, prod, truth_ref, ref, scale: float):
+    """Per element: the product is acceptable iff it is inside the north-star bound of the exact value, or no further outside
+    it than the reference is from ITS exact value:  |p - t_p| <= 1e-3 |t_p| + 1e-5 scale + |r - t_r|.  Returns (ok, e_p, e_r) with
+    the errors in units of the bound."""
+    tp, tr = np.asarray(truth_prod, np.float64), np.asarray(truth_ref, np.float64)
+    p, r = np.asarray(prod, np.float64), np.asarray(ref, np.float64)
+    bp, br = 1e-3 * np.abs(tp) + 1e-5 * scale, 1e-3 * np.abs(tr) + 1e-5 * scale
+    e_p, e_r = np.abs(p - tp) / bp, np.abs(r - tr) / br
+    return (np.abs(p - tp) <= bp + np.abs(r - tr)), e_p, e_r

@@ -168,11 +168,73 @@ def _adjudicate(A: _Side, B: _Side, over, pc, pv, same_width, max_pixels=600):
                 product_median_bars=float(np.median(e_p)), reference_median_bars=float(np.median(e_r)))
 
 
+# leaf gradients produced by the per-Gaussian stage (backward.cu:144-404) from the blend-level sums
+CHAIN_GRADS = {"dL_dmeans3D": "means3D", "dL_dscales": "scales", "dL_drotations": "rotations", "dL_dsh": "shs"}
+LEAF_OF = dict(CHAIN_GRADS, dL_dmeans2D="means2D", dL_dopacity="opacities", dL_dsemantic_feature="semantic_feature",
+               dL_dcolors="colors_precomp", dL_dcov3D="cov3D_precomp")
+
+
+def _adjudicate_gradients(scene, ref_side, over, gst, g_ref, g_prod, pc, pv, max_gaussians=64):
+    """The north-star bar on every gradient element - |prod - ref| <= 1e-3 |ref| + 1e-5 max|ref| - with nothing added; every
+    Gaussian that holds an element ABOVE it goes to the fp64 adjudicator (tests/adjudicate.py), as the pixels above a bar do:
+    the product must be inside the bar of the exact value or no further outside it than the reference is.  (Needle-shaped
+    Gaussians - scale ratios of 1 : 300 - make the cov2D / cov3D backward formulas ill-conditioned in fp32; on the heavy-tailed
+    scenes the REFERENCE is up to 30 bounds away from the exact gradient there, profiles/r05_heavy_tail_probe.txt.)
+    Exact value: the full fp64 backward over all tiles of the Gaussians' rectangles where those are at most 400 tiles; for
+    splats that cover the image the per-Gaussian chain in fp64 from each implementation's own blend-level gradients
+    (`adjudicate.local_chain_truth`) - those (dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsemantic_feature, dL_dcov3D) must
+    then hold the bar themselves."""
+    W, H, P = scene["image_width"], scene["image_height"], scene["P"]
+    bad = {}
+    for k, (mx, worst, mx_self, worst_self) in gst.items():
+        if worst <= 1.0 and mx <= 1e-3:
+            continue
+        a, b = g_ref[k].double(), g_prod[k].double()
+        scale = float(a.abs().max()) + 1e-30
+        ratio = ((b - a).abs() / (1e-3 * a.abs() + 1e-5 * scale)).reshape(P, -1).amax(dim=1)
+        idx = torch.nonzero(ratio > 1.0).flatten().cpu().numpy()
+        assert len(idx) <= max_gaussians, (f"{k}: {len(idx)} Gaussians hold an element outside 1e-3*|g| + 1e-5*max|g| (worst {worst:.2f}x; "
+                                           f"reference run-to-run: {worst_self:.2f}x) - too many to be conditioning")
+        for i in idx:
+            bad.setdefault(int(i), []).append(k)
+    if not bad:
+        return dict(gaussians=0)
+    ids = np.array(sorted(bad))
+    keep = torch.from_numpy((~over).reshape(1, H, W))
+    up = tuple((scene[k] * keep).contiguous() for k in ("dL_dcolor", "dL_dfeature", "dL_ddepth"))
+    full = adj.gradient_truth(scene, ids, up, pc, pv, DEV)
+    mode = "full fp64 backward over the Gaussians' tiles"
+    if full is None:
+        mode = "per-Gaussian chain in fp64 from each implementation's own blend-level gradients"
+        assert float(scene["dL_ddepth"].abs().max()) == 0.0, "local-chain adjudication needs dL_ddepth == 0"
+        blend_level = [k for ks in bad.values() for k in ks if k not in CHAIN_GRADS]
+        assert not blend_level, f"blend-level gradients above the bar on splats too large for the tile-restricted fp64 backward: {sorted(set(blend_level))}"
+        sel = torch.from_numpy(ids).to(DEV)
+        t_ref = adj.local_chain_truth(scene, ids, g_ref["dL_dmeans2D"][sel], g_ref["dL_dcolors"][sel], g_ref["dL_dcov3D"][sel], pc, pv, DEV)
+        t_prod = adj.local_chain_truth(scene, ids, g_prod["dL_dmeans2D"][sel], g_prod["dL_dcolors"][sel], g_prod["dL_dcov3D"][sel], pc, pv, DEV)
+    worst_p, worst_r, n_el = 0.0, 0.0, 0
+    for n, i in enumerate(ids):
+        for k in bad[int(i)]:
+            leaf = LEAF_OF[k]
+            tp = (full[leaf][n] if full is not None else t_prod[leaf][n]).reshape(-1)
+            tr = (full[leaf][n] if full is not None else t_ref[leaf][n]).reshape(-1)
+            r_ = g_ref[k][i].reshape(-1).double().cpu().numpy()
+            p_ = g_prod[k][i].reshape(-1).double().cpu().numpy()
+            if k == "dL_dmeans2D":        # (the op's third column is always zero)
+                tp, tr = np.concatenate([tp[:2], [0.0]])[:len(p_)], np.concatenate([tr[:2], [0.0]])[:len(p_)]
+            ok, e_p, e_r = adj.gradient_verdict(tp, p_, tr, r_, float(g_ref[k].abs().max()))
+            assert ok.all(), (f"gaussian {i} {k}: product {e_p.max():.2f} bounds from the fp64 value, reference {e_r.max():.2f} ({mode}); "
+                              f"scales {scene['scales'][i].tolist()}")
+            worst_p, worst_r, n_el = max(worst_p, float(e_p.max())), max(worst_r, float(e_r.max())), n_el + 1
+    return dict(gaussians=int(len(ids)), tensors=n_el, mode=mode, product_worst_bounds_from_fp64=worst_p, reference_worst_bounds_from_fp64=worst_r)
+
+
 def _grad_names(pc, pv, same_width):
     # dL_dcolors (gradient w.r.t. the per-Gaussian RGB) is returned in SH mode too (rasterize_points.cu:199)
-    names = {"dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors"}
+    # dL_dcov3D (the cov2D stage's output, rasterize_points.cu:199) is returned whether the covariances were given or not
+    names = {"dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dcov3D"}
     names |= set() if pc else {"dL_dsh"}
-    names |= {"dL_dcov3D"} if pv else {"dL_dscales", "dL_drotations"}
+    names |= set() if pv else {"dL_dscales", "dL_drotations"}
     if same_width:
         names |= {"dL_dsemantic_feature"}
     return names
@@ -200,9 +262,7 @@ def _compare(scene, C_ref, pc=False, pv=False, check_state=True, self_noise=True
     assert st["n_contrib_equal_off_flips"]
     st["adjudication"] = _adjudicate(strict, prod, over, pc, pv, same)       # every pixel above a bar, flip or not
     gst, g_ref, g_prod = _backward_stats(strict, prod, over, names, self_noise)
-    for k, (mx, worst, mx_self, worst_self) in gst.items():
-        assert mx <= 1e-3, f"{k}: max err / max|g| = {mx:.2e} (reference run-to-run: {mx_self:.2e})"
-        assert worst <= 1.0, (f"{k}: worst element is {worst:.2f}x outside 1e-3*|g| + 1e-5*max|g| (reference run-to-run: {worst_self:.2f}x)")
+    st["gradient_adjudication"] = _adjudicate_gradients(scene, strict, over, gst, g_ref, g_prod, pc, pv)
     st["grads"] = gst
     stats["vs_strict"] = st
     if not return_grads:

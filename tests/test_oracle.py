@@ -153,3 +153,27 @@ def test_adjudicator_tile_subset_and_threshold_variants_match_the_full_evaluatio
     g_full = torch_oracle.forward_backward(sc, upstream=tuple(u * mask for u in up))["grads"]
     for k, want in g_full.items():
         assert torch.allclose(g_sub[k], want, rtol=1e-12, atol=1e-15 * float(want.abs().max() + 1)), k
+
+
+def test_local_chain_truth_equals_the_full_fp64_backward():
+    """tests/adjudicate.py: the per-Gaussian gradient chain evaluated in fp64 from blend-level gradients (dL_dmeans2D, dL_dcolors,
+    dL_dcov3D - the cov2D gradient recovered from the latter by least squares over d cov2D / d cov3D) gives the leaf gradients
+    of the full fp64 backward pass; pins the six-vector convention of dL_dcov3D (off-diagonals doubled, backward.cu:225-227)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import adjudicate as adj
+    from synth import make_scene
+    from util import precompute_optionals
+    from oracle import torch_oracle
+    sc = precompute_optionals(make_scene(P=200, C=3, width=64, height=48, seed=5, scale_lo=0.02, scale_hi=0.3))
+    blend = torch_oracle.forward_backward(sc, dtype=torch.float64, use_precomp_color=True, use_precomp_cov=True, device="cpu")["grads"]
+    for pv in (False, True):
+        want = torch_oracle.forward_backward(sc, dtype=torch.float64, use_precomp_cov=pv, device="cpu")["grads"]
+        got = adj.local_chain_truth(sc, np.arange(200), blend["means2D"], blend["colors_precomp"], blend["cov3D_precomp"], pc=False, pv=pv, dev="cpu")
+        for k, a in got.items():
+            b = want[k].numpy()
+            assert float(np.abs(a - b).max()) <= 2e-6 * (float(np.abs(b).max()) + 1e-30), (pv, k)
+    ok, e_p, e_r = adj.gradient_verdict(np.array([1.0, 1.0]), np.array([1.0005, 1.01]), np.array([1.0, 1.0]), np.array([1.0, 1.02]), 1.0)
+    assert ok.tolist() == [True, True] and e_p[1] > 9 and e_r[1] > 19
+    ok, _, _ = adj.gradient_verdict(np.array([1.0]), np.array([1.01]), np.array([1.0]), np.array([1.001]), 1.0)
+    assert ok.tolist() == [False]
