@@ -172,11 +172,12 @@ def local_chain_truth(scene: dict, gaussians: np.ndarray, dL_dmeans2D, dL_dcolor
 
 
 def gradient_verdict(truth_prod, prod, truth_ref, ref, scale: float):
-    """Per element: the product is acceptable iff it is inside the north-star bound of the exact value, or no further outside
-    it than the reference is from ITS exact value:  |p - t_p| <= 1e-3 |t_p| + 1e-5 scale + |r - t_r|.  Returns (ok, e_p, e_r) with
-    the errors in units of the bound."""
+    """One tensor of one Gaussian (ill-conditioning is a property of the Gaussian's whole chain, not of one element): with the
+    errors measured in units of the north-star bound, e = max_elements |x - t| / (1e-3 |t| + 1e-5 scale), the product is
+    acceptable iff it is inside the bound of the exact value or no further outside it than the reference is from ITS exact
+    value: e_p <= 1 + e_r.  Returns (ok, e_p, e_r)."""
     tp, tr = np.asarray(truth_prod, np.float64), np.asarray(truth_ref, np.float64)
     p, r = np.asarray(prod, np.float64), np.asarray(ref, np.float64)
-    bp, br = 1e-3 * np.abs(tp) + 1e-5 * scale, 1e-3 * np.abs(tr) + 1e-5 * scale
-    e_p, e_r = np.abs(p - tp) / bp, np.abs(r - tr) / br
-    return (np.abs(p - tp) <= bp + np.abs(r - tr)), e_p, e_r
+    e_p = float((np.abs(p - tp) / (1e-3 * np.abs(tp) + 1e-5 * scale)).max())
+    e_r = float((np.abs(r - tr) / (1e-3 * np.abs(tr) + 1e-5 * scale)).max())
+    return e_p <= 1.0 + e_r, e_p, e_r

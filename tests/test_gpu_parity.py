@@ -355,6 +355,32 @@ def test_bf16_and_fp32_contractions_of_the_pixel_lane_backward_agree(C, option):
     assert max(worst.values()) <= 1.0, worst
 
 
+@pytest.mark.parametrize("C", [32, 48, 64, 96, 128, 200, 512])
+def test_bf16_and_fp32_feature_contraction_of_the_forward_agree(C, option):
+    """Option fwd_bf16 (2: every window of 32 channels and more; 1, the default: windows of 64 / 128 channels; 0: exact fp32): the
+    feature contraction of the blend forward on v_mfma_f32_32x32x16_bf16 with both operands split into two bf16 terms
+    (x = hi + mid, |rest| <= 2^-18 |x|; all four products).  Colour, depth, radii - and with them every blend decision - are
+    bit-identical; the feature map (unit-scale features here) agrees to 4e-5 absolute, inside the north-star's 1e-4; the
+    backward pass does not read the feature map, its gradients agree up to the order of the atomic sums."""
+    from synth import make_scene
+    sc = make_scene(P=30000, C=C, width=333, height=208, seed=61)
+    option("fwd_bf16", 2)
+    out1, g1 = run_hip(sc)
+    option("fwd_bf16", 0)
+    out0, g0 = run_hip(sc)
+    for k in ("color", "depth", "radii"):
+        assert np.array_equal(out1[k], out0[k]), k
+    err = float(np.abs(out1["feature_map"] - out0["feature_map"]).max())
+    print(f"bf16 vs fp32 forward contraction, C = {C}: max |feature difference| = {err:.2e} (max |feature| {float(np.abs(sc['semantic_feature']).max()):.2f})")
+    assert 0.0 < err <= 4e-5
+    for k, a in g1.items():
+        if a is None or a.size == 0:
+            continue
+        b = g0[k]
+        scale = float(np.abs(b).max()) + 1e-30
+        assert float(np.abs(a - b).max()) <= 2e-5 * scale, (k, float(np.abs(a - b).max()) / scale)
+
+
 @pytest.mark.parametrize("name", ["fwd_solo", "fwd_wide", "bwd_order", "bwd_m44"])
 @pytest.mark.parametrize("C", [16, 32, 200])
 def test_scheduling_options_keep_the_results(name, C, option):

@@ -223,9 +223,9 @@ def _adjudicate_gradients(scene, ref_side, over, gst, g_ref, g_prod, pc, pv, max
             if k == "dL_dmeans2D":        # (the op's third column is always zero)
                 tp, tr = np.concatenate([tp[:2], [0.0]])[:len(p_)], np.concatenate([tr[:2], [0.0]])[:len(p_)]
             ok, e_p, e_r = adj.gradient_verdict(tp, p_, tr, r_, float(g_ref[k].abs().max()))
-            assert ok.all(), (f"gaussian {i} {k}: product {e_p.max():.2f} bounds from the fp64 value, reference {e_r.max():.2f} ({mode}); "
-                              f"scales {scene['scales'][i].tolist()}")
-            worst_p, worst_r, n_el = max(worst_p, float(e_p.max())), max(worst_r, float(e_r.max())), n_el + 1
+            assert ok, (f"gaussian {i} {k}: product {e_p:.2f} bounds from the fp64 value, reference {e_r:.2f} ({mode}); "
+                        f"scales {scene['scales'][i].tolist()}")
+            worst_p, worst_r, n_el = max(worst_p, e_p), max(worst_r, e_r), n_el + 1
     return dict(gaussians=int(len(ids)), tensors=n_el, mode=mode, product_worst_bounds_from_fp64=worst_p, reference_worst_bounds_from_fp64=worst_r)
 
 
@@ -297,7 +297,9 @@ def _compare(scene, C_ref, pc=False, pv=False, check_state=True, self_noise=True
         # a radius is ceil(3 sqrt(lambda_max)) (forward.cu:232): a last-bit difference in lambda can move a value sitting on an
         # integer across it - by one, for at most one Gaussian in 250k; num_rendered follows the rectangles
         gx, gy = (W + 15) // 16, (H + 15) // 16
-        assert st_p["radii_mismatch"] == st_s["radii_mismatch"] <= max(1, P // 250000) and st_p["radii_max_diff"] <= 1
+        # (measured: one per 250k on the BASELINE scenes, two per 200k on the heavy-tailed scene whose radii span four decades - the
+        # reference's own two builds against each other; what is asserted of the PRODUCT is that it stands where the strict build does)
+        assert st_p["radii_mismatch"] == st_s["radii_mismatch"] <= max(1, P // 50000) and st_p["radii_max_diff"] <= 1
         assert st_p["num_rendered_diff"] == st_s["num_rendered_diff"] <= st_p["radii_mismatch"] * (gx + gy + 1) + P // 100000
         # what the contracted build costs the PRODUCT it costs the reference's own strict build too (x 1.5 + the strict bar)
         assert st_p["flip_pixels"] <= 1.5 * st_s["flip_pixels"] + budget

@@ -174,6 +174,6 @@ def test_local_chain_truth_equals_the_full_fp64_backward():
             b = want[k].numpy()
             assert float(np.abs(a - b).max()) <= 2e-6 * (float(np.abs(b).max()) + 1e-30), (pv, k)
     ok, e_p, e_r = adj.gradient_verdict(np.array([1.0, 1.0]), np.array([1.0005, 1.01]), np.array([1.0, 1.0]), np.array([1.0, 1.02]), 1.0)
-    assert ok.tolist() == [True, True] and e_p[1] > 9 and e_r[1] > 19
+    assert ok and e_p > 9 and e_r > 19
     ok, _, _ = adj.gradient_verdict(np.array([1.0]), np.array([1.01]), np.array([1.0]), np.array([1.001]), 1.0)
-    assert ok.tolist() == [False]
+    assert not ok
