@@ -198,7 +198,6 @@ const OptionDesc kOptions[] = {
     {"bwd_bf16", "F3DGS_BWD_BF16", &Options::bwd_bf16, 1},
     {"fwd_wide", "F3DGS_FWD_WIDE", &Options::fwd_wide, 1},
     {"fwd_solo", "F3DGS_FWD_SOLO", &Options::fwd_solo, 1},
-    {"fwd_bf16", "F3DGS_FWD_BF16", &Options::fwd_bf16, 1},
     {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},
 #ifdef F3DGS_DEV
     {"dev", "F3DGS_DEV_BITS", &Options::dev, 0},

@@ -173,7 +173,6 @@ struct Options {
     int bwd_bf16;        // pixel-lane blend backward: every contraction on bf16 matrix instructions, operands as two bf16 terms (default 1)
     int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 4; needs feature_mfma
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
-    int fwd_bf16;        // blend forward: feature contraction on bf16 matrix instructions, two-term operands: 0 exact fp32, 1 windows of 64 / 128 channels, 2 also 32
     int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)
     int sort_onesweep;   // 1: single-pass radix passes with decoupled look-back (measured slower on MI355X; default 0)
 #ifdef F3DGS_DEV

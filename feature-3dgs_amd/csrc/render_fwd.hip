@@ -51,7 +51,6 @@ struct FwdArgs {
     int write_base;  // 1: also write colour / depth / final_T / n_contrib
     uint32_t* tile_len;   // per tile: max n_contrib of its pixels (first window's launch; zero-filled beforehand)
     int solo;        // one quadrant per wave: 64-thread workgroups, grid = 4 x tiles
-    int bf16;        // feature contraction on bf16 matrix instructions with two-term operands: 1 windows of 64 / 128 channels, 2 also 32
     int dev;         // development builds: work-skipping bits (128: no feature gathers  256: no matrix instructions  512: no alpha evaluation skip)
 };
 
@@ -260,30 +259,6 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
 // two at a time (K = 2): A[i][k] = w of pixel i for instance j+k, built from the two per-lane weights with
 // one v_permlane32_swap; B[k][n] = feature n of instance j+k, one ds_read_b32 per lane.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// ---- bf16 split operands of the feature contraction (template parameter BF; option fwd_bf16) ------------------------------------
-// The exact-fp32 matrix instruction of the feature contraction runs at 1/16 of the bf16 rate and blocks the vector pipe of its SIMD
-// for its whole duration (tools/pipe_probe.hip): 64 cycles per entry and 32-channel block, as much as the whole alpha
-// evaluation at 128 channels.  With BF both operands are split into TWO bf16 terms by round-to-nearest,
-//     x = hi + mid + e,   hi = bf16(x),  mid = bf16(x - hi)  (x - hi is exact),  |e| <= 2^-18 |x| = 3.8e-6 |x|,
-// and w f is evaluated as (w_hi + w_mid)(f_hi + f_mid) - all four products, K slots (w_hi, w_hi, w_mid, w_mid) against
-// (f_hi, f_mid, f_hi, f_mid) - on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: four entries per instruction of 32 cycles,
-// 8 cycles per entry and block instead of 64.  The feature map then carries a relative error of at most 7.6e-6 of
-// sum_e w_e |f_e| <= max |f| (unit-scale features: 4e-5 at the very worst, a few 1e-6 typically) against the north-star's bar of
-// 1e-4; colour, depth, transmittance and every blend decision stay on the exact fp32 vector path.  A feature value is staged
-// as ONE dword (hi | mid << 16): the LDS image keeps its size.  Option fwd_bf16 = 0 restores the exact-fp32 contraction.
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
-}
-// x -> (bf16(x) | bf16(x - bf16(x)) << 16)
-__device__ __forceinline__ uint32_t split_pair_bf16(float x) {
-    const uint32_t t = pack_bf16(x, x);
-    return pack_bf16(x, x - __uint_as_float(t << 16));
-}
 
 // One staged (compacted) list entry: a single LDS address per instance, three broadcast reads.
 struct FwdEntry {
@@ -315,9 +290,8 @@ struct FwdChunkMF {
 // CH = 16 (windows of 5..16 channels): the 32-column B operand has room to spare, so on the base launch columns 16..19 carry
 // the splat's colour and depth (CDB: read straight out of the staged entry) and their four multiply-adds per (pixel, entry)
 // leave the vector pipe - the pipe this kernel is bound by.
-template <int CH, int PPL, int CHK, int GI, bool BASE, bool BF = false>
+template <int CH, int PPL, int CHK, int GI, bool BASE>
 __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
-    static_assert(!BF || (PPL == 1 && GI == 2 && CH >= 32 && CH % 32 == 0), "bf16 shape: one quadrant per wave, windows of 32 / 64 / 128 channels");
     constexpr int NW = 4 / PPL;
     constexpr int NB = (CH + 31) / 32;
     constexpr bool CDB = BASE && CH == 16;
@@ -438,42 +412,6 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
         constexpr int CHV = CH / 4;
         const bool vec_ok = (a.C & 3) == 0 && (a.c0 & 3) == 0;
         if (FW_DEV_SKIP(128)) {
-        } else if constexpr (BF) {
-            // through registers: every value becomes the dword (hi | mid << 16) of its two bf16 terms; eight requests per lane
-            // in flight together
-            constexpr int NIT = CHK * CHV / 64;
-            constexpr int HB = CH <= 64 ? 4 : 8;
-            uint32_t* const fimg = reinterpret_cast<uint32_t*>(ck.feat);
-            const bool full = vec_ok && a.nc == CH;
-#pragma unroll 1
-            for (int h0 = 0; h0 < NIT; h0 += HB) {
-                float4 v[HB];
-#pragma unroll
-                for (int it = 0; it < HB; it++) {
-                    const int e = (h0 + it) * 64 + lane;
-                    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < cnt * CHV) {
-                        const uint32_t g = ck.ent[e / CHV].id;
-                        const int c4 = 4 * (e % CHV);
-                        const float* src = a.feat + (size_t)g * a.C + a.c0 + c4;
-                        if (full) {
-                            v[it] = *reinterpret_cast<const float4*>(src);
-                        } else {
-                            if (c4 + 0 < a.nc) v[it].x = src[0];
-                            if (c4 + 1 < a.nc) v[it].y = src[1];
-                            if (c4 + 2 < a.nc) v[it].z = src[2];
-                            if (c4 + 3 < a.nc) v[it].w = src[3];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < HB; it++) {
-                    const int e = (h0 + it) * 64 + lane;
-                    if (e < cnt * CHV)
-                        *reinterpret_cast<uint4*>(&fimg[4 * e]) = make_uint4(split_pair_bf16(v[it].x), split_pair_bf16(v[it].y),
-                                                                            split_pair_bf16(v[it].z), split_pair_bf16(v[it].w));
-                }
-            }
         } else if (vec_ok && a.nc == CH) {
             using lds_ptr = __attribute__((address_space(3))) void*;
             using gbl_ptr = const __attribute__((address_space(1))) void*;
@@ -507,81 +445,6 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
         }
         __builtin_amdgcn_wave_barrier();
 
-        if constexpr (BF) {
-            // four entries per matrix instruction: K slots 0..7 (lanes 0-31 of the operand) = entries j, j + 1, slots 8..15 (lanes
-            // 32-63) = entries j + 2, j + 3, four slots per entry: (w_hi, w_hi, w_mid, w_mid) against (f_hi, f_mid, f_hi, f_mid).
-            // The alpha evaluation takes the entries two at a time, exactly as the fp32 shape does.
-            const uint32_t* const fimg = reinterpret_cast<const uint32_t*>(ck.feat);
-            for (int j = 0; j < cnt; j += 4) {
-                uint32_t Ah[4], Am[4];
-                bool any_blend = false;
-                const bool slot_live = __any(T[0] > 0.0f);
-#pragma unroll
-                for (int hf = 0; hf < 2; hf++) {
-                    float4 g0[2], cdv[2];
-                    float2 g1[2];
-                    uint32_t pos_e[2];
-                    bool live_e[2];
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        live_e[e] = j + 2 * hf + e < cnt;
-                        const int je = live_e[e] ? j + 2 * hf + e : j;
-                        g0[e] = ck.ent[je].geo;
-                        if constexpr (BASE) cdv[e] = ck.ent[je].cd;
-                        const float4 tail = *reinterpret_cast<const float4*>(&ck.ent[je].co_c);
-                        g1[e] = make_float2(tail.x, tail.y);
-                        pos_e[e] = __float_as_uint(tail.z);
-                    }
-                    float araw[2];
-                    bool valid[2];
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const float dx = g0[e].x - pxf[0], dy = g0[e].y - pyf[0];
-                        const float power = splat_power2(dx, dy, g0[e].z, g0[e].w, g1[e].x);
-                        araw[e] = fminf(ALPHA_MAX, g1[e].y * __builtin_amdgcn_exp2f(power));
-                        valid[e] = slot_live && live_e[e] && !(power > 0.0f) && !(araw[e] < ALPHA_MIN);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const float test_T = T[0] * (1.0f - araw[e]);      // negative once the pixel is finished
-                        const bool below = test_T < T_MIN;
-                        const bool ok = valid[e] & !below;
-                        const bool term = valid[e] & below;                 // (re-)marks finished pixels
-                        const float wv = ok ? araw[e] * T[0] : 0.0f;
-                        T[0] = ok ? test_T : (term ? -fabsf(T[0]) : T[0]);
-                        if constexpr (BASE) {
-                            last[0] = ok ? pos_e[e] : last[0];
-                            col[0][0] = fmaf(cdv[e].x, wv, col[0][0]);
-                            col[0][1] = fmaf(cdv[e].y, wv, col[0][1]);
-                            col[0][2] = fmaf(cdv[e].z, wv, col[0][2]);
-                            dep[0] = fmaf(cdv[e].w, wv, dep[0]);
-                        }
-                        any_blend = any_blend || ok;
-                        const uint32_t t = pack_bf16(wv, wv);
-                        Ah[2 * hf + e] = t;
-                        const float r = wv - __uint_as_float(t << 16);
-                        Am[2 * hf + e] = pack_bf16(r, r);
-                    }
-                }
-                if (__any(any_blend) && !FW_DEV_SKIP(256)) {
-                    const int kg = lane >> 5;
-                    const int r0 = (j + 2 * kg < cnt) ? j + 2 * kg : j, r1 = (j + 2 * kg + 1 < cnt) ? j + 2 * kg + 1 : j;
-                    const auto s0 = __builtin_amdgcn_permlane32_swap((int)Ah[0], (int)Ah[2], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap((int)Am[0], (int)Am[2], false, false);
-                    const auto s2 = __builtin_amdgcn_permlane32_swap((int)Ah[1], (int)Ah[3], false, false);
-                    const auto s3 = __builtin_amdgcn_permlane32_swap((int)Am[1], (int)Am[3], false, false);
-                    const bf16x8 X = __builtin_bit_cast(bf16x8, u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s2[0], (uint32_t)s3[0]});
-                    const bf16x8 Y = __builtin_bit_cast(bf16x8, u32x4{(uint32_t)s0[1], (uint32_t)s1[1], (uint32_t)s2[1], (uint32_t)s3[1]});
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) {
-                        const uint32_t b0 = fimg[r0 * CH + (lane & 31) + 32 * nb], b1 = fimg[r1 * CH + (lane & 31) + 32 * nb];
-                        const bf16x8 B = __builtin_bit_cast(bf16x8, u32x4{b0, b0, b1, b1});
-                        acc[0][0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X, B, acc[0][0][nb], 0, 0, 0);
-                        acc[0][1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y, B, acc[0][1][nb], 0, 0, 0);
-                    }
-                }
-            }
-        } else
         for (int j = 0; j < cnt; j += GI) {
             float4 g0[GI], cdv[GI];
             float2 g1[GI];
@@ -741,29 +604,29 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
 // at three waves, 0.42-0.43 for two quadrants per wave with 64-instance chunks at three waves: 168 registers, 11.4 KB).
 // 64 channels, same shape: 150 registers and 9.7 KB, three waves per SIMD (c4: 2.58 -> 2.23 ms with 64-instance chunks at
 // two).  128 channels: 128 accumulator registers per quadrant, two waves per SIMD.
-template <int CH, bool BASE, bool BF = false>
+template <int CH, bool BASE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_forward_mfma_kernel_w4(FwdArgs a) {
-    render_forward_mfma_body<CH, 1, 32, 2, BASE, BF>(a);
+    render_forward_mfma_body<CH, 1, 32, 2, BASE>(a);
 }
-template <int CH, bool BASE, bool BF = false>
+template <int CH, bool BASE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) render_forward_mfma_kernel_w3(FwdArgs a) {
-    render_forward_mfma_body<CH, 1, 32, 2, BASE, BF>(a);
+    render_forward_mfma_body<CH, 1, 32, 2, BASE>(a);
 }
-template <int CH, bool BASE, bool BF = false>
+template <int CH, bool BASE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) render_forward_mfma_kernel_w2(FwdArgs a) {
-    render_forward_mfma_body<CH, 1, 32, 2, BASE, BF>(a);
+    render_forward_mfma_body<CH, 1, 32, 2, BASE>(a);
 }
 
 // The 128-channel shape needs 70 KB of LDS per four-wave workgroup (above the 64 KB default limit): the limit is raised once
 // per device; where that is refused the caller falls back to 64-channel windows.
-template <bool BASE, bool BF = false>
+template <bool BASE>
 bool wide_shape_usable() {
     constexpr int MAX_DEV = 64;
     static std::atomic<int> state[MAX_DEV];      // 0: not asked yet, 1: usable, -1: refused (the ABI is re-entrant across threads)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
     if (state[dev].load(std::memory_order_acquire) == 0) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_forward_mfma_kernel_w2<128, BASE, BF>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_forward_mfma_kernel_w2<128, BASE>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(FwdChunkMF<128, 32>)));
         if (e != hipSuccess) (void)hipGetLastError();     // not sticky: the narrower windows take over
         state[dev].store(e == hipSuccess ? 1 : -1, std::memory_order_release);
@@ -771,24 +634,18 @@ bool wide_shape_usable() {
     return state[dev].load(std::memory_order_acquire) > 0;
 }
 
-template <int CH, bool BASE, bool BF = false>
+template <int CH, bool BASE>
 void launch_shape(const FwdArgs& a, hipStream_t s) {
     const bool solo = a.solo != 0;
     const size_t lds = (solo ? 1 : 4) * sizeof(FwdChunkMF<CH, 32>);
     const dim3 grid(solo ? 4 * a.gx * a.gy : a.gx * a.gy), block(solo ? 64 : 256);
-    if constexpr (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w4<CH, BASE, BF>), grid, block, lds, s, a);
-    else if constexpr (CH <= 64) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, BASE, BF>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((render_forward_mfma_kernel_w2<CH, BASE, BF>), grid, block, lds, s, a);
+    if constexpr (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w4<CH, BASE>), grid, block, lds, s, a);
+    else if constexpr (CH <= 64) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, BASE>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((render_forward_mfma_kernel_w2<CH, BASE>), grid, block, lds, s, a);
 }
 template <int CH>
 void launch_one_mf(const FwdArgs& a, hipStream_t s) {
     // later channel windows of wide features run without the colour / depth half
-    if constexpr (CH >= 32) {
-        if (a.bf16 && (CH > 32 || a.bf16 > 1)) {      // option fwd_bf16: 1 windows of 64 / 128 channels, 2 also 32
-            if (a.write_base) launch_shape<CH, true, true>(a, s); else launch_shape<CH, false, true>(a, s);
-            return;
-        }
-    }
     if (a.write_base) launch_shape<CH, true>(a, s); else launch_shape<CH, false>(a, s);
 }
 
@@ -813,7 +670,6 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     a.out_depth = out_depth;
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
     a.solo = options().fwd_solo;
-    a.bf16 = options().fwd_bf16;
     a.tile_len = tile_len;
 #ifdef F3DGS_DEV
     a.dev = options().dev;
@@ -828,8 +684,7 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     }
     // channel window: 64 channels, or 128 on the matrix pipe when more than 64 remain (every window re-evaluates the
     // blend weights of the whole list: fewer, wider windows - two waves per SIMD, the matrix pipe hides the rest)
-    const bool wide_ok = mf && options().fwd_wide != 0 && C > 64 && wide_shape_usable<true>() && wide_shape_usable<false>() &&
-                         (!a.bf16 || (wide_shape_usable<true, true>() && wide_shape_usable<false, true>()));
+    const bool wide_ok = mf && options().fwd_wide != 0 && C > 64 && wide_shape_usable<true>() && wide_shape_usable<false>();
     const int wide = wide_ok ? 128 : 64;
     for (int c0 = 0; c0 < C;) {
         const int win = (C - c0 > 64) ? wide : 64;

@@ -360,6 +360,101 @@ def all_gather_params(shards: Dict[str, torch.Tensor], full: Dict[str, torch.Ten
         full[k].copy_(recv[:P].reshape(full[k].shape))
 
 
+class ShardedOptimizer:
+    """The byte-halving exchange made usable end to end: every rank owns the contiguous row range `shard_range(P, rank,
+    world)` of every per-Gaussian parameter and keeps optimizer state (Adam's two moments: 2/3 of the training state) for
+    those rows only.  One step =
+
+        reduce-scatter of the ranks' gradients  ->  the summed gradient of MY rows        ((N-1)/N of the bytes, once)
+        the optimizer's step on my rows         ->  any elementwise optimizer (`make_optimizer`: FusedAdam on HIP
+                                                    tensors, torch.optim.Adam in the CPU tests)
+        all-gather of the updated rows          ->  every rank holds all P updated rows   ((N-1)/N of the PARAMETER bytes)
+
+    against all-reduce (2 (N-1)/N of the gradient bytes) + N identical full optimizer steps.  The gradient message is
+    (59 + C) floats per Gaussian, the parameter message the same: the bytes on the wire are equal, but the all-gather
+    carries parameters - it has no dependence on the NEXT step's backward pass and can run under the next forward's
+    preprocess (`step(..., gather=False)` + `gather()`), and the optimizer's work and state shrink by N.
+    An elementwise optimizer stepped on a row range gives those rows bit for bit what the full step gives them, so at
+    world size 2 (a sum of two terms is order-free) the parameters equal the all-reduce path's EXACTLY
+    (tests/test_dp_gloo.py::test_sharded_optimizer_equals_the_all_reduce_path).
+
+    `params`: name -> full (P, ...) tensor (updated in place by `step`).  `make_optimizer(shards)`: name -> my rows as a
+    leaf tensor; returns the optimizer over them (the caller chooses groups / learning rates, as
+    scene/gaussian_model.py:163-178 does for the full tensors).  Densification changes P: call `full_state()` before
+    it (all moments gathered, keyed like torch.optim.Adam's state) and build a new ShardedOptimizer after it
+    (`load_full_state`)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], make_optimizer: Callable[[Dict[str, torch.Tensor]], "torch.optim.Optimizer"],
+                 group=None):
+        self.group = group
+        self.params = params
+        self.world = dist.get_world_size(group) if _active(group) else 1
+        self.rank = dist.get_rank(group) if _active(group) else 0
+        self.P = next(iter(params.values())).shape[0]
+        for k, v in params.items():
+            if v.shape[0] != self.P:
+                raise ValueError(f"parameter '{k}' has {v.shape[0]} rows, expected {self.P}")
+        self.lo, self.hi = shard_range(self.P, self.rank, self.world)
+        self.shards = {k: v.detach()[self.lo:self.hi].clone().requires_grad_(True) for k, v in params.items()}
+        self.optimizer = make_optimizer(self.shards)
+        self._pending = False
+
+    def step(self, grads: Dict[str, torch.Tensor], gather: bool = True) -> None:
+        """`grads`: name -> this rank's LOCAL (unreduced) gradient of the full tensor (e.g. `dp_step(..., reduce=False)`)."""
+        local = {k: grads[k] for k in self.shards}
+        mine = reduce_scatter_gaussian_grads(local, group=self.group)
+        for k, p in self.shards.items():
+            g = mine[k]
+            p.grad = g[self.lo:self.hi] if self.world == 1 else g      # (world 1: the helper returns the full tensors)
+        self.optimizer.step()
+        self._pending = True
+        if gather:
+            self.gather()
+
+    @torch.no_grad()
+    def gather(self) -> None:
+        """The updated rows of every rank -> the full parameters, in place."""
+        if not self._pending:
+            return
+        if self.world == 1:
+            for k, p in self.shards.items():
+                self.params[k].data[self.lo:self.hi].copy_(p.detach())
+        else:
+            all_gather_params({k: p.detach() for k, p in self.shards.items()}, {k: self.params[k].data for k in self.shards}, group=self.group)
+        self._pending = False
+
+    @torch.no_grad()
+    def full_state(self) -> Dict[str, Dict[str, torch.Tensor]]:
+        """name -> {state key -> full (P, ...) tensor} (per-row state tensors gathered from all ranks; scalars such as Adam's
+        `step` as they are): what an unsharded optimizer would hold, e.g. for the reference's densification code."""
+        out = {}
+        for k, p in self.shards.items():
+            st = self.optimizer.state.get(p, {})
+            full = {}
+            for name, val in st.items():
+                if isinstance(val, torch.Tensor) and val.dim() >= 1 and val.shape[0] == p.shape[0]:
+                    dst = torch.zeros((self.P,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
+                    all_gather_params({"x": val}, {"x": dst}, group=self.group) if self.world > 1 else dst[self.lo:self.hi].copy_(val)
+                    full[name] = dst
+                else:
+                    full[name] = val.clone() if isinstance(val, torch.Tensor) else val
+            out[k] = full
+        return out
+
+    @torch.no_grad()
+    def load_full_state(self, state: Dict[str, Dict[str, torch.Tensor]]) -> None:
+        """Inverse of `full_state` (after a densification built a new ShardedOptimizer over the new P rows)."""
+        for k, p in self.shards.items():
+            if k not in state:
+                continue
+            st = self.optimizer.state[p]
+            for name, val in state[k].items():
+                if isinstance(val, torch.Tensor) and val.dim() >= 1 and val.shape[0] == self.P:
+                    st[name] = val[self.lo:self.hi].clone()
+                else:
+                    st[name] = val.clone() if isinstance(val, torch.Tensor) else val
+
+
 def reduce_densification_stats(grad_norm_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,
                                group=None) -> None:
     """In-place: SUM the accumulated view-space gradient norms and visibility counts, MAX the radii."""
@@ -375,14 +470,16 @@ def reduce_densification_stats(grad_norm_accum: torch.Tensor, denom: torch.Tenso
 def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.Tensor], view_ids: Iterable[int],
             group=None, buckets: Optional[GradBuckets] = None, overlap: bool = False,
             feature_key: str = "semantic_feature", rows_leaves: Optional[Dict[str, Sequence[str]]] = None,
-            rows_chunks: int = 4) -> Dict[str, torch.Tensor]:
+            rows_chunks: int = 4, reduce: bool = True) -> Dict[str, torch.Tensor]:
     """One data-parallel step: `render_and_backward(view_id)` must run the op forward+backward for that view
     and accumulate into `leaves[k].grad`; afterwards `leaves[k].grad` holds the sum over all ranks' views for
     EVERY leaf (any names).  `overlap=True` starts the all-reduce of `leaves[feature_key].grad` inside the backward
     pass (one view per rank and step; the leaf must be fed to the op directly; needs the HIP extension).
     `rows_leaves` (with overlap): op gradient name -> the leaves that receive nothing but that gradient, e.g.
     {"sh": ("_features_dc", "_features_rest")} for the reference's model; those op gradients are reduced in `rows_chunks`
-    row ranges inside the per-Gaussian stage of the backward pass (RowsGradOverlap) and their leaves are not reduced again."""
+    row ranges inside the per-Gaussian stage of the backward pass (RowsGradOverlap) and their leaves are not reduced again.
+    `reduce=False`: no exchange - the leaves keep this rank's LOCAL sums (zeros for a leaf its views did not reach, so that
+    every rank holds the same key list): the input of `ShardedOptimizer.step`, whose reduce-scatter is the exchange."""
     for v in leaves.values():
         v.grad = None
     view_ids = list(view_ids)
@@ -396,6 +493,10 @@ def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.
                     v.grad = torch.zeros_like(v)
         return {k: v.grad for k, v in leaves.items() if v.grad is not None}
 
+    if not reduce:
+        for vid in view_ids:
+            render_and_backward(vid)
+        return all_grads()
     if overlap and len(view_ids) == 1 and _active(group):
         import contextlib
         rows_leaves = {n: tuple(k for k in ks if k in leaves) for n, ks in (rows_leaves or {}).items()}
@@ -447,7 +548,8 @@ def _side_streams(device, n: int) -> list:
 
 def dp_step_views(forward: Callable[[int], object], backward: Callable[[object], None], leaves: Dict[str, torch.Tensor],
                   view_ids: Iterable[int], group=None, buckets: Optional[GradBuckets] = None, overlap: bool = True,
-                  feature_key: str = "semantic_feature", n_streams: int = 2, accumulate: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+                  feature_key: str = "semantic_feature", n_streams: int = 2, accumulate: Optional[bool] = None,
+                  reduce: bool = True) -> Dict[str, torch.Tensor]:
     """One data-parallel step over SEVERAL views per rank (a step of `views_per_iter` views on fewer GPUs than views;
     SURVEY.md 8(e): config c4 is "8 views per iteration").  `forward(view_id)` runs the op forward and the loss of one view
     and returns a handle; `backward(handle)` runs its backward pass, accumulating into `leaves[k].grad`.  Afterwards
@@ -466,11 +568,14 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
         follow in the bucketed all-reduce.  (The row-chunked SH overlap of `dp_step` needs the op-level gradient to BE the
         step's gradient, i.e. one view per rank.)
 
-    The collective schedule depends on the leaves and the view COUNT only - every rank must render the same number of views."""
+    The collective schedule depends on the leaves and the view COUNT only - every rank must render the same number of views.
+    `reduce=False`: no exchange, the leaves keep this rank's local sums (see dp_step)."""
     for v in leaves.values():
         v.grad = None
     view_ids = list(view_ids)
     V = len(view_ids)
+    if not reduce:
+        overlap = False
     first = next(iter(leaves.values()))
     dev = first.device
     on_gpu = dev.type == "cuda"
@@ -547,7 +652,7 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
             if v.grad is None:
                 v.grad = torch.zeros_like(v)
     grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
-    if not active:
+    if not active or not reduce:
         return grads
     skip: List[str] = []
     if have_feat and overlap and on_gpu:

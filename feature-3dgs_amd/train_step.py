@@ -55,13 +55,17 @@ def densification_deltas(render_pkg: dict, P: int, device) -> tuple:
 def dp_train_step(render: Callable, loss_fn: Callable, model, cameras: Iterable, pipe, background: torch.Tensor,
                   group=None, overlap: bool = True, param_names: Sequence[str] = REFERENCE_PARAM_NAMES,
                   feature_param: str = "_semantic_feature", densification_stats: bool = True,
-                  sh_params: Sequence[str] = ("_features_dc", "_features_rest"), rows_chunks: int = 4) -> StepResult:
+                  sh_params: Sequence[str] = ("_features_dc", "_features_rest"), rows_chunks: int = 4,
+                  reduce: bool = True) -> StepResult:
     """Render + loss + backward for this rank's `cameras`, then make gradients and densification statistics
     global.  `render(camera, model, pipe, background)` is the reference's `gaussian_renderer.render`;
     `loss_fn(render_pkg, camera)` returns the scalar loss of one view.  The optimizer step stays with the caller
     (train.py:146-151), exactly as in the reference.  `sh_params`: the parameters that receive nothing but the op's SH
     gradient (scene/gaussian_model.py:113-116: get_features = cat(_features_dc, _features_rest)); with `overlap` their
-    all-reduce runs in `rows_chunks` row ranges inside the backward pass (empty: reduce them afterwards)."""
+    all-reduce runs in `rows_chunks` row ranges inside the backward pass (empty: reduce them afterwards).
+    `reduce=False`: the gradients stay LOCAL to the rank (the densification statistics are still made global) - for a sharded
+    optimizer, whose reduce-scatter is the exchange: `dp.ShardedOptimizer(...).step(result.grads)` (half the gradient
+    bytes of the all-reduce, optimizer work and state divided by the world size)."""
     params = {n: getattr(model, n) for n in param_names if getattr(model, n, None) is not None}
     cameras = list(cameras)
     P = next(iter(params.values())).shape[0]
@@ -88,12 +92,12 @@ def dp_train_step(render: Callable, loss_fn: Callable, model, cameras: Iterable,
         # several views per rank: pipelined over two streams, the feature gradient accumulated in place across the views and
         # reduced from inside the last view's backward pass (dp.dp_step_views)
         grads = dp.dp_step_views(forward, lambda loss: loss.backward(), params, range(len(cameras)), group=group,
-                                 overlap=overlap, feature_key=feature_param,
-                                 accumulate=None if overlap else False)
+                                 overlap=overlap and reduce, feature_key=feature_param,
+                                 accumulate=None if overlap else False, reduce=reduce)
     else:
         grads = dp.dp_step(render_and_backward, params, range(len(cameras)), group=group,
-                           overlap=overlap and len(cameras) == 1, feature_key=feature_param,
-                           rows_leaves={"sh": tuple(sh_params)} if sh_params else None, rows_chunks=rows_chunks)
+                           overlap=overlap and reduce and len(cameras) == 1, feature_key=feature_param,
+                           rows_leaves={"sh": tuple(sh_params)} if sh_params else None, rows_chunks=rows_chunks, reduce=reduce)
 
     if densification_stats:
         with torch.no_grad():

@@ -97,11 +97,6 @@ const char* f3dgs_last_error(void);
  *                    the column blocks are split over the four waves by quadrants as well (no wave without matrix work, partial
  *                    sums added in the flush), 0 by columns only
  *   "fwd_wide"       blend forward: 1 (default) 128-channel windows where more than 64 channels remain
- *   "fwd_bf16"       blend forward: the feature contraction on bf16 matrix instructions (v_mfma_f32_32x32x16_bf16, fp32
- *                    accumulation) with both operands split into two bf16 terms - the feature map then carries a relative
- *                    error of at most 7.6e-6 of max |feature| (a few 1e-6 typically) against the 1e-4 bar; colour, depth and
- *                    every blend decision stay exact fp32.  1 (default) channel windows of 64 / 128, 2 also of 32,
- *                    0 exact-fp32 matrix instructions everywhere (16x slower per multiply-add)
  *   "fwd_solo"       blend forward: 1 (default) one 64-thread workgroup per quadrant wave
  * Unknown names return F3DGS_ERR_INVALID_ARGUMENT.
  */

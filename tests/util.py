@@ -103,9 +103,13 @@ def harsh_scene(kind: str, P: int, C: int, width: int, height: int, seed: int, w
     """Scenes OUTSIDE the synthetic family of SURVEY.md 8(d) (uniform depth, log-uniform scales), for the comparison against
     the reference-compiled checker:
 
-      heavy_tail  log-normal scales (median 0.04, sigma_log 1.3, up to 4 world units: splats larger than the image), half of
-                  the Gaussians nearly transparent (opacity 0.004 .. 0.03: just above the 1/255 cut, so that pixels do NOT
-                  saturate early and the deep tile lists - tens of thousands of entries at 1080p - are actually walked)
+      heavy_tail  log-normal scales, independent per axis (median 0.04, sigma_log 1.3, up to 4 world units: splats larger than
+                  the image AND needles with axis ratios of 1 : 300, for which the fp32 cov2D / cov3D backward formulas of
+                  either implementation are ill-conditioned), half of the Gaussians nearly transparent (opacity 0.004 .. 0.03:
+                  just above the 1/255 cut, so that pixels do NOT saturate early and the deep tile lists are actually walked)
+      heavy_tail_round  the same size distribution with axis ratios of at most 2 : 1 (one log-normal size per Gaussian):
+                  splats larger than the image and tile lists of tens of thousands of entries at 1080p without the needles -
+                  the stress on the BLEND kernels alone
       opacity01   a third of the opacities exactly 0, a third exactly 1 (the 0.99 clamp, Q1; alpha = 0 < 1/255)
       zero_scales scales exactly 0 on all three axes (cov2D = the 0.3 low-pass alone), on one axis (flat splats), denormal
                   scales, and a few all-zero quaternions (the kernels do not normalise: R = I)
@@ -114,8 +118,12 @@ def harsh_scene(kind: str, P: int, C: int, width: int, height: int, seed: int, w
     from synth import make_scene
     sc = make_scene(P=P, C=C, width=width, height=height, seed=seed, with_depth_grad=with_depth_grad)
     g = torch.Generator().manual_seed(seed * 7919 + 13)
-    if kind == "heavy_tail":
-        sc["scales"] = torch.exp(math.log(0.04) + 1.3 * torch.randn(P, 3, generator=g)).clamp(1e-5, 4.0).contiguous()
+    if kind in ("heavy_tail", "heavy_tail_round"):
+        if kind == "heavy_tail":
+            sc["scales"] = torch.exp(math.log(0.04) + 1.3 * torch.randn(P, 3, generator=g)).clamp(1e-5, 4.0).contiguous()
+        else:
+            size = torch.exp(math.log(0.04) + 1.3 * torch.randn(P, 1, generator=g))
+            sc["scales"] = (size * (1.0 + torch.rand(P, 3, generator=g))).clamp(1e-5, 4.0).contiguous()
         low = torch.rand(P, generator=g) < 0.5
         faint = 0.004 + 0.026 * torch.rand(P, 1, generator=g)
         sc["opacities"] = torch.where(low[:, None], faint, sc["opacities"]).contiguous()
