@@ -665,6 +665,41 @@ def main():
                         "bytes_per_rank": nbytes, "comm_algbw_GBps": nbytes / (float(tt.item()) / args.steps) / 1e9,
                         "note": "same K steps without the exchange (max over ranks), and the bucketed all-reduce alone; "
                                 "ms_per_step below their sum = overlap achieved"}
+        # Two whole training steps, optimizer included: (A) this bench's exchange (all-reduce with its in-backward overlap) + the
+        # full FusedAdam step on every rank; (B) local gradients -> dp.ShardedOptimizer: reduce-scatter, FusedAdam on this rank's
+        # 1/N of the rows, all-gather of the updated parameters (half the gradient bytes; tests/test_dp_gloo.py: bit-identical
+        # parameters at world size 2).  What the first multi-GPU lease needs to decide between them.
+        try:
+            from fused_adam import FusedAdam
+            keys6 = ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")
+            mk = lambda t: FusedAdam([{"params": [t[k]], "lr": 1e-5} for k in keys6], lr=0.0, eps=1e-15)
+            opt_a = mk({k: leaves[k] for k in keys6})
+
+            def step_a(i):
+                _step(i)
+                opt_a.step()
+            step = step_a
+            for i in range(3):
+                step(i)
+            el_a, _ = timed(args.steps, per_step_events=False)
+            sh = dp.ShardedOptimizer({k: leaves_local[k] for k in keys6}, mk)
+
+            def step_b(i):
+                step_local(i)
+                sh.step({k: (leaves_local[k].grad if leaves_local[k].grad is not None else torch.zeros_like(leaves_local[k])) for k in keys6})
+            step = step_b
+            for i in range(3):
+                step(i)
+            el_b, _ = timed(args.steps, per_step_events=False)
+            step = _step
+            dp_breakdown.update({"train_step_allreduce_full_adam_ms": 1e3 * el_a / args.steps,
+                                 "train_step_sharded_optimizer_ms": 1e3 * el_b / args.steps,
+                                 "train_step_note": "whole steps INCLUDING the optimizer: all-reduce (overlapped with the backward pass) + "
+                                                    "FusedAdam on all rows, against reduce-scatter + FusedAdam on 1/N of the rows + all-gather of "
+                                                    "the parameters (dp.ShardedOptimizer; not overlapped)"})
+        except Exception as exc:     # diagnostic legs must never cost the bench line
+            dp_breakdown["train_step_note"] = f"sharded-optimizer legs failed: {type(exc).__name__}: {exc}"
+            step = _step
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         mpix = (V if V else world) * W * H / 1e6 / (elapsed / args.steps)

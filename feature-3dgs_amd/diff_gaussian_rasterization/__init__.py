@@ -16,6 +16,7 @@ non-HIP tensors.
 from __future__ import annotations
 
 import itertools
+import os
 import threading
 from typing import NamedTuple, Optional
 
@@ -63,7 +64,9 @@ _user_accumulator = False
 # of pure HBM writes in front of the backward pass.  From this many bytes on, the buffer is allocated by the FORWARD call of a
 # pass that will need it and cleared on a side stream while the (issue-bound, HBM-idle) blend forward runs; the backward call adds
 # into it.  None disables.  (At 128 MB - 1M x 32 - the fill is 0.03 ms and hiding it gains nothing: profiles/r04_notes.md.)
-prefill_feature_grad_bytes = 512 << 20
+prefill_feature_grad_bytes = int(os.environ.get("F3DGS_PREFILL_BYTES", 512 << 20))      # (read once at import; < 0: off)
+if prefill_feature_grad_bytes < 0:
+    prefill_feature_grad_bytes = None
 _fill_streams = {}
 
 

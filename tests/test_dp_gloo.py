@@ -278,3 +278,92 @@ def test_view_sharding_with_several_views_per_rank():
     assert dp.views_for_rank(16, 1, 2, 0, views_per_iter=8) == [4, 5, 6, 7]
     with pytest.raises(ValueError):
         dp.views_for_rank(16, 0, 2, 0, views_per_iter=3)
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "feature-3dgs_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dp
+    P = 121                                             # not a multiple of the world size: a ragged last shard
+    sc = _scene_for_view(0, P=P)
+    lrs = {"means3D": 1.6e-4, "shs": 2.5e-3, "semantic_feature": 1e-3, "opacities": 5e-2, "scales": 5e-3, "rotations": 1e-3}
+
+    def make_opt(tensors):
+        return torch.optim.Adam([{"params": [tensors[k]], "lr": lrs[k], "name": k} for k in KEYS], lr=0.0, eps=1e-15)
+
+    def local_grads(step, params):
+        # stands in for this rank's backward pass: depends on the CURRENT parameters, the rank and the step
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        return {k: (torch.randn(params[k].shape, generator=g) * (1.0 + params[k].abs())).float() for k in KEYS}
+
+    # ---- path A: all-reduce + the full optimizer on every rank (dp_step) --------------------------------------------------
+    pa = {k: sc[k].clone().requires_grad_(True) for k in KEYS}
+    opt_a = make_opt(pa)
+    # ---- path B: local gradients (reduce=False) + ShardedOptimizer -------------------------------------------------------
+    pb = {k: sc[k].clone().requires_grad_(True) for k in KEYS}
+    sh = dp.ShardedOptimizer(pb, make_opt)
+    assert (sh.lo, sh.hi) == dp.shard_range(P, rank, world)
+    for step in range(4):
+        def bw_a(_vid):
+            for k, g in local_grads(step, pa).items():
+                pa[k].grad = g
+        dp.dp_step(bw_a, pa, [rank])
+        opt_a.step()
+
+        def bw_b(_vid):
+            for k, g in local_grads(step, pb).items():
+                pb[k].grad = g
+        grads = dp.dp_step(bw_b, pb, [rank], reduce=False)
+        sh.step(grads, gather=(step % 2 == 0))
+        sh.gather()                                     # (a deferred gather: no-op where step() already gathered)
+        if step == 1:
+            # densification changes P: the moments leave as full tensors and come back into a new sharded optimizer
+            full = sh.full_state()
+            for k in KEYS:
+                st_a = opt_a.state[pa[k]]
+                assert torch.equal(full[k]["exp_avg"], st_a["exp_avg"]) and torch.equal(full[k]["exp_avg_sq"], st_a["exp_avg_sq"]), k
+            sh = dp.ShardedOptimizer(pb, make_opt)
+            sh.load_full_state(full)
+    state_floats = sum(v.numel() for p in sh.shards.values() for v in sh.optimizer.state[p].values() if isinstance(v, torch.Tensor) and v.dim() > 0)
+    np.savez(os.path.join(out_dir, f"sh{rank}.npz"), state_floats=state_floats,
+             **{"a_" + k: pa[k].detach().numpy() for k in KEYS}, **{"b_" + k: pb[k].detach().numpy() for k in KEYS})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_equals_the_all_reduce_path(tmp_path):
+    """dp.ShardedOptimizer (reduce-scatter of the gradients -> the optimizer on this rank's rows only -> all-gather of the
+    updated parameters) against all-reduce + the full optimizer on every rank, four Adam steps on a ragged sharding (121 rows
+    on 2 ranks) with a state hand-over (`full_state` / `load_full_state`: what a densification needs) in the middle: the
+    parameters are EQUAL BIT FOR BIT on both ranks (a sum of two terms does not depend on the order; Adam is elementwise), and
+    every rank holds optimizer state for its own rows only."""
+    world = 2
+    mp.spawn(_sharded_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (np.load(os.path.join(str(tmp_path), f"sh{r}.npz")) for r in range(world))
+    per_gaussian = 3 + 48 + 3 + 1 + 3 + 4
+    for k in KEYS:
+        assert np.array_equal(r0["a_" + k], r0["b_" + k]), k
+        assert np.array_equal(r1["a_" + k], r1["b_" + k]), k
+        assert np.array_equal(r0["b_" + k], r1["b_" + k]), k
+    assert int(r0["state_floats"]) == 2 * per_gaussian * 61 and int(r1["state_floats"]) == 2 * per_gaussian * 60
+
+
+def test_sharded_optimizer_world_size_one():
+    import dp
+    sc = _scene_for_view(0, P=50)
+    pa = {k: sc[k].clone().requires_grad_(True) for k in KEYS}
+    pb = {k: sc[k].clone().requires_grad_(True) for k in KEYS}
+    mk = lambda t: torch.optim.Adam([{"params": [t[k]], "lr": 1e-3} for k in KEYS], lr=0.0, eps=1e-15)
+    oa, sh = mk(pa), dp.ShardedOptimizer(pb, mk)
+    for step in range(3):
+        g = {k: torch.randn(pa[k].shape, generator=torch.Generator().manual_seed(step)) for k in KEYS}
+        for k in KEYS:
+            pa[k].grad = g[k].clone()
+        oa.step()
+        sh.step({k: g[k].clone() for k in KEYS})
+    for k in KEYS:
+        assert torch.equal(pa[k], pb[k]), k

@@ -132,6 +132,21 @@ def _solo_worker(rank, port, out_dir):
     full = {k: torch.zeros(1000, 3, device=dev) for k in g}
     dp.all_gather_params(shards, full)
     res["rs_ok"] = np.array([float(all(torch.equal(full[k], g[k]) for k in g))])
+    # dp.ShardedOptimizer over FusedAdam through the same one-rank group (reduce-scatter, the HIP Adam kernel on "its" rows,
+    # the hand-back of the updated rows) against FusedAdam on the full tensors: bit for bit
+    from fused_adam import FusedAdam
+    gen = torch.Generator(device=dev).manual_seed(3)
+    pa = {k: torch.randn(1000, w, device=dev, generator=gen).requires_grad_(True) for k, w in (("a", 3), ("b", 48))}
+    pb = {k: v.detach().clone().requires_grad_(True) for k, v in pa.items()}
+    mk = lambda t: FusedAdam([{"params": [t[k]], "lr": 1e-3} for k in t], lr=0.0, eps=1e-15)
+    oa, sh = mk(pa), dp.ShardedOptimizer(pb, mk)
+    for _ in range(3):
+        gr = {k: torch.randn(pa[k].shape, device=dev, generator=gen) for k in pa}
+        for k in pa:
+            pa[k].grad = gr[k].clone()
+        oa.step()
+        sh.step({k: gr[k].clone() for k in pb})
+    res["sharded_ok"] = np.array([float(all(torch.equal(pa[k], pb[k]) for k in pa))])
     np.savez(os.path.join(out_dir, "solo.npz"), **res)
     dist.destroy_process_group()
 
@@ -151,6 +166,7 @@ def test_rccl_code_paths_on_one_rank(tmp_path):
             w = leaves[k].grad.cpu().numpy().astype(np.float64)
             assert np.abs(got[f"{mode}_{k}"] - w).max() <= 1e-4 * np.abs(w).max() + 1e-12, (mode, k)
     assert got["rs_ok"][0] == 1.0
+    assert got["sharded_ok"][0] == 1.0
 
 
 def _run_views_fb(leaves, dev):
