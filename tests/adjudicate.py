@@ -17,7 +17,7 @@ The verdict functions turn them into statements the tests assert:
 
   * a pixel where product and reference differ by more than the bar is acceptable iff the product is within the bar of
     the truth under SOME threshold position in [1 - delta, 1 + delta] (then the difference is a borderline decision taken
-    the other way), or the product's error against the truth is within `slack` x the reference's own error against the
+    the other way), or the product's error against the truth is within `slack` (= SLACK) x the reference's own error against the
     truth (+ bar) (then the pixel is ill-conditioned for fp32 and the product is no further from the exact value than the
     reference is);
   * the same for gradient elements.
@@ -73,7 +73,10 @@ def forward_truth(scene: dict, pix: np.ndarray, pc=False, pv=False, dev="cuda:0"
     return done, out
 
 
-def forward_verdict(truths, prod: dict, ref: dict, bars: dict, slack=3.0):
+SLACK = 2.0           # "no further from the exact value than the reference is": e_prod <= SLACK e_ref + 1 (round 4: 3.0)
+
+
+def forward_verdict(truths, prod: dict, ref: dict, bars: dict, slack=SLACK):
     """Per adjudicated pixel: (ok, e_prod, e_ref, borderline) with errors normalised by the bars (<= 1 means inside).
     prod / ref: dicts like a truth variant (without n_contrib).  See the module docstring for the rule."""
     def nerr(val, tr):
@@ -175,9 +178,10 @@ def gradient_verdict(truth_prod, prod, truth_ref, ref, scale: float):
     """One tensor of one Gaussian (ill-conditioning is a property of the Gaussian's whole chain, not of one element): with the
     errors measured in units of the north-star bound, e = max_elements |x - t| / (1e-3 |t| + 1e-5 scale), the product is
     acceptable iff it is inside the bound of the exact value or no further outside it than the reference is from ITS exact
-    value: e_p <= 1 + e_r.  Returns (ok, e_p, e_r)."""
+    value - by the rule of the forward verdict: e_p <= 1 + SLACK e_r (where both are tens of bounds away - axis ratios of
+    1 : 1500 - which of the two fp32 evaluations lands closer is luck).  Returns (ok, e_p, e_r)."""
     tp, tr = np.asarray(truth_prod, np.float64), np.asarray(truth_ref, np.float64)
     p, r = np.asarray(prod, np.float64), np.asarray(ref, np.float64)
     e_p = float((np.abs(p - tp) / (1e-3 * np.abs(tp) + 1e-5 * scale)).max())
     e_r = float((np.abs(r - tr) / (1e-3 * np.abs(tr) + 1e-5 * scale)).max())
-    return e_p <= 1.0 + e_r, e_p, e_r
+    return e_p <= 1.0 + SLACK * e_r, e_p, e_r
