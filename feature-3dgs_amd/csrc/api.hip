@@ -30,87 +30,6 @@ thread_local int g_rows_ready_chunks = 1;
 thread_local int g_feature_accumulate = 0;
 thread_local LowresGrad g_lowres;      // consumed by the next f3dgs_backward of this thread
 
-// ---- feature-gradient prefill (f3dgs_prefill_feature_grad): the (P, C) buffer of the coming backward pass, cleared on a
-// library-owned side stream that forks from the caller's stream right in front of the blend forward ----------------------
-struct PrefillRequest {
-    float* buf = nullptr;
-    size_t bytes = 0;
-};
-thread_local PrefillRequest g_prefill_req;       // armed by f3dgs_prefill_feature_grad, consumed by the next f3dgs_forward of the thread
-struct PrefillPending {
-    float* buf;
-    hipEvent_t done;
-};
-// (process-wide: autograd runs the backward call on another host thread than the forward call)
-std::mutex g_prefill_mu;
-std::vector<PrefillPending> g_prefill_pending;
-std::vector<hipEvent_t> g_prefill_events;
-std::vector<std::pair<int, hipStream_t>> g_prefill_streams;      // one per device
-
-hipStream_t prefill_stream_locked() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    for (auto& ds : g_prefill_streams)
-        if (ds.first == dev) return ds.second;
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    g_prefill_streams.push_back({dev, st});
-    return st;
-}
-hipEvent_t prefill_event_locked() {
-    if (!g_prefill_events.empty()) { hipEvent_t e = g_prefill_events.back(); g_prefill_events.pop_back(); return e; }
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return e;
-}
-// Takes the thread's request when f3dgs_forward starts; `fork()` issues the fill on the side stream behind everything enqueued
-// on `s` so far; a call that returns before that point (P == 0, an argument error) clears the buffer on `s` itself - an armed
-// buffer is ALWAYS cleared by the forward call it was armed for.
-struct PrefillGuard {
-    PrefillRequest req;
-    hipStream_t s;
-    explicit PrefillGuard(hipStream_t st) : req(g_prefill_req), s(st) { g_prefill_req = PrefillRequest(); }
-    PrefillGuard(const PrefillGuard&) = delete;
-    PrefillGuard& operator=(const PrefillGuard&) = delete;
-    void fork() {
-        if (!req.buf) return;
-        bool ok = false;
-        {
-            std::lock_guard<std::mutex> lk(g_prefill_mu);
-            hipStream_t side = prefill_stream_locked();
-            hipEvent_t at = prefill_event_locked(), done = prefill_event_locked();
-            if (side && at && done && hipEventRecord(at, s) == hipSuccess && hipStreamWaitEvent(side, at, 0) == hipSuccess &&
-                hipMemsetAsync(req.buf, 0, req.bytes, side) == hipSuccess && hipEventRecord(done, side) == hipSuccess) {
-                for (auto it = g_prefill_pending.begin(); it != g_prefill_pending.end();)     // a stale entry of the same buffer
-                    if (it->buf == req.buf) { g_prefill_events.push_back(it->done); it = g_prefill_pending.erase(it); } else ++it;
-                g_prefill_pending.push_back({req.buf, done});
-                g_prefill_events.push_back(at);      // (recorded and waited for: free to be re-recorded by a later call)
-                ok = true;
-            } else {
-                (void)hipGetLastError();
-                if (at) g_prefill_events.push_back(at);
-                if (done) g_prefill_events.push_back(done);
-            }
-        }
-        if (ok) req.buf = nullptr;       // otherwise the destructor clears it on `s`
-    }
-    ~PrefillGuard() {
-        if (req.buf && req.bytes) (void)hipMemsetAsync(req.buf, 0, req.bytes, s);
-    }
-};
-// backward: the fill of `buf` (if one is pending) must have landed before the blend backward adds into it
-bool prefill_join(float* buf, hipStream_t s) {
-    std::lock_guard<std::mutex> lk(g_prefill_mu);
-    for (auto it = g_prefill_pending.begin(); it != g_prefill_pending.end(); ++it)
-        if (it->buf == buf) {
-            (void)hipStreamWaitEvent(s, it->done, 0);
-            g_prefill_events.push_back(it->done);
-            g_prefill_pending.erase(it);
-            return true;
-        }
-    return false;
-}
-
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -358,7 +277,7 @@ CountReadback* count_readback(hipStream_t s) {
 
 extern "C" {
 
-int f3dgs_version(void) { return 30300; }   // 3.3.0 (major * 10000 + minor * 100 + patch): 3.1 seven untested shape knobs removed, f3dgs_option_name; 3.2 f3dgs_set_feature_grad_lowres; 3.3 option bwd_bf16, f3dgs_prefill_feature_grad, 16-byte alignment checked
+int f3dgs_version(void) { return 30300; }   // 3.3.0 (major * 10000 + minor * 100 + patch): 3.1 seven untested shape knobs removed, f3dgs_option_name; 3.2 f3dgs_set_feature_grad_lowres; 3.3 option bwd_bf16, 16-byte alignment checked
 
 int f3dgs_set_option(const char* name, int value) {
     if (!name) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null option name");
@@ -393,19 +312,6 @@ void f3dgs_set_feature_grad_ready_callback(f3dgs_stage_fn fn, void* ctx) {
 }
 
 void f3dgs_set_feature_grad_accumulate(int on) { g_feature_accumulate = on ? 1 : 0; }
-
-int f3dgs_prefill_feature_grad(float* buf, size_t bytes) {
-    if (!buf || bytes == 0) { g_prefill_req = PrefillRequest(); return F3DGS_OK; }
-    if (reinterpret_cast<uintptr_t>(buf) & 15) return fail(F3DGS_ERR_INVALID_ARGUMENT, "prefill buffer must be 16-byte aligned");
-    g_prefill_req.buf = buf;
-    g_prefill_req.bytes = bytes;
-    return F3DGS_OK;
-}
-
-void* f3dgs_prefill_stream(void) {
-    std::lock_guard<std::mutex> lk(g_prefill_mu);
-    return prefill_stream_locked();
-}
 
 int f3dgs_set_feature_grad_lowres(const float* gx, int Hg, int Wg, const float* scale) {
     if (!gx) { g_lowres = LowresGrad(); return F3DGS_OK; }
@@ -442,7 +348,6 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
                   int* radii, int debug, void* stream, int* num_rendered) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)prefiltered;  // the reference only uses it to __trap() on an impossible cull (auxiliary.h:162-166)
-    PrefillGuard prefill(s);     // f3dgs_prefill_feature_grad: consumed by this call whatever it returns
     if (num_rendered) *num_rendered = 0;
     if (P < 0 || C < 0 || width <= 0 || height <= 0) return fail(F3DGS_ERR_INVALID_ARGUMENT, "bad sizes");
     if (!geometry_resize || !binning_resize || !image_resize) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null resize hook");
@@ -560,9 +465,6 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
         }
     }
 
-    // the coming backward pass's feature-gradient buffer: cleared on the side stream from HERE on - under the blend forward, which
-    // is issue-bound and leaves HBM idle (in front of the binning kernels, which are HBM-bound, the same fill costs them what it saves)
-    prefill.fork();
     launch_render_forward(vp, C, bin.ranges_enc, img.ranges, bin.point_list, geom.rec, semantic_feature, img.final_T,
                           img.n_contrib, out_color, out_feature_map, out_depth, img.tile_len, s);
     if ((rc = check_debug(debug, s, "render"))) return rc;
@@ -629,10 +531,11 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
 
     StageTimer tm(s);
     HIP_TRY(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
-    // (f3dgs_set_feature_grad_accumulate: the caller's buffer already holds the sum over its earlier views;
-    //  f3dgs_prefill_feature_grad: it was cleared under the forward pass - wait for that fill)
-    const bool prefilled = C > 0 && prefill_join(dL_dsemantic_feature, s);
-    if (C > 0 && !g_feature_accumulate && !prefilled) HIP_TRY(hipMemsetAsync(dL_dsemantic_feature, 0, (size_t)P * C * sizeof(float), s));
+    // (f3dgs_set_feature_grad_accumulate: the caller's buffer already holds the sum over its earlier views)
+    // Clearing this buffer ahead of time on a side stream - under the blend forward, forked right in front of it - was measured
+    // at c4 / c5 in round 5: the fill leaves the backward pass (0.32 -> 0.02 ms) and costs the forward blend MORE (1.95 -> 2.41 ms
+    // at c4, 3.40 -> 4.07 at c5: its feature-row gathers queue behind 2 - 2.5 GB of writes); profiles/r05_notes.md.
+    if (C > 0 && !g_feature_accumulate) HIP_TRY(hipMemsetAsync(dL_dsemantic_feature, 0, (size_t)P * C * sizeof(float), s));
     tm.mark("zero");
     if (R > 0)
         launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,

@@ -513,16 +513,6 @@ PYBIND11_MODULE(_C, m) {
           },
           "tensor (P*C float32, contiguous, on the op's device) that the following backward calls ADD dL/dsemantic_feature into "
           "(they then return an empty tensor for that gradient); None restores the default");
-    m.def("prefill_feature_grad", [](py::object t) {
-              if (t.is_none()) { check_status(f3dgs_prefill_feature_grad(nullptr, 0), "prefill_feature_grad"); return; }
-              torch::Tensor b = t.cast<torch::Tensor>();
-              TORCH_CHECK(b.is_cuda() && b.scalar_type() == torch::kFloat32 && b.is_contiguous(), "prefill buffer: contiguous float32 on a HIP device");
-              c10::hip::HIPGuardMasqueradingAsCUDA guard(b.device());
-              check_status(f3dgs_prefill_feature_grad(b.data_ptr<float>(), (size_t)b.numel() * sizeof(float)), "prefill_feature_grad");
-          },
-          "arms the next rasterize_gaussians call of this thread to clear `t` (the feature-gradient buffer of the coming backward "
-          "pass) on the library's side stream, under the blend forward (include/f3dgs.h: f3dgs_prefill_feature_grad)");
-    m.def("prefill_stream", []() { return (uintptr_t)f3dgs_prefill_stream(); }, "the library's side stream (hipStream_t as an integer)");
     m.def("set_grad_rows_hook", [](py::object fn, int chunks) { grad_rows_hook() = std::move(fn); grad_rows_chunks() = chunks > 0 ? chunks : 1; },
           py::arg("fn"), py::arg("chunks") = 4,
           "callable(row_begin, row_end, grads: dict) run inside rasterize_gaussians_backward after each of `chunks` row ranges of the "

@@ -16,7 +16,6 @@ non-HIP tensors.
 from __future__ import annotations
 
 import itertools
-import os
 import threading
 from typing import NamedTuple, Optional
 
@@ -59,16 +58,6 @@ def set_grad_rows_hook(on_rows, chunks: int = 4, on_done=None) -> None:
 
 _accum_leaf = None       # (data_ptr, numel) of the leaf whose .grad the accumulator is, or None: not checked
 _user_accumulator = False
-
-# The blend backward sums the feature gradient into a zero-filled (P, 1, C) buffer: 2 GB at 2M Gaussians x 256 channels, 0.32 ms
-# of pure HBM writes in front of the backward pass.  From this many bytes on, the buffer is allocated by the FORWARD call of a
-# pass that will need it and cleared by the library on a side stream that forks right in front of the (issue-bound, HBM-idle)
-# blend forward (include/f3dgs.h: f3dgs_prefill_feature_grad); the backward call adds into it.  None disables.  (At 128 MB -
-# 1M x 32 - the fill is 0.03 ms and hiding it gains nothing: profiles/r04_notes.md.  Forked from Python behind the forward
-# CALL the fill lands on the HBM-bound binning kernels and costs them what it saves: profiles/r05_notes.md.)
-prefill_feature_grad_bytes = int(os.environ.get("F3DGS_PREFILL_BYTES", 512 << 20))      # (read once at import; < 0: off)
-if prefill_feature_grad_bytes < 0:
-    prefill_feature_grad_bytes = None
 
 
 def set_feature_grad_accumulator(buffer: Optional[torch.Tensor], leaf: Optional[torch.Tensor] = None) -> None:
@@ -160,23 +149,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, colors_precomp, semantic_feature, opacities, scales, rotations, rs.scale_modifier,
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
                 rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        # feature-gradient buffer of the coming backward pass, cleared under the blend forward (see prefill_feature_grad_bytes)
-        gbuf = None
-        if (prefill_feature_grad_bytes is not None and not _user_accumulator and ctx.needs_input_grad[4]
-                and semantic_feature.is_cuda and semantic_feature.numel() * 4 >= max(1, prefill_feature_grad_bytes)):
-            gbuf = torch.empty(semantic_feature.shape, dtype=torch.float32, device=semantic_feature.device)
-            _C.prefill_feature_grad(gbuf)       # consumed by the call below whatever it does
-        try:
-            (num_rendered, color, feature_map, depth, radii, geomBuffer, binningBuffer, imgBuffer) = _call_with_snapshot(
-                _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
-        except Exception:
-            if gbuf is not None:
-                _C.prefill_feature_grad(None)       # (the binding may have raised before the library consumed the request)
-            raise
-        ctx.prefill = gbuf
-        if gbuf is not None:
-            # the fill runs on the library's stream: the allocator must not hand the block out again before it has passed
-            gbuf.record_stream(torch.cuda.ExternalStream(_C.prefill_stream(), device=gbuf.device))
+        (num_rendered, color, feature_map, depth, radii, geomBuffer, binningBuffer, imgBuffer) = _call_with_snapshot(
+            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         # undefined upstream gradients arrive as None instead of zero tensors: `radii` is an integer output, autograd would
@@ -212,12 +186,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         offer = _lowres_offers.pop(ctx.call_serial, None)
         if offer is not None:       # this call's feature-map gradient (or part of it) waits at the loss's resolution
             _C.set_feature_grad_lowres(offer[0], offer[1])
-        # the buffer cleared under the forward pass: used once (a second backward pass over a retained graph takes the plain path)
-        prefill, ctx.prefill = getattr(ctx, "prefill", None), None
-        if prefill is not None and _user_accumulator:
-            prefill = None
-        if prefill is not None:
-            _C.set_feature_grad_accumulator(prefill)          # (the library waits for the fill: f3dgs_prefill_feature_grad)
         try:
             (grad_means2D, grad_colors_precomp, grad_semantic_feature, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
              grad_sh, grad_scales, grad_rotations) = _call_with_snapshot(
@@ -225,11 +193,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         finally:
             if offer is not None:
                 _C.set_feature_grad_lowres(None)
-            if prefill is not None:
-                _C.set_feature_grad_accumulator(None)
-        if prefill is not None:
-            grad_semantic_feature = prefill
-        elif grad_semantic_feature.numel() == 0 and semantic_feature.numel() != 0:
+        if grad_semantic_feature.numel() == 0 and semantic_feature.numel() != 0:
             grad_semantic_feature = None        # accumulated into the buffer of set_feature_grad_accumulator
         if _backward_done_hook is not None:
             _backward_done_hook()

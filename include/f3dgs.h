@@ -364,24 +364,6 @@ void f3dgs_set_feature_grad_ready_callback(f3dgs_stage_fn fn, void* ctx);
 void f3dgs_set_feature_grad_accumulate(int on);
 
 /*
- * The zero-fill of the feature-gradient buffer taken out of the backward pass (no counterpart in the reference, which
- * zero-fills every gradient tensor in its binding, rasterize_points.cu:163-173): the blend backward SUMS into
- * dL_dsemantic_feature, (P, C) floats - 2 GB at 2M Gaussians x 256 channels, 0.32 ms of pure HBM writes.  A caller that
- * knows a backward pass will follow hands the buffer over BEFORE the forward call:
- *     f3dgs_prefill_feature_grad(buf, P * C * sizeof(float));   f3dgs_forward(...);   ...   f3dgs_backward(..., buf, ...);
- * The next f3dgs_forward of this host thread clears `buf` on a library-owned side stream that forks from the caller's stream
- * right in front of the blend forward (issue-bound, HBM idle) - ordered behind everything the caller had enqueued before;
- * the f3dgs_backward call (any host thread) that receives `buf` as dL_dsemantic_feature waits for the fill and adds into
- * the buffer without clearing it.  A forward call that returns early (P == 0, an error) clears the buffer on the caller's
- * stream instead: an armed buffer is always cleared by the forward call it was armed for.  `buf` must stay allocated until
- * that backward call - or, if none follows, until the side stream (f3dgs_prefill_stream) has passed the fill.
- * buf == NULL disarms.  16-byte aligned.
- */
-int f3dgs_prefill_feature_grad(float* buf, size_t bytes);
-/* The side stream (hipStream_t) of the current device, created on first use; NULL on failure. */
-void* f3dgs_prefill_stream(void);
-
-/*
  * Second optional notification inside f3dgs_backward (no counterpart in the reference): with a callback registered the
  * per-Gaussian stage (K8 + K9, R/cuda_rasterizer/backward.cu:145-404 - row-parallel) runs as `chunks` launches over
  * consecutive row ranges, and `fn(ctx, stream, row_begin, row_end)` is called on the calling host thread right after the
