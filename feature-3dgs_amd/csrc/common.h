@@ -171,7 +171,7 @@ struct Options {
     int bwd_m44;         // pixel-lane blend backward: the colour / depth sums on 4 x 4 matrix blocks (default 1)
     int bwd_split16;     // pixel-lane blend backward, up to 16 channels: feature and moment blocks split over the waves by quadrants (default 1)
     int bwd_bf16;        // pixel-lane blend backward: every contraction on bf16 matrix instructions, operands as two bf16 terms (default 1)
-    int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 4; needs feature_mfma
+    int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 0 (C > 4 with bwd_bf16 = 0); needs feature_mfma
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
     int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)
     int sort_onesweep;   // 1: single-pass radix passes with decoupled look-back (measured slower on MI355X; default 0)

@@ -727,7 +727,9 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     // feature and moment blocks are split over the waves by quadrants, option bwd_split16).  c2-sized scenes, ms per launch,
     // instance-lane / pixel-lane: C = 0 0.452 / 0.603, 3 0.568 / 0.603, 8 0.651 / 0.615, 12 0.66 / 0.619, 16 0.66 / 0.618
     // (a low-resolution feature-map gradient is taken by the pixel-lane kernel only: the caller has checked feature_mfma)
-    if (low || ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > 4)) && opt.feature_mfma)) {
+    // (round 5, with the bf16 contractions - option bwd_bf16 - the pixel-lane kernel wins from the first channel on: c2-sized scenes,
+    // instance-lane / pixel-lane: C = 0 0.445 / 0.491, 3 0.567 / 0.509, 4 0.566 / 0.510, 8 0.650 / 0.519)
+    if (low || ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > (opt.bwd_bf16 ? 0 : 4))) && opt.feature_mfma)) {
         if (opt.bwd_order && tile_len && tile_order) {
             launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, s);
             a.order = tile_order;

@@ -83,7 +83,8 @@ const char* f3dgs_last_error(void);
  *   "sort_onesweep"  0 (default): three-kernel radix passes; 1: single-pass radix scatter with decoupled look-back
  *                    (measured slower on MI355X, kept as a tested alternative)
  *   "bwd_pl"         blend backward formulation: 1 pixel-lane kernel (all sums on the matrix pipe), 0 instance-lane
- *                    kernel, -1 (default) by channel count
+ *                    kernel, -1 (default) by channel count (pixel-lane from the first feature channel on; from five with
+ *                    bwd_bf16 = 0)
  *   "bwd_half"       instance-lane blend backward: 1 (default) chunks of 32 instances against two pixel halves,
  *                    0 chunks of 64
  *   "bwd_order"      blend backward: 1 (default) workgroups take the tiles longest walk first
