@@ -714,20 +714,23 @@ def main():
             dom_ms = stage_ms.get(kernel_stage[dom], float("nan"))
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
         profiled = None
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
             f = os.path.join(ROOT, "profiles", name)
             if os.path.exists(f):
                 try:
-                    d = json.load(open(f))
+                    raw = open(f, "rb").read()
+                    d = json.loads(raw)
+                    import hashlib
                     profiled = {"source": f"profiles/{name} (rocprofv3 --pmc, separate runs of this config; NOT measured by "
-                                          f"this process)", **({dom: d[dom]} if dom in d else {})}
+                                          f"this process)", "source_sha256_16": hashlib.sha256(raw).hexdigest()[:16],
+                                **({dom: d[dom]} if dom in d else {})}
                     break
                 except Exception:
                     pass
         # VALU-issue fraction of both blend kernels from the committed SQ counters (same caveat: a separate run)
         sq_names = {"render_bwd": "render_backward", "render_fwd": "render_forward", "preprocess": "preprocess_kernel",
                     "preprocess_bwd": "preprocess_backward_kernel"}
-        for sqf in ("r04_pmc_sq_counters.json", "r03_pmc_sq_counters.json", "r02_pmc_sq_counters.json"):
+        for sqf in ("r05_pmc_sq_counters.json", "r04_pmc_sq_counters.json", "r03_pmc_sq_counters.json", "r02_pmc_sq_counters.json"):
             f = os.path.join(ROOT, "profiles", sqf)
             if profiled is None or not os.path.exists(f):
                 continue
@@ -765,7 +768,10 @@ def main():
             "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if V else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "blend_kernels": "vector pipe only (option feature_mfma = 0)" if args.valu else "feature / gradient contractions on the matrix pipe (exact fp32)",
+            "blend_kernels": "vector pipe only (option feature_mfma = 0)" if args.valu else
+                             "forward: feature contraction on exact-fp32 matrix instructions; backward: every per-Gaussian sum on bf16 matrix "
+                             "instructions with two-term operands (fp32 accumulation, option bwd_bf16; gradients within 1e-4 |g| + 1e-5 max|g| "
+                             "of the exact-fp32 contraction, tests/test_gpu_parity.py)",
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {scene['sh_degree']}, feat_dim={C}, "
                                    + (f"{V} views per step ({per_rank} per GPU, rotated 5 degrees apart, pipelined over two streams, "
                                       f"gradients accumulated across the views)" if V else "one view per GPU")
@@ -786,9 +792,10 @@ def main():
                          "traffic_source": (profiled or {}).get("source") if args.config == "c3" and not V else None,
                          "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": dom_ms,
                          "kernel_ms_source": "HIP events around the kernel on the op's stream, inside the timed region",
+                         "traffic_source_sha256_16": (profiled or {}).get("source_sha256_16") if args.config == "c3" and not V else None,
                          "note": "HBM is the roofline the contract names for this path; the kernel itself is bound by "
-                                 "vector + fp32 matrix issue, which exclude each other on a SIMD (DESIGN.md 3.5, profiles/): see "
-                                 "`profiled.valu_issue.*.vector_plus_matrix_frac`"},
+                                 "vector-instruction issue (an exponential, a reciprocal, three threshold tests and ~30 dependent operations "
+                                 "per (pixel, Gaussian) pair; DESIGN.md 3.5, profiles/): see `profiled.valu_issue.*`"},
             "profiled": profiled,
             "roofline_whole_step": {"algorithmic_bytes": alg["total"], "algorithmic_bytes_min": alg["total_min"],
                                     "achieved": alg["total"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
@@ -805,7 +812,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_kw)
             out["cpu_reference_path_c1"] = cpu_reference_path_c1(dev)
-            nm, red = _committed(("r04_cpu_c3_reduced.json",))
+            nm, red = _committed(("r05_cpu_c3_reduced.json", "r04_cpu_c3_reduced.json"))
             out["cpu_reference_path_c3_reduced"] = ({"source": f"profiles/{nm} (bench.py --cpu-reduced-c3 on a GPU box's host; minutes of "
                                                                f"host time, not re-run here)", **red} if red else
                                                     {"status": "not measured in this tree: run bench.py --cpu-reduced-c3"})

@@ -617,26 +617,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
     render_forward_mfma_body<CH, 1, 32, 2, BASE>(a);
 }
 
-// 256 channels in one window (option fwd_wide = 2, where more than 128 channels remain): 256 accumulator registers, ONE wave per
-// SIMD - the blend weights of an entry are evaluated once for 256 channels instead of twice for 128 each; fp32 matrix and vector
-// instructions exclude each other on a SIMD anyway (tools/pipe_probe.hip), so the second wave only ever hid memory latency.
-template <int CH, bool BASE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) render_forward_mfma_kernel_w1(FwdArgs a) {
-    render_forward_mfma_body<CH, 1, 32, 2, BASE>(a);
-}
-
 // The 128-channel shape needs 70 KB of LDS per four-wave workgroup (above the 64 KB default limit): the limit is raised once
 // per device; where that is refused the caller falls back to 64-channel windows.
-template <bool BASE, int CH = 128>
+template <bool BASE>
 bool wide_shape_usable() {
     constexpr int MAX_DEV = 64;
     static std::atomic<int> state[MAX_DEV];      // 0: not asked yet, 1: usable, -1: refused (the ABI is re-entrant across threads)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
     if (state[dev].load(std::memory_order_acquire) == 0) {
-        const void* fn = CH == 128 ? reinterpret_cast<const void*>(&render_forward_mfma_kernel_w2<128, BASE>)
-                                   : reinterpret_cast<const void*>(&render_forward_mfma_kernel_w1<256, BASE>);
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(FwdChunkMF<CH, 32>)));
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_forward_mfma_kernel_w2<128, BASE>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(FwdChunkMF<128, 32>)));
         if (e != hipSuccess) (void)hipGetLastError();     // not sticky: the narrower windows take over
         state[dev].store(e == hipSuccess ? 1 : -1, std::memory_order_release);
     }
@@ -650,8 +641,7 @@ void launch_shape(const FwdArgs& a, hipStream_t s) {
     const dim3 grid(solo ? 4 * a.gx * a.gy : a.gx * a.gy), block(solo ? 64 : 256);
     if constexpr (CH <= 32) hipLaunchKernelGGL((render_forward_mfma_kernel_w4<CH, BASE>), grid, block, lds, s, a);
     else if constexpr (CH <= 64) hipLaunchKernelGGL((render_forward_mfma_kernel_w3<CH, BASE>), grid, block, lds, s, a);
-    else if constexpr (CH <= 128) hipLaunchKernelGGL((render_forward_mfma_kernel_w2<CH, BASE>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((render_forward_mfma_kernel_w1<CH, BASE>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((render_forward_mfma_kernel_w2<CH, BASE>), grid, block, lds, s, a);
 }
 template <int CH>
 void launch_one_mf(const FwdArgs& a, hipStream_t s) {
@@ -696,9 +686,8 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     // blend weights of the whole list: fewer, wider windows - two waves per SIMD, the matrix pipe hides the rest)
     const bool wide_ok = mf && options().fwd_wide != 0 && C > 64 && wide_shape_usable<true>() && wide_shape_usable<false>();
     const int wide = wide_ok ? 128 : 64;
-    const bool wider_ok = wide_ok && options().fwd_wide >= 2 && C > 128 && wide_shape_usable<true, 256>() && wide_shape_usable<false, 256>();
     for (int c0 = 0; c0 < C;) {
-        const int win = (wider_ok && C - c0 > 128) ? 256 : (C - c0 > 64) ? wide : 64;
+        const int win = (C - c0 > 64) ? wide : 64;
         a.c0 = c0; a.nc = min(win, C - c0); a.write_base = (c0 == 0);
         c0 += win;
         // up to four channels: vector pipe; 5..16: the 32-column matrix shape with colour and depth in its spare columns
@@ -706,8 +695,7 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
         else if (a.nc <= 16) { if (mf) launch_one_mf<16>(a, s); else launch_one<16, 1>(a, s); }
         else if (a.nc <= 32) { if (mf) launch_one_mf<32>(a, s); else launch_one<32, 2>(a, s); }
         else if (a.nc <= 64) { if (mf) launch_one_mf<64>(a, s); else launch_one<64, 1>(a, s); }
-        else if (a.nc <= 128) launch_one_mf<128>(a, s);
-        else launch_one_mf<256>(a, s);
+        else launch_one_mf<128>(a, s);
     }
 }
 
