@@ -58,6 +58,17 @@ if len(pix):
     ok, ep, er, bl = adj.forward_verdict(truths, pv_, rv_, bars)
     print(f"adjudicated {len(sel)} pixels: ok {int(ok.sum())}, borderline {int(bl.sum())}; e_prod/bar: median {np.median(ep):.2f} max {ep.max():.2f}; "
           f"e_ref/bar: median {np.median(er):.2f} max {er.max():.2f}")
+    # is the product's side of a borderline decision biased?  (exp2 on a pre-scaled conic against the
+    # reference's exp): sign of (value - fp64 value) of the final transmittance and of n_contrib on the adjudicated pixels
+    dTp = np.asarray(pv_["final_T"], np.float64) - truths[0]["final_T"]
+    dTr = np.asarray(rv_["final_T"], np.float64) - truths[0]["final_T"]
+    ncp = img_prod["n_contrib"][sel].astype(np.int64) - truths[0]["n_contrib"]
+    ncr = img_ref["n_contrib"][sel].astype(np.int64) - truths[0]["n_contrib"]
+    big_p, big_r = np.abs(dTp) > 1e-5, np.abs(dTr) > 1e-5
+    print(f"decision bias on the {len(sel)} adjudicated pixels: final_T off by more than 1e-5 - product {int(big_p.sum())} ({int((dTp[big_p] > 0).sum())} too "
+          f"transparent = an entry dropped, {int((dTp[big_p] < 0).sum())} too opaque = an entry kept), reference {int(big_r.sum())} "
+          f"({int((dTr[big_r] > 0).sum())} / {int((dTr[big_r] < 0).sum())}); n_contrib against fp64: product {int((ncp > 0).sum())} longer / "
+          f"{int((ncp < 0).sum())} shorter, reference {int((ncr > 0).sum())} / {int((ncr < 0).sum())}")
     for j in np.argsort(-ep)[:12]:
         for k_ in bars:
             dp_ = np.abs(np.asarray(pv_[k_], np.float64)[j] - truths[0][k_][j]).max() / bars[k_]

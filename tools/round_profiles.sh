@@ -13,6 +13,9 @@ timeout 200 python bench.py --no-cpu-baseline --valu > $OUT/${TAG}_bench_c3_valu
 timeout 300 python bench.py --config c5 --densify-every 5 --steps 40 --warmup 10 > $OUT/${TAG}_bench_c5_densify.json 2> $OUT/bench_c5_densify.err
 timeout 300 python bench.py --config c4 --views-per-iter 8 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_c4_8views.json 2> $OUT/bench_c4_8views.err
 timeout 300 python bench.py --config c3 --views-per-iter 8 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_c3_8views.json 2> $OUT/bench_c3_8views.err
+# 1b'. the LSeg width of the reference's README (NUM_SEMANTIC_CHANNELS 512) on c4's 2M Gaussians, and the fp32 shape of the blend backward
+timeout 200 python bench.py --config c4 --feat-dim 512 --no-cpu-baseline --steps 20 --warmup 5 > $OUT/${TAG}_bench_c4_C512.json 2> $OUT/bench_c4_C512.err
+F3DGS_BWD_BF16=0 timeout 200 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > $OUT/${TAG}_bench_c3_bwd_fp32.json 2> $OUT/bench_c3_bwd_fp32.err
 timeout 200 python tools/adam_bench.py > $OUT/${TAG}_adam.txt 2>&1
 timeout 200 python tools/adam_bench.py 5000000 128 >> $OUT/${TAG}_adam.txt 2>&1
 timeout 200 python tools/feature_loss_bench.py > $OUT/${TAG}_feature_loss.txt 2>&1
@@ -41,6 +44,10 @@ cd $ROOT
 python tools/pmc_summary.py $OUT/${TAG}_pmc_sq_counters.json $OUT/pmc_sq
 python tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_raw.json $OUT/pmc_fetch $OUT/pmc_write
 python tools/pmc_summary.py --traffic $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_hbm_raw.json
+# 3b. decision bias of the product on borderline blend decisions (c4, the two views where round 4 saw the largest product-vs-fp64 medians)
+if [ -z "$QUICK" ]; then
+for v in 4 5; do timeout 200 python tools/adjudicate_probe.py c4 $v strict 2>&1 | grep -E "^(mode|c4 yaw|adjudicated|decision bias)" >> $OUT/${TAG}_decision_bias_c4.txt; done
+fi
 # 4. work statistics of the blend kernels (lane utilisation)
 timeout 200 python tools/pair_stats.py c3 > $OUT/${TAG}_pair_stats_c3.txt 2>&1
 rm -rf $OUT/kt $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
