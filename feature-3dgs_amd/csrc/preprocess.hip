@@ -399,7 +399,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
 // A lane owns one Gaussian and produces its run of the list; the 64 runs of a wave are adjacent in the list (offsets are
 // an exclusive scan in this very order), so the wave first lays them out in LDS and then copies the whole range out with
 // contiguous stores (a lane storing straight to its own run writes one dword to 64 different places per instruction:
-// 0.061 ms for 42 MB at c3).  Waves whose range exceeds the LDS slice (a few huge splats) store directly.
+// 0.061 ms for 42 MB at c3).  Ranges longer than the LDS slice are staged window by window (round 5).
 constexpr int EMIT_CAP = 1024;      // list entries per wave in LDS (8 KB)
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_sums,
@@ -433,37 +433,49 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
     const uint32_t inc = wave_incl_scan(cnt, lane);
     const uint32_t off0 = base + inc - cnt;
     const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
-    const bool staged = total <= (uint32_t)EMIT_CAP;          // wave-uniform
+    // Every wave stages its range of the list in LDS in windows of EMIT_CAP entries and stores each window contiguously
+    // (coalesced 256-byte requests).  A lane walks its splat's rows and columns as a resumable state machine - (y, x, xb) survive
+    // from window to window - so ranges of any length are staged: until round 5 a range above one window (c5: 33 tiles per
+    // splat, 2100 entries per wave; a splat larger than the image: 8160 entries from ONE lane) was stored straight from the
+    // per-lane loops, 64 scattered dwords per store instruction - the memory pipeline's address rate, not the loop, bound it.
+    uint32_t off = off0;
+    const uint32_t my_end = off0 + cnt;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    CullParams ck{};
+    float cdet_inv = 0.f;
     if (cnt != 0) {
-        uint32_t off = off0;
-        const float4 q0 = rec[g].q0, q1 = rec[g].q1;
+        q0 = rec[g].q0; q1 = rec[g].q1;
         const int radius = __float_as_int(rec[g].q2.z);  // integer bits stored by preprocess_kernel
-        int x0, y0, x1, y1;
         tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
-        const CullParams ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-        const float cdet_inv = __builtin_amdgcn_rcpf(q0.z * q1.x - q0.w * q0.w);
-        for (int y = y0; y < y1; y++) {
-            int xa = x0, xb = x1 - 1;
-            if (cull && !row_span(ck, cdet_inv, y, x0, x1, xa, xb)) continue;
-            for (int x = xa; x <= xb; x++) {
-                if (staged) {
-                    s_tile[w][off - base] = (uint32_t)(y * gx + x);
-                    s_id[w][off - base] = g;
-                } else {
-                    inst_tile[off] = (uint32_t)(y * gx + x);
-                    inst_id[off] = g;
-                }
-                off++;
-            }
-        }
+        ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+        cdet_inv = __builtin_amdgcn_rcpf(q0.z * q1.x - q0.w * q0.w);
     }
-    if (staged) {
+    int y = y0 - 1, x = 0, xb = -1;          // "row exhausted": the first step advances to row y0
+    for (uint32_t wbase = base; wbase < base + total; wbase += (uint32_t)EMIT_CAP) {
+        const uint32_t wend = min(wbase + (uint32_t)EMIT_CAP, base + total);
+        while (off < my_end && off < wend) {
+            if (x > xb) {                        // next row of the rectangle that has tiles under the ellipse
+                y++;
+                if (y >= y1) { off = my_end; break; }       // (cannot happen: the count came from the same spans; never spin)
+                int xa = x0;
+                xb = x1 - 1;
+                if (cull && !row_span(ck, cdet_inv, y, x0, x1, xa, xb)) { xb = -1; x = 0; continue; }
+                x = xa;
+                continue;
+            }
+            s_tile[w][off - wbase] = (uint32_t)(y * gx + x);
+            s_id[w][off - wbase] = g;
+            off++;
+            x++;
+        }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes have landed
-        for (uint32_t k = lane; k < total; k += 64) {
-            inst_tile[base + k] = s_tile[w][k];
-            inst_id[base + k] = s_id[w][k];
+        for (uint32_t k = wbase + lane; k < wend; k += 64) {
+            inst_tile[k] = s_tile[w][k - wbase];
+            inst_id[k] = s_id[w][k - wbase];
         }
+        __builtin_amdgcn_wave_barrier();          // the window is re-used
     }
 }
 
