@@ -202,31 +202,51 @@ __constant__ const float K3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4
 // The SH block of one Gaussian is M*3 contiguous floats; read as V3 (12-byte) elements.
 __device__ __forceinline__ V3 ldv3(const float* p, int k) { return {p[3 * k], p[3 * k + 1], p[3 * k + 2]}; }
 
-__device__ V3 sh_to_rgb(int deg, V3 mean, const float* campos, const float* sh, uint8_t& clamp_bits) {
+// The colour sum in the reference's order of operations (forward.cu:30-61; no contraction: bit-equal colours), cut where the
+// two halves of the staged SH row meet: coefficients 0..7 (`sh_first`) and 8..15 (`sh_second`, given at indices 0..7).  The
+// band-2 sum `res + t4 + t5 + t6 + t7 + t8` is left-associative, so the cut after t7 changes nothing.
+struct ShDir {
+    float x, y, z;
+};
+__device__ __forceinline__ ShDir sh_dir(V3 mean, const float* campos) {
     V3 dir = {mean.x - campos[0], mean.y - campos[1], mean.z - campos[2]};
     const float len = sqrtf(dot3(dir, dir));
-    dir = {dir.x / len, dir.y / len, dir.z / len};
+    return {dir.x / len, dir.y / len, dir.z / len};
+}
+__device__ __forceinline__ V3 sh_first(int deg, ShDir d, const float* sh) {
     V3 res = K0 * ldv3(sh, 0);
     if (deg > 0) {
-        const float x = dir.x, y = dir.y, z = dir.z;
+        const float x = d.x, y = d.y, z = d.z;
         res = res - (K1 * y) * ldv3(sh, 1) + (K1 * z) * ldv3(sh, 2) - (K1 * x) * ldv3(sh, 3);
         if (deg > 1) {
             const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
             res = res + (K2[0] * xy) * ldv3(sh, 4) + (K2[1] * yz) * ldv3(sh, 5) +
-                  (K2[2] * (2.0f * zz - xx - yy)) * ldv3(sh, 6) + (K2[3] * xz) * ldv3(sh, 7) +
-                  (K2[4] * (xx - yy)) * ldv3(sh, 8);
-            if (deg > 2) {
-                res = res + ((K3[0] * y) * (3.0f * xx - yy)) * ldv3(sh, 9) + ((K3[1] * xy) * z) * ldv3(sh, 10) +
-                      ((K3[2] * y) * (4.0f * zz - xx - yy)) * ldv3(sh, 11) +
-                      ((K3[3] * z) * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * ldv3(sh, 12) +
-                      ((K3[4] * x) * (4.0f * zz - xx - yy)) * ldv3(sh, 13) + ((K3[5] * z) * (xx - yy)) * ldv3(sh, 14) +
-                      ((K3[6] * x) * (xx - 3.0f * yy)) * ldv3(sh, 15);
-            }
+                  (K2[2] * (2.0f * zz - xx - yy)) * ldv3(sh, 6) + (K2[3] * xz) * ldv3(sh, 7);
+        }
+    }
+    return res;
+}
+__device__ __forceinline__ V3 sh_second(int deg, ShDir d, V3 res, const float* sh8, uint8_t& clamp_bits) {
+    if (deg > 1) {
+        const float x = d.x, y = d.y, z = d.z;
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y;
+        res = res + (K2[4] * (xx - yy)) * ldv3(sh8, 0);
+        if (deg > 2) {
+            res = res + ((K3[0] * y) * (3.0f * xx - yy)) * ldv3(sh8, 1) + ((K3[1] * xy) * z) * ldv3(sh8, 2) +
+                  ((K3[2] * y) * (4.0f * zz - xx - yy)) * ldv3(sh8, 3) +
+                  ((K3[3] * z) * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * ldv3(sh8, 4) +
+                  ((K3[4] * x) * (4.0f * zz - xx - yy)) * ldv3(sh8, 5) + ((K3[5] * z) * (xx - yy)) * ldv3(sh8, 6) +
+                  ((K3[6] * x) * (xx - 3.0f * yy)) * ldv3(sh8, 7);
         }
     }
     res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
     clamp_bits = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
     return {fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f)};
+}
+// all sixteen coefficients at `sh` (any M >= the degree's count: coefficients beyond it are not read)
+__device__ V3 sh_to_rgb(int deg, V3 mean, const float* campos, const float* sh, uint8_t& clamp_bits) {
+    const ShDir d = sh_dir(mean, campos);
+    return sh_second(deg, d, sh_first(deg, d, sh), sh + 24, clamp_bits);
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D, ViewParams vp,
@@ -243,7 +263,7 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
 // an odd stride.  Round 3 read the coefficients per lane straight from global memory: 48 dword requests per lane with a
 // 192-byte lane stride (64 cache lines per request, the 48 KB a workgroup touches do not fit its 32 KB vector cache) in
 // four dependent rounds (one per SH band) - 3.8 TB/s, 47 % of the kernel's cycles vector-pipe busy.
-constexpr int PF_ROW = 49;        // LDS row stride of the SH tile (floats): odd, so that the per-lane rows are conflict-free
+constexpr int PF_ROW = 25;        // LDS row stride of the SH tile (floats; half a row of 48 + 1): odd, so that the per-lane rows are conflict-free
 template <int M3C>
 __global__ void __launch_bounds__(256)
 preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
@@ -307,31 +327,50 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         alive = true;
     } while (false);
 
-    // ---- part 2 (M3C): the SH rows of the wave's surviving Gaussians -> the wave's LDS tile
+    // ---- part 2 (M3C): the SH rows of the wave's surviving Gaussians -> the wave's LDS tile, in two HALVES (coefficients 0..7,
+    // then 8..15, through the same 64 x 25 floats: 25 KB per workgroup instead of 49 - the tile, not the 96 registers, capped
+    // the kernel at three waves per SIMD).  All twelve requests of a lane go out up front; the second half waits in registers
+    // while the first is summed (sh_first), then takes its place (sh_second).
     float* const tile = sh_tile + w * (64 * PF_ROW);
+    V3 col_part = {0.f, 0.f, 0.f};
+    ShDir sdir = {0.f, 0.f, 0.f};
     if constexpr (M3C != 0) {
+        static_assert(M3C == 48, "two halves of eight coefficients");
         const unsigned long long amask = __ballot(alive);
         const int wave_first = blockIdx.x * 256 + 64 * w;        // the wave's first Gaussian
         if (amask != 0ull) {                                      // (wave-uniform; a wave with a survivor starts inside [0, P))
-            constexpr int NQ = M3C / 4;                           // 16-byte requests per lane
+            constexpr int NH = 6;                                 // 16-byte requests per lane and half: 64 rows x 24 floats
             const float4* src = reinterpret_cast<const float4*>(shs + (size_t)wave_first * M3C);
-            float4 q[NQ];
+            float4 q[2][NH];
 #pragma unroll
-            for (int k = 0; k < NQ; k++) {
-                const int f = lane + 64 * k;                      // request f covers floats [4 f, 4 f + 4) of row f / (M3C / 4)
-                const bool on = (amask >> (f / NQ)) & 1ull;
-                q[k] = src[on ? f : 0];
-            }
+            for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int k = 0; k < NQ; k++) {
-                const int f = lane + 64 * k;
-                if ((amask >> (f / NQ)) & 1ull) {
-                    float* d = tile + 4 * f + f / NQ;             // element e of row r at e + r  (row stride M3C + 1 = PF_ROW)
-                    d[0] = q[k].x; d[1] = q[k].y; d[2] = q[k].z; d[3] = q[k].w;
+                for (int k = 0; k < NH; k++) {
+                    const int f = lane + 64 * k;                  // request f of a half: floats [4 (f % 6), + 4) of that half of row f / 6
+                    const int r = f / NH, c4 = f % NH;
+                    const bool on = (amask >> r) & 1ull;
+                    q[h][k] = src[on ? r * (M3C / 4) + h * NH + c4 : 0];
+                }
+            if (alive) sdir = sh_dir(p, vp.campos);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int k = 0; k < NH; k++) {
+                    const int f = lane + 64 * k;
+                    const int r = f / NH, c4 = f % NH;
+                    if ((amask >> r) & 1ull) {
+                        float* d = tile + r * PF_ROW + 4 * c4;    // row stride 25: the per-lane rows are conflict-free
+                        d[0] = q[h][k].x; d[1] = q[h][k].y; d[2] = q[h][k].z; d[3] = q[h][k].w;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
+                __builtin_amdgcn_wave_barrier();
+                if (h == 0) {
+                    if (alive && !colors_precomp) col_part = sh_first(D, sdir, tile + lane * PF_ROW);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);           // every lane has read its row: the tile takes the second half
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wave's own LDS writes have landed
-            __builtin_amdgcn_wave_barrier();
         }
     }
 
@@ -342,7 +381,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         if (colors_precomp) {
             col = {colors_precomp[3 * (size_t)i], colors_precomp[3 * (size_t)i + 1], colors_precomp[3 * (size_t)i + 2]};
         } else if constexpr (M3C != 0) {
-            col = sh_to_rgb(D, p, vp.campos, tile + lane * PF_ROW, cl);
+            col = sh_second(D, sdir, col_part, tile + lane * PF_ROW, cl);
         } else {
             col = sh_to_rgb(D, p, vp.campos, shs + 3 * (size_t)M * i, cl);
         }
@@ -450,6 +489,26 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
         tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
         ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
         cdet_inv = __builtin_amdgcn_rcpf(q0.z * q1.x - q0.w * q0.w);
+    }
+    if (total <= (uint32_t)EMIT_CAP) {          // (wave-uniform) one window: the plain loops (c3: 0.044 ms; the state machine 0.046)
+        if (cnt != 0) {
+            for (int y = y0; y < y1; y++) {
+                int xa = x0, xb = x1 - 1;
+                if (cull && !row_span(ck, cdet_inv, y, x0, x1, xa, xb)) continue;
+                for (int x = xa; x <= xb; x++) {
+                    s_tile[w][off - base] = (uint32_t)(y * gx + x);
+                    s_id[w][off - base] = g;
+                    off++;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes have landed
+        for (uint32_t k = lane; k < total; k += 64) {
+            inst_tile[base + k] = s_tile[w][k];
+            inst_id[base + k] = s_id[w][k];
+        }
+        return;
     }
     int y = y0 - 1, x = 0, xb = -1;          // "row exhausted": the first step advances to row y0
     for (uint32_t wbase = base; wbase < base + total; wbase += (uint32_t)EMIT_CAP) {
