@@ -392,6 +392,36 @@ def test_forward_backward_vs_reference(case, record_property):
     print(case["id"], st)
 
 
+def test_non_finite_positions_vanish_as_in_the_reference():
+    """NaN / +inf / -inf coordinates on 2 % of the Gaussians (tests/util.py: harsh_scene "nonfinite_means"): on both
+    implementations they project to NaN pixel coordinates and an empty tile rectangle - radii, tiles and num_rendered EXACTLY
+    as the strict reference build's, images finite everywhere and within the strict bars, every gradient of every OTHER
+    Gaussian within the bound, and the gradients of the non-finite Gaussians themselves zero on both sides."""
+    from util import harsh_scene
+    scene = precompute_optionals(harsh_scene("nonfinite_means", P=20000, C=16, width=320, height=200, seed=33))
+    bad = ~torch.isfinite(scene["means3D"]).all(dim=1)
+    assert 300 < int(bad.sum()) < 500
+    C = scene["C"]
+    prod, ref = _Side("prod", scene, C, False, False), _Side("ref", scene, C, False, False, strict=True)
+    assert torch.equal(prod.f[4], ref.f[4]) and int(prod.f[0]) == int(ref.f[0])
+    assert int((prod.f[4][bad.to(DEV)] != 0).sum()) == 0
+    for i in (1, 2, 3):
+        assert bool(torch.isfinite(prod.f[i]).all()) and bool(torch.isfinite(ref.f[i]).all())
+    st, flips, over = _forward_stats(ref, prod, True)
+    assert st["flip_pixels"] <= flip_budget_for(320 * 200) and st["over_bar_pixels"] <= flip_budget_for(320 * 200), st
+    keep = torch.from_numpy((~over).reshape(1, 200, 320)).to(DEV)
+    g_ref, g_prod = ref.backward(keep), prod.backward(keep)
+    good = (~bad).to(DEV)
+    for k in sorted(_grad_names(False, False, True)):
+        a, b = g_ref[k], g_prod[k]
+        assert a.shape == b.shape
+        assert bool(torch.isfinite(b[good]).all()), k
+        mx, worst = ru.grad_errors(b[good], a[good])
+        assert mx <= 1e-3 and worst <= 1.0, (k, mx, worst)
+        # the non-finite Gaussians were culled: whatever the reference leaves in their rows (zeros), the product leaves too
+        assert bool((b[~good] == 0).all()) or bool(torch.equal(torch.nan_to_num(b[~good]), torch.nan_to_num(a[~good]))), k
+
+
 @pytest.mark.parametrize("seed,P,W,H,C", [(1, 5000, 256, 256, 16), (2, 20000, 320, 200, 32), (3, 3000, 97, 61, 128),
                                           (4, 1200, 128, 96, 16), (5, 10000, 256, 256, 3)])     # (4), (5): both sorts in one launch each
 def test_instance_lists_match_reference_bit_for_bit(seed, P, W, H, C, option):

@@ -145,6 +145,17 @@ def harsh_scene(kind: str, P: int, C: int, width: int, height: int, seed: int, w
         q = sc["rotations"].clone()
         q[(r >= 0.25) & (r < 0.27)] = 0.0
         sc["rotations"] = q.contiguous()
+    elif kind == "nonfinite_means":
+        # 2 % of the Gaussians with a NaN / +inf / -inf coordinate: projected to NaN pixel coordinates, their tile rectangle
+        # is empty on either implementation (forward.cu:232-238: the int conversions of NaN give an empty rectangle) - they
+        # must vanish without a trace: no hang, no NaN anywhere in the images or in any other Gaussian's gradient
+        r = torch.rand(P, generator=g)
+        m = sc["means3D"].clone()
+        axis = torch.randint(0, 3, (P,), generator=g)
+        for lo_, hi_, val in ((0.0, 0.007, float("nan")), (0.007, 0.014, float("inf")), (0.014, 0.02, float("-inf"))):
+            sel = (r >= lo_) & (r < hi_)
+            m[sel, axis[sel]] = val
+        sc["means3D"] = m.contiguous()
     else:
         raise ValueError(kind)
     return sc
