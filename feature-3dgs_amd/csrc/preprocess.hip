@@ -440,6 +440,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
 // contiguous stores (a lane storing straight to its own run writes one dword to 64 different places per instruction:
 // 0.061 ms for 42 MB at c3).  Ranges longer than the LDS slice are staged window by window (round 5).
 constexpr int EMIT_CAP = 1024;      // list entries per wave in LDS (8 KB)
+constexpr int EMIT_BIG = 512;       // tiles from which on a splat is emitted by the whole wave
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_sums,
                       const uint32_t* __restrict__ sub, const uint32_t* __restrict__ tiles_touched,
@@ -472,6 +473,71 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
     const uint32_t inc = wave_incl_scan(cnt, lane);
     const uint32_t off0 = base + inc - cnt;
     const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+    // A splat of more than EMIT_BIG tiles (a Gaussian close to the camera plane of a rotated view: thousands of tiles, up to the
+    // whole grid) would keep ONE lane looping for all of them while 63 idle.  A wave that holds such splats (wave-uniform
+    // ballot; rare) emits them cooperatively, one at a time: lane = tile row for the spans (one closed-form span per row, a
+    // wave scan over the row counts), then row by row lane = tile column, consecutive lanes storing consecutive entries - same
+    // order as the per-lane walk (rows ascending, columns ascending): the lists are bit-identical.  The wave's other lanes
+    // store straight from their loops.  (c3 as eight rotated views: emit 0.27 ms per view with the per-lane walk alone.)
+    const unsigned long long bigm = __ballot(cnt > (uint32_t)EMIT_BIG);
+    if (bigm != 0ull) {
+        unsigned long long m = bigm;
+        while (m != 0ull) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)g, b);
+            uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off0, b);
+            const float4 b0 = rec[gb].q0, b1 = rec[gb].q1;            // (one request: every lane asks for the same record)
+            const int bradius = __float_as_int(rec[gb].q2.z);
+            int bx0, by0, bx1, by1;
+            tile_rect(b0.x, b0.y, bradius, gx, gy, bx0, by0, bx1, by1);
+            const CullParams bk = make_cull(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
+            const float bdet_inv = __builtin_amdgcn_rcpf(b0.z * b1.x - b0.w * b0.w);
+            for (int yb = by0; yb < by1; yb += 64) {
+                const int yl = yb + lane;
+                int xa = bx0, n = 0;
+                if (yl < by1) {
+                    int xb_ = bx1 - 1;
+                    if (!cull || row_span(bk, bdet_inv, yl, bx0, bx1, xa, xb_)) n = xb_ - xa + 1;
+                }
+                const uint32_t inc_r = wave_incl_scan((uint32_t)n, lane);
+                const uint32_t roff = inc_r - (uint32_t)n;
+                const uint32_t btot = (uint32_t)__shfl((int)inc_r, 63, 64);
+                const int rows = min(64, by1 - yb);
+                for (int r = 0; r < rows; r++) {
+                    const int nr = __builtin_amdgcn_readlane(n, r);
+                    if (nr == 0) continue;
+                    const int xar = __builtin_amdgcn_readlane(xa, r);
+                    const uint32_t ro = o + (uint32_t)__builtin_amdgcn_readlane((int)roff, r);
+                    const uint32_t t0 = (uint32_t)((yb + r) * gx + xar);
+                    for (int k = lane; k < nr; k += 64) {
+                        inst_tile[ro + k] = t0 + (uint32_t)k;
+                        inst_id[ro + k] = gb;
+                    }
+                }
+                o += btot;
+            }
+        }
+        if (cnt != 0 && cnt <= (uint32_t)EMIT_BIG) {
+            uint32_t off_d = off0;
+            const float4 d0 = rec[g].q0, d1 = rec[g].q1;
+            const int dradius = __float_as_int(rec[g].q2.z);
+            int dx0, dy0, dx1, dy1;
+            tile_rect(d0.x, d0.y, dradius, gx, gy, dx0, dy0, dx1, dy1);
+            const CullParams dk = make_cull(d0.x, d0.y, d0.z, d0.w, d1.x, d1.y);
+            const float ddet_inv = __builtin_amdgcn_rcpf(d0.z * d1.x - d0.w * d0.w);
+            for (int y = dy0; y < dy1; y++) {
+                int xa = dx0, xb = dx1 - 1;
+                if (cull && !row_span(dk, ddet_inv, y, dx0, dx1, xa, xb)) continue;
+                for (int x = xa; x <= xb; x++) {
+                    inst_tile[off_d] = (uint32_t)(y * gx + x);
+                    inst_id[off_d] = g;
+                    off_d++;
+                }
+            }
+        }
+        return;
+    }
     // Every wave stages its range of the list in LDS in windows of EMIT_CAP entries and stores each window contiguously
     // (coalesced 256-byte requests).  A lane walks its splat's rows and columns as a resumable state machine - (y, x, xb) survive
     // from window to window - so ranges of any length are staged: until round 5 a range above one window (c5: 33 tiles per

@@ -429,6 +429,21 @@ def test_instance_lists_match_reference_bit_for_bit(seed, P, W, H, C, option):
     reference's (`rasterizer_impl.cu:291-327`: hipCUB radix sort on (tile | depth) keys), bit for bit."""
     option("tile_cull", 0)
     scene = _scene(P=P, C=C, width=W, height=H, seed=seed, scale_lo=0.005, scale_hi=0.08)
+    _lists_match(scene, P, W, H, C)
+
+
+@pytest.mark.parametrize("kind,P,W,H", [("heavy_tail", 4000, 640, 360), ("heavy_tail_round", 6000, 1296, 720)])
+def test_instance_lists_with_huge_splats_match_reference_bit_for_bit(kind, P, W, H, option):
+    """The same with splats of hundreds to thousands of tiles (up to the whole grid: 920 / 3645 tiles): the emit kernel hands
+    every splat above 512 tiles to the whole wave (lane = tile row for the spans, then lane = tile column) and stages the long
+    ranges of the other waves through LDS window by window - the lists stay the reference's, bit for bit."""
+    from util import harsh_scene
+    option("tile_cull", 0)
+    scene = harsh_scene(kind, P=P, C=16, width=W, height=H, seed=41)
+    _lists_match(scene, P, W, H, 16, min_big=8)
+
+
+def _lists_match(scene, P, W, H, C, min_big=0):
     ref, prod = ru.load_ref(C), ru.product_module()
     d = ru.device_inputs(scene, C, DEV)
     f_ref, f_prod = ru.raw_forward(ref, scene, d), ru.raw_forward(prod, scene, d)
@@ -436,8 +451,11 @@ def test_instance_lists_match_reference_bit_for_bit(seed, P, W, H, C, option):
     assert int(f_prod[0]) == n
     assert torch.equal(f_ref[4], f_prod[4])
     geo = ru.ref_geometry_state(f_ref, P, C)
-    assert np.array_equal(ru.product_read("tiles_touched", scene, f_prod, np.uint32, P), geo["tiles_touched"])
     vis = f_ref[4].cpu().numpy() > 0
+    tt = ru.product_read("tiles_touched", scene, f_prod, np.uint32, P)
+    # (the reference leaves tiles_touched of culled Gaussians unwritten)
+    assert np.array_equal(tt[vis], geo["tiles_touched"][vis]) if min_big else np.array_equal(tt, geo["tiles_touched"])
+    assert int((tt[vis] > 512).sum()) >= min_big, "the scene holds no splat large enough for the cooperative emission"
     depth_equal = np.array_equal(ru.product_read("rec", scene, f_prod, np.float32, P * 12).reshape(P, 12)[:, 9][vis],
                                  geo["depths"][vis])
     pl_ref = ru.ref_point_list(f_ref)
