@@ -617,273 +617,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
     render_forward_mfma_body<CH, 1, 32, 2, BASE>(a);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// 129 .. 256 channels in ONE walk of the list (option fwd_wide = 2).  The list walk and the alpha evaluation are 64 - 73 % of
-// the blend forward at every width (profiles/r05_notes.md, work-skipping build) and a wide feature paid them once per
-// 128-channel window.  256 accumulator registers in one wave would leave one wave per SIMD (measured: slower) - so a quadrant
-// is taken by a PAIR of waves, one 128-thread workgroup: wave 0 walks the list exactly as the single-window kernel does (wave-level
-// culling, compaction, alpha evaluation, colour / depth, its own 128 channels on the matrix pipe) and leaves, per chunk of 16
-// list entries, the compacted entries and the matrix instructions' A operands - the blend weights of every entry pair at the
-// 64 pixels, already lane-swapped - in LDS; wave 1 follows one chunk behind, gathers the feature rows of ITS 128 channels for
-// the same entries and contracts them against those operands: no list walk, no alpha evaluation.  One workgroup barrier per
-// chunk, buffers in two parities.  Every channel sees the same multiply-adds in the same order as in the single-window kernel:
-// bit-identical images.
-constexpr int DU_CHK = 16;          // list entries per chunk
-constexpr int DU_CH = 128;          // channels per wave
-struct DualShared {
-    FwdEntry ent[2][DU_CHK];                  // compacted hits of the chunk (parity)
-    float wx[2][DU_CHK / 2][64];              // per entry pair: A operand of pixels 0-31 (lanes 0-31: entry j, lanes 32-63: entry j + 1)
-    float wy[2][DU_CHK / 2][64];              //                 A operand of pixels 32-63
-    float feat[2][(32 * 65 > DU_CHK * DU_CH) ? 32 * 65 : DU_CHK * DU_CH];      // per wave: feature rows; reused as the epilogue transpose tile
-    int cnt[2];
-    uint32_t pair_mask[2];                    // bit k: some lane blends in pair k
-    int last[2];                              // no chunk follows this one
-};
-
-template <bool BASE>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) render_forward_dual_kernel(FwdArgs a) {
-    constexpr int NB = DU_CH / 32;
-    constexpr int CHV = DU_CH / 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    DualShared& L = *reinterpret_cast<DualShared*>(smem);
-    const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // 0: walks the list; 1: follows
-    const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);      // four consecutive virtual ids = the quadrants of one tile
-    const int quad = (int)(vb & 3u);
-    const uint32_t tile = vb >> 2;
-    const int tx = tile % a.gx, ty = tile / a.gx;
-    uint2 rg;
-    if (a.write_base) {
-        const uint2 e = a.ranges_enc[tile];
-        rg = e.x == 0xFFFFFFFFu ? make_uint2(0u, 0u) : make_uint2(e.x, 0xFFFFFFFFu - e.y);
-        if (threadIdx.x == 0) a.ranges[tile] = rg;
-    } else {
-        rg = a.ranges[tile];
-    }
-    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x), r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
-    const int iwx0 = tx * TILE + (quad & 1) * 8, iwx1 = iwx0 + 7, iwy0 = ty * TILE + (quad >> 1) * 8, iwy1 = iwy0 + 7;
-    const int x = iwx0 + (lane & 7), y = iwy0 + (lane >> 3);
-    const float pxf = (float)x, pyf = (float)y;
-    const bool inside = x < a.W && y < a.H;
-    const int pix_id = y * a.W + x;
-    const int cw0 = a.c0 + role * DU_CH;                       // this wave's first channel
-    const int ncw = min(DU_CH, a.nc - role * DU_CH);           // ... and how many it has (wave 0: 128)
-    const int nbu = (ncw + 31) / 32;                           // 32-channel blocks in use
-    float* const myfeat = L.feat[role];
-    const bool vec_ok = (a.C & 3) == 0 && (cw0 & 3) == 0;
-    f32x16 acc[2][NB];
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[h][nb][r] = 0.f;
-
-    // feature rows of the `cnt` compacted entries of parity p -> this wave's LDS image (row-major [entry][128])
-    auto stage_features = [&](int p, int cnt) {
-        if (vec_ok && ncw == DU_CH) {
-            using lds_ptr = __attribute__((address_space(3))) void*;
-            using gbl_ptr = const __attribute__((address_space(1))) void*;
-#pragma unroll
-            for (int it = 0; it < DU_CHK * CHV / 64; it++) {
-                const int e = it * 64 + lane;
-                if (e < cnt * CHV) {
-                    const uint32_t g = L.ent[p][e / CHV].id;
-                    const float* src = a.feat + (size_t)g * a.C + cw0 + 4 * (e % CHV);
-                    __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)&myfeat[it * 256], 16, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            for (int e = lane; e < cnt * CHV; e += 64) {
-                const int inst = e / CHV, v = e % CHV;
-                const uint32_t g = L.ent[p][inst].id;
-                const float* src = a.feat + (size_t)g * a.C + cw0 + 4 * v;
-                float4 f;
-                if (vec_ok && 4 * v + 3 < ncw) {
-                    f = *reinterpret_cast<const float4*>(src);
-                } else {
-                    f.x = 4 * v + 0 < ncw ? src[0] : 0.f;
-                    f.y = 4 * v + 1 < ncw ? src[1] : 0.f;
-                    f.z = 4 * v + 2 < ncw ? src[2] : 0.f;
-                    f.w = 4 * v + 3 < ncw ? src[3] : 0.f;
-                }
-                *reinterpret_cast<float4*>(&myfeat[inst * DU_CH + 4 * v]) = f;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    // the pair's two matrix-instruction rounds on this wave's channel blocks
-    auto contract = [&](int j, int cnt, float X, float Y) {
-        const int rsel = (lane >> 5) ? (j + 1 < cnt ? j + 1 : j) : j;
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            if (nb < nbu) {
-                const float Bv = myfeat[rsel * DU_CH + (lane & 31) + 32 * nb];
-                acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv, acc[0][nb], 0, 0, 0);
-                acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv, acc[1][nb], 0, 0, 0);
-            }
-        }
-    };
-
-    float T = inside ? 1.0f : -1.0f, col0 = 0.f, col1 = 0.f, col2 = 0.f, dep = 0.f;
-    uint32_t last = 0;
-    if (role == 0) {
-        uint32_t n_id = 0, f_id = 0;
-        float4 n_q0 = make_float4(0, 0, 0, 0), n_q1 = n_q0;
-        float2 n_q2 = make_float2(0, 0);
-        if (lane < DU_CHK && r_lo + lane < r_hi) n_id = a.point_list[r_lo + lane];
-        if (lane < DU_CHK && r_lo + DU_CHK + lane < r_hi) f_id = a.point_list[r_lo + DU_CHK + lane];
-        if (lane < DU_CHK && r_lo + lane < r_hi) {
-            const SplatRec* rp = a.rec + n_id;
-            n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = *reinterpret_cast<const float2*>(&rp->q2);
-        }
-        int it = 0;
-        for (uint32_t base = r_lo;; base += DU_CHK, it++) {
-            const int p = it & 1;
-            const int cnt_in = base < r_hi ? (int)min((uint32_t)DU_CHK, r_hi - base) : 0;
-            const bool hit = lane < cnt_in && rect_hit(n_q0.x, n_q0.y, n_q0.z, n_q0.w, n_q1.x, n_q1.y, (float)sgpr_opaque(iwx0),
-                                                       (float)sgpr_opaque(iwx1), (float)sgpr_opaque(iwy0), (float)sgpr_opaque(iwy1));
-            const unsigned long long hmask = __ballot(hit);
-            const int cnt = __popcll(hmask);
-            const int slot = __popcll(hmask & ((1ull << lane) - 1ull));
-            if (hit) {
-                FwdEntry en;
-                en.geo = make_float4(n_q0.x, n_q0.y, n_q0.z * CONIC_SCALE_AC, n_q0.w * CONIC_SCALE_B);
-                en.cd = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
-                en.co_c = n_q1.x * CONIC_SCALE_AC; en.co_o = n_q1.y;
-                en.pos = base - r_lo + lane + 1;
-                en.id = n_id;
-                L.ent[p][slot] = en;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            n_id = f_id;
-            if (lane < DU_CHK && base + DU_CHK + lane < r_hi) {
-                const SplatRec* rp = a.rec + n_id;
-                n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = *reinterpret_cast<const float2*>(&rp->q2);
-            }
-            if (lane < DU_CHK && base + 2 * DU_CHK + lane < r_hi) f_id = a.point_list[base + 2 * DU_CHK + lane];
-            if (cnt > 0) stage_features(p, cnt);
-            uint32_t pm = 0;
-            for (int j = 0; j < cnt; j += 2) {
-                float4 g0[2], cdv[2];
-                float2 g1[2];
-                uint32_t pos_e[2];
-                bool live_e[2];
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    live_e[e] = j + e < cnt;
-                    const int je = live_e[e] ? j + e : j;
-                    g0[e] = L.ent[p][je].geo;
-                    if constexpr (BASE) cdv[e] = L.ent[p][je].cd;
-                    const float4 tail = *reinterpret_cast<const float4*>(&L.ent[p][je].co_c);
-                    g1[e] = make_float2(tail.x, tail.y);
-                    pos_e[e] = __float_as_uint(tail.z);
-                }
-                float w[2] = {0.f, 0.f};
-                bool any_blend = false;
-                if (__any(T > 0.0f)) {
-                    float araw[2];
-                    bool valid[2];
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const float dx = g0[e].x - pxf, dy = g0[e].y - pyf;
-                        const float power = splat_power2(dx, dy, g0[e].z, g0[e].w, g1[e].x);
-                        araw[e] = fminf(ALPHA_MAX, g1[e].y * __builtin_amdgcn_exp2f(power));
-                        valid[e] = live_e[e] && !(power > 0.0f) && !(araw[e] < ALPHA_MIN);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const float test_T = T * (1.0f - araw[e]);          // negative once the pixel is finished
-                        const bool below = test_T < T_MIN;
-                        const bool ok = valid[e] & !below;
-                        const bool term = valid[e] & below;
-                        const float wv = ok ? araw[e] * T : 0.0f;
-                        w[e] = wv;
-                        T = ok ? test_T : (term ? -fabsf(T) : T);
-                        if constexpr (BASE) {
-                            last = ok ? pos_e[e] : last;
-                            col0 = fmaf(cdv[e].x, wv, col0);
-                            col1 = fmaf(cdv[e].y, wv, col1);
-                            col2 = fmaf(cdv[e].z, wv, col2);
-                            dep = fmaf(cdv[e].w, wv, dep);
-                        }
-                        any_blend = any_blend || ok;
-                    }
-                }
-                if (__any(any_blend)) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[0]), __float_as_int(w[1]), false, false);
-                    const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
-                    L.wx[p][j >> 1][lane] = X;
-                    L.wy[p][j >> 1][lane] = Y;
-                    pm |= 1u << (j >> 1);
-                    contract(j, cnt, X, Y);
-                }
-            }
-            const bool more = base + DU_CHK < r_hi && __any(T > 0.0f);
-            if (lane == 0) { L.cnt[p] = cnt; L.pair_mask[p] = pm; L.last[p] = more ? 0 : 1; }
-            __syncthreads();                  // chunk `it` is published; wave 1 has finished chunk `it - 1`
-            if (!more) break;
-        }
-        __syncthreads();                      // wave 1 works off the last chunk
-    } else {
-        __syncthreads();
-        for (int it = 0;; it++) {
-            const int p = it & 1;
-            const int cnt = __builtin_amdgcn_readfirstlane(L.cnt[p]);
-            const uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.pair_mask[p]);
-            const int lastf = __builtin_amdgcn_readfirstlane(L.last[p]);
-            if (pm != 0u && ncw > 0) {
-                stage_features(p, cnt);
-                for (int j = 0; j < cnt; j += 2) {
-                    if ((pm >> (j >> 1)) & 1u) contract(j, cnt, L.wx[p][j >> 1][lane], L.wy[p][j >> 1][lane]);
-                }
-            }
-            __syncthreads();
-            if (lastf) break;
-        }
-    }
-
-    const size_t HW = (size_t)a.W * a.H;
-    if (BASE && role == 0 && a.write_base) {
-        const uint32_t m = wave_max_u32(last);
-        if (lane == 0 && m) atomicMax(&a.tile_len[tile], m);
-        if (inside) {
-            const size_t pid = (size_t)pix_id;
-            const float Tf = fabsf(T);
-            a.final_T[pid] = Tf;
-            a.n_contrib[pid] = last;
-            a.out_color[pid] = col0 + Tf * a.bg[0];
-            a.out_color[HW + pid] = col1 + Tf * a.bg[1];
-            a.out_color[2 * HW + pid] = col2 + Tf * a.bg[2];
-            a.out_depth[pid] = dep;
-        }
-    }
-    // D[i][n]: lane holds column n = lane & 31 (channel), register r holds row i = (r&3) + 8(r>>2) + 4(lane>>5): transpose through
-    // the wave's own LDS region so that lanes are pixels again
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-        if (nb >= nbu) break;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int i = 32 * h + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                myfeat[(lane & 31) * 65 + i] = acc[h][nb][r];
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        if (inside) {
-#pragma unroll 8
-            for (int n = 0; n < 32; n++)
-                if (32 * nb + n < ncw) a.out_feat[(size_t)(cw0 + 32 * nb + n) * HW + (size_t)pix_id] = myfeat[n * 65 + lane];
-        }
-    }
-}
-
 // The 128-channel shape needs 70 KB of LDS per four-wave workgroup (above the 64 KB default limit): the limit is raised once
 // per device; where that is refused the caller falls back to 64-channel windows.
 template <bool BASE>
@@ -953,16 +686,7 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     // blend weights of the whole list: fewer, wider windows - two waves per SIMD, the matrix pipe hides the rest)
     const bool wide_ok = mf && options().fwd_wide != 0 && C > 64 && wide_shape_usable<true>() && wide_shape_usable<false>();
     const int wide = wide_ok ? 128 : 64;
-    const bool dual_ok = wide_ok && options().fwd_wide >= 2;     // 129 .. 256 channels in one walk by wave pairs
     for (int c0 = 0; c0 < C;) {
-        if (dual_ok && C - c0 > 128) {
-            a.c0 = c0; a.nc = min(256, C - c0); a.write_base = (c0 == 0);
-            c0 += 256;
-            const dim3 grid(4 * a.gx * a.gy), block(128);
-            if (a.write_base) hipLaunchKernelGGL(render_forward_dual_kernel<true>, grid, block, sizeof(DualShared), s, a);
-            else hipLaunchKernelGGL(render_forward_dual_kernel<false>, grid, block, sizeof(DualShared), s, a);
-            continue;
-        }
         const int win = (C - c0 > 64) ? wide : 64;
         a.c0 = c0; a.nc = min(win, C - c0); a.write_base = (c0 == 0);
         c0 += win;
