@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: collect everything that goes under profiles/ for one round (run through gpurun; output in gpurun_out/<tag>).
-#   tools/round_profiles.sh r04 [quick]
-TAG=${1:-r04}
+#   tools/round_profiles.sh r05 [quick]
+TAG=${1:-r05}
 QUICK=${2:-}
 export TMPDIR=/tmp
 ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
