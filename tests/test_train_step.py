@@ -161,3 +161,53 @@ def test_two_ranks_reduce_gradients_and_statistics(tmp_path):
         assert np.allclose(got[r]["acc"], model.xyz_gradient_accum.numpy(), rtol=1e-5)
         assert np.array_equal(got[r]["den"], model.denom.numpy()) and np.array_equal(got[r]["rad"], model.max_radii2D.numpy())
     assert got[0]["den"].max() == 2.0          # a Gaussian visible in both views counts twice
+
+
+def _sharded_loop_worker(rank, world, port, out_dir):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "feature-3dgs_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dp
+    import train_step
+    lrs = dict(_xyz=1e-3, _features_dc=2e-3, _features_rest=1e-4, _opacity=5e-2, _scaling=5e-3, _rotation=1e-3, _semantic_feature=1e-3)
+
+    def make_opt(t):
+        return torch.optim.Adam([{"params": [t[n]], "lr": lrs[n], "name": n} for n in NAMES], lr=0.0, eps=1e-15)
+    sc = _scene(P=41, C=3, W=32, H=32)                   # 41 rows on two ranks: a ragged sharding
+    cam = types.SimpleNamespace(k=float(rank + 2))
+    # (A) the reference's arrangement made data-parallel: all-reduce of the gradients, the full optimizer on every rank
+    ma = StubModel(sc, "cpu")
+    oa = make_opt({n: getattr(ma, n) for n in NAMES})
+    # (B) local gradients + sharded optimizer
+    mb = StubModel(sc, "cpu")
+    sh = dp.ShardedOptimizer({n: getattr(mb, n) for n in NAMES}, make_opt)
+    for _ in range(3):
+        train_step.dp_train_step(_fake_render, _fake_loss, ma, [cam], None, None, overlap=False)
+        oa.step()
+        res = train_step.dp_train_step(_fake_render, _fake_loss, mb, [cam], None, None, overlap=False, reduce=False)
+        sh.step(res.grads)
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), acc_a=ma.xyz_gradient_accum.numpy(), acc_b=mb.xyz_gradient_accum.numpy(),
+             **{"a" + n: getattr(ma, n).detach().numpy() for n in NAMES}, **{"b" + n: getattr(mb, n).detach().numpy() for n in NAMES})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_loop_with_the_sharded_optimizer_equals_the_all_reduce_loop(tmp_path):
+    """Three iterations of the loop body on two ranks (gloo), one view each: `dp_train_step` + the full Adam on every rank
+    against `dp_train_step(reduce=False)` + `dp.ShardedOptimizer` (reduce-scatter, Adam on this rank's rows, all-gather of the
+    parameters).  The parameters agree BIT FOR BIT on both ranks after every parameter has been updated three times, and the
+    densification statistics - reduced in both arrangements - are the same."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_loop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = (np.load(os.path.join(tmp_path, f"s{r}.npz")) for r in range(2))
+    for n in NAMES:
+        assert np.array_equal(g0["a" + n], g0["b" + n]), n
+        assert np.array_equal(g1["a" + n], g1["b" + n]), n
+        assert np.array_equal(g0["b" + n], g1["b" + n]), n
+    assert np.array_equal(g0["acc_a"], g0["acc_b"]) and np.array_equal(g0["acc_b"], g1["acc_b"])
