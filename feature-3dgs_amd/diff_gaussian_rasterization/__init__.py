@@ -57,7 +57,6 @@ def set_grad_rows_hook(on_rows, chunks: int = 4, on_done=None) -> None:
 
 
 _accum_leaf = None       # (data_ptr, numel) of the leaf whose .grad the accumulator is, or None: not checked
-_user_accumulator = False
 
 
 def set_feature_grad_accumulator(buffer: Optional[torch.Tensor], leaf: Optional[torch.Tensor] = None) -> None:
@@ -70,9 +69,8 @@ def set_feature_grad_accumulator(buffer: Optional[torch.Tensor], leaf: Optional[
     `semantic_feature` input IS the tensor `buffer` is the gradient of.  Pass that tensor as `leaf` and every backward call
     checks it (same storage, and an autograd leaf at forward time); a transformed, masked or copied feature tensor then
     raises instead of silently receiving nothing."""
-    global _accum_leaf, _user_accumulator
+    global _accum_leaf
     _accum_leaf = None if (buffer is None or leaf is None) else (leaf.data_ptr(), leaf.numel())
-    _user_accumulator = buffer is not None
     _C.set_feature_grad_accumulator(buffer)
 
 
