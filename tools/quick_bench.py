@@ -18,7 +18,7 @@ settings = sys.argv[3:] or [""]
 kw = dict(CONFIGS[cfg.split("@")[0]])
 if "@" in cfg:          # "c2@8": config c2 with 8 feature channels
     kw["C"] = int(cfg.split("@")[1])
-sc = make_scene(seed=0, **kw)
+sc = make_scene(seed=0, yaw_deg=float(os.environ.get("F3DGS_BENCH_YAW", "0")), **kw)      # (a rotated view: F3DGS_BENCH_YAW=35)
 dev = "cuda:0"
 t = lambda x: x.to(dev)
 st = dgr.GaussianRasterizationSettings(sc["image_height"], sc["image_width"], sc["tanfovx"], sc["tanfovy"], t(sc["bg"]), 1.0,
