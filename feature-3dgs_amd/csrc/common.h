@@ -51,6 +51,7 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 8;                                   // fewest keys per thread of any pass (sizes the histograms)
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;           // items per workgroup
 constexpr int SCAN_CHUNK = 256 * 16;
+constexpr int BIGQ_CAP = 1024;                                  // slots of the big-splat queue of the emit kernel (4 x 256: zeroed by four workgroups)
 constexpr int DEPTH_SORT_ITEMS = 8;                             // onesweep depth passes: 2048 keys per workgroup
 
 inline size_t sort_blocks(size_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
@@ -75,6 +76,10 @@ struct GeomState {
     // -- control words of the single-pass sorts (lookback.h).  depth_hist is zeroed by preprocess_kernel (it is
     //    accumulated by the kernel after it); everything from lb_words on is zeroed by sort_prologue_kernel.
     uint32_t* depth_hist;     // 4 x 256 digit totals of the depth keys
+    // -- queue of the splats of more than EMIT_BIG tiles (emit kernel, work stealing): big_ctl[0] slots handed out, [1] the
+    //    stealers' cursor, [4 + i] state of slot i (0 empty, 1 published, 2 claimed); zeroed by preprocess_kernel
+    uint32_t* big_ctl;        // 4 + BIGQ_CAP
+    uint2* big_items;         // BIGQ_CAP x {Gaussian, first list position}
     uint32_t* lb_words;       // start of the zero-filled region, n_lb_words long:
     size_t n_lb_words;
     uint32_t* tickets;        //   8  arrival counters: [0..3] depth passes, [4] emit, [5..6] tile passes, [7] emit "done"
@@ -99,6 +104,8 @@ struct GeomState {
         g.ref_partial = c.take<uint32_t>(2 * ((P + 255) / 256) + 2);
         g.counters = c.take<uint32_t>(16);
         g.depth_hist = c.take<uint32_t>(4 * 256);
+        g.big_ctl = c.take<uint32_t>(4 + BIGQ_CAP);
+        g.big_items = c.take<uint2>(BIGQ_CAP);
         g.n_lb_words = 8 + 2 * 256 + 4 * depth_sort_blocks(P) * 256 + emit_blocks(P) + 64 * 512;
         g.lb_words = c.take<uint32_t>(g.n_lb_words);
         g.tickets = g.lb_words;

@@ -272,12 +272,16 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   const float* __restrict__ colors_precomp, ViewParams vp, int* __restrict__ radii,
                   SplatRec* __restrict__ rec, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
                   uint32_t* __restrict__ depth_key, int cull, uint32_t* __restrict__ ref_partial,
-                  uint32_t* __restrict__ depth_hist) {
+                  uint32_t* __restrict__ depth_hist, uint32_t* __restrict__ big_ctl) {
     extern __shared__ __attribute__((aligned(16))) float sh_tile[];      // M3C: four wave-private tiles of 64 x PF_ROW floats
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // the digit histograms of the depth sort are accumulated by the NEXT kernel: zero them here (1024 words)
-    if (blockIdx.x < 4) depth_hist[blockIdx.x * 256 + threadIdx.x] = 0;
+    if (blockIdx.x < 4) {
+        depth_hist[blockIdx.x * 256 + threadIdx.x] = 0;
+        big_ctl[4 + blockIdx.x * 256 + threadIdx.x] = 0;         // the emit kernel's big-splat queue: slot states ...
+        if (blockIdx.x == 0 && threadIdx.x < 4) big_ctl[threadIdx.x] = 0;      // ... and counters
+    }
     int out_radius = 0;
     uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu, bbox_tiles = 0;
     // ---- part 1: projection and culling.  Every input of the Gaussian is requested first (index clamped: no branch in
@@ -439,13 +443,79 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
 // an exclusive scan in this very order), so the wave first lays them out in LDS and then copies the whole range out with
 // contiguous stores (a lane storing straight to its own run writes one dword to 64 different places per instruction:
 // 0.061 ms for 42 MB at c3).  Ranges longer than the LDS slice are staged window by window (round 5).
+// One splat of many tiles emitted by a whole wave: lane = tile row for the closed-form spans (a wave scan over the row counts),
+// then row by row lane = tile column, consecutive lanes storing consecutive entries - the order of the per-lane walk (rows
+// ascending, columns ascending).  `o`: the splat's first position in the list.
+__device__ __forceinline__ void emit_big_splat(uint32_t gb, uint32_t o, const SplatRec* __restrict__ rec, int gx, int gy, int cull,
+                                               uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_id, int lane) {
+    const float4 b0 = rec[gb].q0, b1 = rec[gb].q1;            // (one request: every lane asks for the same record)
+    const int bradius = __float_as_int(rec[gb].q2.z);
+    int bx0, by0, bx1, by1;
+    tile_rect(b0.x, b0.y, bradius, gx, gy, bx0, by0, bx1, by1);
+    const CullParams bk = make_cull(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
+    const float bdet_inv = __builtin_amdgcn_rcpf(b0.z * b1.x - b0.w * b0.w);
+    for (int yb = by0; yb < by1; yb += 64) {
+        const int yl = yb + lane;
+        int xa = bx0, n = 0;
+        if (yl < by1) {
+            int xb_ = bx1 - 1;
+            if (!cull || row_span(bk, bdet_inv, yl, bx0, bx1, xa, xb_)) n = xb_ - xa + 1;
+        }
+        const uint32_t inc_r = wave_incl_scan((uint32_t)n, lane);
+        const uint32_t roff = inc_r - (uint32_t)n;
+        const uint32_t btot = (uint32_t)__shfl((int)inc_r, 63, 64);
+        const int rows = min(64, by1 - yb);
+        for (int r = 0; r < rows; r++) {
+            const int nr = __builtin_amdgcn_readlane(n, r);
+            if (nr == 0) continue;
+            const int xar = __builtin_amdgcn_readlane(xa, r);
+            const uint32_t ro = o + (uint32_t)__builtin_amdgcn_readlane((int)roff, r);
+            const uint32_t t0 = (uint32_t)((yb + r) * gx + xar);
+            for (int k = lane; k < nr; k += 64) {
+                inst_tile[ro + k] = t0 + (uint32_t)k;
+                inst_id[ro + k] = gb;
+            }
+        }
+        o += btot;
+    }
+}
+
+// The big splats of a view are its NEAREST Gaussians - neighbours in depth order, i.e. lanes of the same one or two waves: emitted
+// by their own wave they run one after the other (33 splats of ~5000 tiles at c3 rotated by 25 degrees: 0.2 ms on one wave
+// while the chip idles).  So the owner PUBLISHES them - {Gaussian, first list position} in a slot of a small queue - before it
+// does anything else, and every wave of the launch, when its own range is written, takes what it finds published (one claim
+// per slot: 1 -> 2 by compare-and-swap); the owner takes whatever nobody claimed when it comes back.  No wave ever waits.
+__device__ __forceinline__ uint32_t big_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool emit_big_claim(uint32_t* big_ctl, uint32_t slot, int lane) {
+    uint32_t was = 0;
+    if (lane == 0) was = atomicCAS(&big_ctl[4 + slot], 1u, 2u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)was) == 1u;
+}
+__device__ __forceinline__ void emit_big_steal(uint32_t* big_ctl, const uint2* big_items, const SplatRec* __restrict__ rec, int gx, int gy,
+                                               int cull, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_id, int lane) {
+    for (;;) {
+        const uint32_t handed = min(big_load(&big_ctl[0]), (uint32_t)BIGQ_CAP);
+        if (big_load(&big_ctl[1]) >= handed) return;             // (plain loads first: an empty or drained queue costs no atomic)
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(&big_ctl[1], 1u);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        if (i >= handed) return;
+        if (emit_big_claim(big_ctl, i, lane)) {                  // (a slot handed out but not yet published is left to its owner)
+            __threadfence();
+            const uint32_t gb = big_load(&big_items[i].x), o = big_load(&big_items[i].y);
+            emit_big_splat(gb, o, rec, gx, gy, cull, inst_tile, inst_id, lane);
+        }
+    }
+}
+
 constexpr int EMIT_CAP = 1024;      // list entries per wave in LDS (8 KB)
 constexpr int EMIT_BIG = 512;       // tiles from which on a splat is emitted by the whole wave
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_sums,
                       const uint32_t* __restrict__ sub, const uint32_t* __restrict__ tiles_touched,
                       const SplatRec* __restrict__ rec, int gx, int gy, int cull, uint32_t* __restrict__ inst_tile,
-                      uint32_t* __restrict__ inst_id, uint2* __restrict__ ranges_enc, uint32_t* __restrict__ tile_len) {
+                      uint32_t* __restrict__ inst_id, uint2* __restrict__ ranges_enc, uint32_t* __restrict__ tile_len,
+                      uint32_t* __restrict__ big_ctl, uint2* __restrict__ big_items) {
     __shared__ uint32_t s_tile[4][EMIT_CAP];
     __shared__ uint32_t s_id[4][EMIT_CAP];
     // all-ones = "no entry yet" for both halves of the encoded tile ranges (BinState::ranges_enc; the final sort pass,
@@ -474,49 +544,29 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
     const uint32_t off0 = base + inc - cnt;
     const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
     // A splat of more than EMIT_BIG tiles (a Gaussian close to the camera plane of a rotated view: thousands of tiles, up to the
-    // whole grid) would keep ONE lane looping for all of them while 63 idle.  A wave that holds such splats (wave-uniform
-    // ballot; rare) emits them cooperatively, one at a time: lane = tile row for the spans (one closed-form span per row, a
-    // wave scan over the row counts), then row by row lane = tile column, consecutive lanes storing consecutive entries - same
-    // order as the per-lane walk (rows ascending, columns ascending): the lists are bit-identical.  The wave's other lanes
-    // store straight from their loops.  (c3 as eight rotated views: emit 0.27 ms per view with the per-lane walk alone.)
+    // whole grid) would keep ONE lane looping for all of them while 63 idle: it is emitted by a whole wave (emit_big_splat) - by
+    // whichever wave of the launch gets to it first (emit_big_steal).  A wave that holds such splats (wave-uniform ballot; rare)
+    // publishes them, lets its other lanes store straight from their loops, then helps with the queue and finally takes what is
+    // left of its own.  (c3 rotated by 25 degrees: emit 0.27 ms with the per-lane walk, 0.20 with the owner's wave emitting them
+    // one after the other.)
     const unsigned long long bigm = __ballot(cnt > (uint32_t)EMIT_BIG);
     if (bigm != 0ull) {
-        unsigned long long m = bigm;
-        while (m != 0ull) {
+        uint32_t myslot = 0xFFFFFFFFu;
+        for (unsigned long long m = bigm; m != 0ull; m &= m - 1ull) {
             const int b = __builtin_ctzll(m);
-            m &= m - 1ull;
             const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)g, b);
-            uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off0, b);
-            const float4 b0 = rec[gb].q0, b1 = rec[gb].q1;            // (one request: every lane asks for the same record)
-            const int bradius = __float_as_int(rec[gb].q2.z);
-            int bx0, by0, bx1, by1;
-            tile_rect(b0.x, b0.y, bradius, gx, gy, bx0, by0, bx1, by1);
-            const CullParams bk = make_cull(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
-            const float bdet_inv = __builtin_amdgcn_rcpf(b0.z * b1.x - b0.w * b0.w);
-            for (int yb = by0; yb < by1; yb += 64) {
-                const int yl = yb + lane;
-                int xa = bx0, n = 0;
-                if (yl < by1) {
-                    int xb_ = bx1 - 1;
-                    if (!cull || row_span(bk, bdet_inv, yl, bx0, bx1, xa, xb_)) n = xb_ - xa + 1;
+            const uint32_t ob = (uint32_t)__builtin_amdgcn_readlane((int)off0, b);
+            uint32_t slot = 0xFFFFFFFFu;
+            if (lane == 0) {
+                slot = atomicAdd(&big_ctl[0], 1u);
+                if (slot < (uint32_t)BIGQ_CAP) {
+                    big_items[slot] = make_uint2(gb, ob);
+                    __threadfence();
+                    atomicExch(&big_ctl[4 + slot], 1u);          // published
                 }
-                const uint32_t inc_r = wave_incl_scan((uint32_t)n, lane);
-                const uint32_t roff = inc_r - (uint32_t)n;
-                const uint32_t btot = (uint32_t)__shfl((int)inc_r, 63, 64);
-                const int rows = min(64, by1 - yb);
-                for (int r = 0; r < rows; r++) {
-                    const int nr = __builtin_amdgcn_readlane(n, r);
-                    if (nr == 0) continue;
-                    const int xar = __builtin_amdgcn_readlane(xa, r);
-                    const uint32_t ro = o + (uint32_t)__builtin_amdgcn_readlane((int)roff, r);
-                    const uint32_t t0 = (uint32_t)((yb + r) * gx + xar);
-                    for (int k = lane; k < nr; k += 64) {
-                        inst_tile[ro + k] = t0 + (uint32_t)k;
-                        inst_id[ro + k] = gb;
-                    }
-                }
-                o += btot;
             }
+            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+            if (lane == b) myslot = slot;
         }
         if (cnt != 0 && cnt <= (uint32_t)EMIT_BIG) {
             uint32_t off_d = off0;
@@ -535,6 +585,14 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
                     off_d++;
                 }
             }
+        }
+        emit_big_steal(big_ctl, big_items, rec, gx, gy, cull, inst_tile, inst_id, lane);
+        for (unsigned long long m = bigm; m != 0ull; m &= m - 1ull) {          // what nobody took (or what found the queue full)
+            const int b = __builtin_ctzll(m);
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)myslot, b);
+            if (slot >= (uint32_t)BIGQ_CAP || emit_big_claim(big_ctl, slot, lane))
+                emit_big_splat((uint32_t)__builtin_amdgcn_readlane((int)g, b), (uint32_t)__builtin_amdgcn_readlane((int)off0, b), rec, gx, gy,
+                               cull, inst_tile, inst_id, lane);
         }
         return;
     }
@@ -574,6 +632,7 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
             inst_tile[base + k] = s_tile[w][k];
             inst_id[base + k] = s_id[w][k];
         }
+        emit_big_steal(big_ctl, big_items, rec, gx, gy, cull, inst_tile, inst_id, lane);       // (two loads where no view holds a big splat)
         return;
     }
     int y = y0 - 1, x = 0, xb = -1;          // "row exhausted": the first step advances to row y0
@@ -602,6 +661,7 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
         }
         __builtin_amdgcn_wave_barrier();          // the window is re-used
     }
+    emit_big_steal(big_ctl, big_items, rec, gx, gy, cull, inst_tile, inst_id, lane);
 }
 
 
@@ -1014,17 +1074,17 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
     if (M == 16 && shs && !colors_precomp)
         hipLaunchKernelGGL(preprocess_kernel<48>, dim3(grid), dim3(256), 4 * 64 * PF_ROW * sizeof(float), s, P, D, M, means3D, scales,
                            rotations, opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped,
-                           g.tiles_touched, g.depth_key, cull, g.ref_partial, g.depth_hist);
+                           g.tiles_touched, g.depth_key, cull, g.ref_partial, g.depth_hist, g.big_ctl);
     else
         hipLaunchKernelGGL(preprocess_kernel<0>, dim3(grid), dim3(256), 0, s, P, D, M, means3D, scales, rotations,
                            opacities, shs, cov3D_precomp, colors_precomp, vp, radii, g.rec, g.clamped, g.tiles_touched,
-                           g.depth_key, cull, g.ref_partial, g.depth_hist);
+                           g.depth_key, cull, g.ref_partial, g.depth_hist, g.big_ctl);
 }
 
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
                            uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, hipStream_t s) {
     hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.scan_tmp, g.scan_sub,
-                       g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc, tile_len);
+                       g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc, tile_len, g.big_ctl, g.big_items);
 }
 
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,
