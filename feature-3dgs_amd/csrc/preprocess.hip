@@ -551,23 +551,17 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
     // one after the other.)
     const unsigned long long bigm = __ballot(cnt > (uint32_t)EMIT_BIG);
     if (bigm != 0ull) {
-        uint32_t myslot = 0xFFFFFFFFu;
-        for (unsigned long long m = bigm; m != 0ull; m &= m - 1ull) {
-            const int b = __builtin_ctzll(m);
-            const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)g, b);
-            const uint32_t ob = (uint32_t)__builtin_amdgcn_readlane((int)off0, b);
-            uint32_t slot = 0xFFFFFFFFu;
-            if (lane == 0) {
-                slot = atomicAdd(&big_ctl[0], 1u);
-                if (slot < (uint32_t)BIGQ_CAP) {
-                    big_items[slot] = make_uint2(gb, ob);
-                    __threadfence();
-                    atomicExch(&big_ctl[4 + slot], 1u);          // published
-                }
-            }
-            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-            if (lane == b) myslot = slot;
-        }
+        // (one slot reservation for all of the wave's big splats, the items written by their own lanes, one fence: publishing
+        // them one by one - an atomic round trip, a fence and an exchange each - cost the owner 3 us per splat)
+        const bool isbig = cnt > (uint32_t)EMIT_BIG;
+        uint32_t slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&big_ctl[0], (uint32_t)__popcll(bigm));
+        slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+        const uint32_t myslot = isbig ? slot0 + (uint32_t)__popcll(bigm & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+        const bool queued = isbig && myslot < (uint32_t)BIGQ_CAP;
+        if (queued) big_items[myslot] = make_uint2(g, off0);
+        __threadfence();
+        if (queued) __hip_atomic_store(&big_ctl[4 + myslot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // published
         if (cnt != 0 && cnt <= (uint32_t)EMIT_BIG) {
             uint32_t off_d = off0;
             const float4 d0 = rec[g].q0, d1 = rec[g].q1;

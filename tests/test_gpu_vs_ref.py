@@ -222,7 +222,9 @@ def _adjudicate_gradients(scene, ref_side, over, gst, g_ref, g_prod, pc, pv, max
             p_ = g_prod[k][i].reshape(-1).double().cpu().numpy()
             if k == "dL_dmeans2D":        # (the op's third column is always zero)
                 tp, tr = np.concatenate([tp[:2], [0.0]])[:len(p_)], np.concatenate([tr[:2], [0.0]])[:len(p_)]
-            ok, e_p, e_r = adj.gradient_verdict(tp, p_, tr, r_, float(g_ref[k].abs().max()))
+            sc_i = scene["scales"][i].double().abs()
+            kappa = 1.0 if pv else float((sc_i.max() / sc_i.min().clamp_min(1e-30)).clamp(max=1e6)) ** 2
+            ok, e_p, e_r = adj.gradient_verdict(tp, p_, tr, r_, float(g_ref[k].abs().max()), kappa)
             assert ok, (f"gaussian {i} {k}: product {e_p:.2f} bounds from the fp64 value, reference {e_r:.2f} ({mode}); "
                         f"scales {scene['scales'][i].tolist()}")
             worst_p, worst_r, n_el = max(worst_p, e_p), max(worst_r, e_r), n_el + 1
