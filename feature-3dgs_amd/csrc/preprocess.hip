@@ -548,7 +548,7 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
     // whichever wave of the launch gets to it first (emit_big_steal).  A wave that holds such splats (wave-uniform ballot; rare)
     // publishes them, lets its other lanes store straight from their loops, then helps with the queue and finally takes what is
     // left of its own.  (c3 rotated by 25 degrees: emit 0.27 ms with the per-lane walk, 0.20 with the owner's wave emitting them
-    // one after the other.)
+    // one after the other, 0.08 with the queue.)
     const unsigned long long bigm = __ballot(cnt > (uint32_t)EMIT_BIG);
     if (bigm != 0ull) {
         // (one slot reservation for all of the wave's big splats, the items written by their own lanes, one fence: publishing

@@ -445,6 +445,15 @@ def test_instance_lists_with_huge_splats_match_reference_bit_for_bit(kind, P, W,
     _lists_match(scene, P, W, H, 16, min_big=8)
 
 
+def test_instance_lists_with_more_huge_splats_than_the_queue_holds(option):
+    """1583 splats that each cover the whole 920-tile grid: more than the emit kernel's big-splat queue has slots for
+    (BIGQ_CAP = 1024, csrc/common.h) - the splats that find it full are emitted by their own wave; every wave of the launch
+    publishes, steals and finally claims what is left of its own.  Lists bit-identical to the reference's."""
+    option("tile_cull", 0)
+    scene = _scene(P=1600, C=16, width=640, height=360, seed=7, scale_lo=1.5, scale_hi=4.0)
+    _lists_match(scene, 1600, 640, 360, 16, min_big=1500)
+
+
 def _lists_match(scene, P, W, H, C, min_big=0):
     ref, prod = ru.load_ref(C), ru.product_module()
     d = ru.device_inputs(scene, C, DEV)
