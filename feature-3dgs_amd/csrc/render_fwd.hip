@@ -443,18 +443,24 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                 *reinterpret_cast<float4*>(&ck.feat[inst * CH + 4 * v]) = f;
             }
         }
+        // an odd (not a multiple of GI) count is padded with null entries - opacity 0: alpha = 0 fails the 1/255 test at every
+        // pixel; a zero feature row - so that the blend loop below needs no "is there a second entry" logic at all
+        if ((cnt & (GI - 1)) != 0) {
+            for (int q = cnt; q < ((cnt + GI - 1) & ~(GI - 1)); q++) {
+                if (lane < 12) reinterpret_cast<float*>(&ck.ent[q])[lane] = 0.0f;
+                for (int c = lane; c < CH; c += 64) ck.feat[q * CH + c] = 0.0f;
+            }
+        }
         __builtin_amdgcn_wave_barrier();
 
         for (int j = 0; j < cnt; j += GI) {
             float4 g0[GI], cdv[GI];
             float2 g1[GI];
             uint32_t pos_e[GI];
-            bool live_e[GI];
             float Bv[NP][NB];
 #pragma unroll
             for (int e = 0; e < GI; e++) {
-                live_e[e] = j + e < cnt;
-                const int je = live_e[e] ? j + e : j;
+                const int je = j + e;
                 g0[e] = ck.ent[je].geo;
                 if constexpr (BASE && !CDB) cdv[e] = ck.ent[je].cd;
                 const float4 tail = *reinterpret_cast<const float4*>(&ck.ent[je].co_c);
@@ -463,10 +469,10 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
             }
 #pragma unroll
             for (int k = 0; k < NP; k++) {
-                // B rows: instance j+2k for lanes 0-31, j+2k+1 for lanes 32-63 (a missing instance has w = 0 and
-                // re-reads row j so that stale LDS contents can never inject a NaN)
+                // B rows: instance j+2k for lanes 0-31, j+2k+1 for lanes 32-63 (a missing instance is a null entry: w = 0
+                // against a row of zeros)
                 const int e0 = 2 * k;
-                const int rsel = (lane >> 5) ? (live_e[e0 + 1] ? j + e0 + 1 : j) : (live_e[e0] ? j + e0 : j);
+                const int rsel = j + e0 + (lane >> 5);
                 if constexpr (CH == 16) {
                     Bv[k][0] = reinterpret_cast<const float*>(&ck)[rsel * b_stride + b_off];
                 } else {
@@ -479,7 +485,8 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
 #pragma unroll
             for (int p = 0; p < PPL; p++) slot_live[p] = __any(T[p] > 0.0f);
             float w[GI][PPL];
-            bool any_blend = false;
+            unsigned long long blend_mask = 0ull;       // (a wave-uniform mask, not a per-lane flag: the flag would cross the
+                                                        //  slot_live branch as a 0/1 register and be compared again)
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 if (!slot_live[p]) {
@@ -494,7 +501,7 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                     const float dx = g0[e].x - pxf[p], dy = g0[e].y - pyf[p];
                     const float power = splat_power2(dx, dy, g0[e].z, g0[e].w, g1[e].x);
                     araw[e] = fminf(ALPHA_MAX, g1[e].y * __builtin_amdgcn_exp2f(power));
-                    valid[e] = live_e[e] && !(power > 0.0f) && !(araw[e] < ALPHA_MIN);
+                    valid[e] = !(power > 0.0f) && !(araw[e] < ALPHA_MIN);
                 }
 #pragma unroll
                 for (int e = 0; e < GI; e++) {
@@ -514,10 +521,15 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                             dep[p] = fmaf(cdv[e].w, wv, dep[p]);
                         }
                     }
-                    any_blend = any_blend || ok;
                 }
+                // any weight of the pixel non-zero?  The weights are >= 0: one compare per entry pair (w0 != -w1), and a compare is
+                // what the ballot wants to see - from a combination of lane masks it goes through a 0/1 register and a second compare
+                bool nz = w[0][p] != -w[1][p];
+#pragma unroll
+                for (int e = 2; e < GI; e += 2) nz = nz || (w[e][p] != -w[e + 1][p]);
+                blend_mask |= __builtin_amdgcn_ballot_w64(nz);
             }
-            if (__any(any_blend) && !FW_DEV_SKIP(256)) {
+            if (blend_mask != 0ull && !FW_DEV_SKIP(256)) {
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
                     const int e0 = 2 * k;
