@@ -316,7 +316,8 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     } else {
         rg = a.ranges[tile];
     }
-    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x), r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
+    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
+    uint32_t r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
 
     // pixel-centre rectangle covered by this wave (PPL quadrants): used by the wave-level footprint test
     // (kept as scalar integers; converted where the test runs, see sgpr_opaque)
@@ -341,6 +342,14 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
         inside[p] = x < a.W && y < a.H;
         pix_id[p] = y * a.W + x;
         T[p] = inside[p] ? 1.0f : -1.0f; dep[p] = 0.f; last[p] = 0;
+        if constexpr (!BASE) {
+            // a later channel window knows where every pixel's walk ended (n_contrib of the first window: the position of its last
+            // contributor): "pos <= n_contrib" replaces the transmittance test and the finished flag - the entries that pass are
+            // the same, entry by entry (an entry fails the transmittance test only by ending the walk, and then lies behind the
+            // last contributor) - and the quadrant stops at its deepest pixel instead of looking for live ones
+            T[p] = 1.0f;
+            last[p] = inside[p] ? a.n_contrib[pix_id[p]] : 0u;
+        }
         col[p][0] = col[p][1] = col[p][2] = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; h++)
@@ -348,6 +357,13 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
             for (int nb = 0; nb < NB; nb++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[p][h][nb][r] = 0.f;
+    }
+
+    if constexpr (!BASE) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int p = 0; p < PPL; p++) m = max(m, last[p]);
+        r_hi = min(r_hi, r_lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(m)));
     }
 
     // CH = 16: where this lane's B column lives (dwords from the start of the chunk image, per staged entry): channels 0..15
@@ -375,10 +391,12 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     }
 
     for (uint32_t base = r_lo; base < r_hi; base += CHK) {
-        bool anylive = false;
+        if constexpr (BASE) {
+            bool anylive = false;
 #pragma unroll
-        for (int p = 0; p < PPL; p++) anylive = anylive || T[p] > 0.0f;
-        if (!__any(anylive)) break;
+            for (int p = 0; p < PPL; p++) anylive = anylive || T[p] > 0.0f;
+            if (!__any(anylive)) break;
+        }
         const int cnt_in = (int)min((uint32_t)CHK, r_hi - base);
         // wave-level culling: drop splats whose 1/255 footprint misses this wave's pixel block, compact the rest
         const bool hit = lane < cnt_in && rect_hit(n_q0.x, n_q0.y, n_q0.z, n_q0.w, n_q1.x, n_q1.y, (float)sgpr_opaque(iwx0),
@@ -483,7 +501,7 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
             // a quadrant whose 64 pixels are all saturated is skipped as a whole (wave-uniform branch)
             bool slot_live[PPL];
 #pragma unroll
-            for (int p = 0; p < PPL; p++) slot_live[p] = __any(T[p] > 0.0f);
+            for (int p = 0; p < PPL; p++) slot_live[p] = BASE ? __any(T[p] > 0.0f) : true;
             float w[GI][PPL];
             unsigned long long blend_mask = 0ull;       // (a wave-uniform mask, not a per-lane flag: the flag would cross the
                                                         //  slot_live branch as a 0/1 register and be compared again)
@@ -502,16 +520,18 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
                     const float power = splat_power2(dx, dy, g0[e].z, g0[e].w, g1[e].x);
                     araw[e] = fminf(ALPHA_MAX, g1[e].y * __builtin_amdgcn_exp2f(power));
                     valid[e] = !(power > 0.0f) && !(araw[e] < ALPHA_MIN);
+                    if constexpr (!BASE) valid[e] = valid[e] && pos_e[e] <= last[p];
                 }
 #pragma unroll
                 for (int e = 0; e < GI; e++) {
                     const float test_T = T[p] * (1.0f - araw[e]);      // negative once the pixel is finished
-                    const bool below = test_T < T_MIN;
+                    const bool below = BASE && test_T < T_MIN;
                     const bool ok = valid[e] & !below;
                     const bool term = valid[e] & below;                 // (re-)marks finished pixels
                     const float wv = ok ? araw[e] * T[p] : 0.0f;
                     w[e][p] = wv;
-                    T[p] = ok ? test_T : (term ? -fabsf(T[p]) : T[p]);
+                    if constexpr (BASE) T[p] = ok ? test_T : (term ? -fabsf(T[p]) : T[p]);
+                    else T[p] = ok ? test_T : T[p];
                     if constexpr (BASE) {
                         last[p] = ok ? pos_e[e] : last[p];
                         if constexpr (!CDB) {
