@@ -177,3 +177,28 @@ def test_local_chain_truth_equals_the_full_fp64_backward():
     assert ok and e_p > 9 and e_r > 19
     ok, _, _ = adj.gradient_verdict(np.array([1.0]), np.array([1.01]), np.array([1.0]), np.array([1.001]), 1.0)
     assert not ok
+
+
+def test_gradient_verdict_rule():
+    """tests/adjudicate.py::gradient_verdict, the three ways a (Gaussian, tensor) passes - inside the bound; no further from the
+    exact value than the reference is (e_p <= 1 + SLACK e_r); inside what fp32 can resolve of a chain with condition number
+    kappa (e_p <= 1 + kappa 2^-24 / 1e-3) - and the case that passes none of them."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import adjudicate as adj
+    t = np.array([2.0, -1.0])
+    one = lambda rel: t * (1.0 + rel)                       # an evaluation `rel` off the exact value, relatively
+    ok, e_p, e_r = adj.gradient_verdict(t, one(0.9e-3), t, one(5e-3), 0.0)
+    assert ok and e_p < 1.0 < e_r                           # inside the bound whatever the reference does
+    ok, e_p, e_r = adj.gradient_verdict(t, one(1.8e-3), t, one(0.45e-3), 0.0)
+    assert ok and abs(e_p - 1.8) < 1e-6 and abs(e_r - 0.45) < 1e-6      # 1.8 <= 1 + 2 x 0.45
+    ok, _, _ = adj.gradient_verdict(t, one(2.0e-3), t, one(0.45e-3), 0.0)
+    assert not ok                                           # 2.0 > 1.9
+    kappa = (271.0) ** 2                                    # an axis ratio of 1 : 271 -> 4.4 bounds of allowance
+    ok, _, _ = adj.gradient_verdict(t, one(5.0e-3), t, one(0.1e-3), 0.0, kappa)
+    assert ok
+    ok, _, _ = adj.gradient_verdict(t, one(6.0e-3), t, one(0.1e-3), 0.0, kappa)
+    assert not ok
+    # the absolute term of the bound: 1e-5 of the tensor's scale
+    ok, e_p, _ = adj.gradient_verdict(np.zeros(2), np.array([0.9e-5, 0.0]), np.zeros(2), np.zeros(2), 1.0)
+    assert ok and abs(e_p - 0.9) < 1e-9
