@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "render_common.h"
+#include "pl_phase1.h"
 #include "resize_taps.h"
 
 namespace f3dgs {
@@ -59,9 +60,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // one term.  Per chunk a wave issues 24 (moment wave: 16) matrix instructions of 16 cycles instead of 64 of 32 cycles.
 // One v_cvt_pk_bf16_f32 converts two values (round to nearest even); the halves are stored with ds_write_b16 /
 // ds_write_b16_d16_hi as they stand.
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
-}
 // (lo, hi) -> packed high terms `h` and packed middle terms `m`
 __device__ __forceinline__ void split_bf16(float lo, float hi, uint32_t& h, uint32_t& m) {
     h = pack_bf16(lo, hi);
@@ -71,12 +69,11 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint32_t (&a)[4], const uint32_
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u32x4{a[0], a[1], a[2], a[3]}),
                                                    __builtin_bit_cast(bf16x8, u32x4{b[0], b[1], b[2], b[3]}), c, 0, 0, 0);
 }
-// BF tile layout (aliases PlShared::wt and ::st, 32 KB): quadrant q at byte 8192 q; term t (0: w high, 1: w middle, 2: s high,
-// 3: s middle) at + 2048 t; row (entry) i at + 128 i; the row's eight 16-byte units = the eight pixel rows of the quadrant, unit
-// y stored at slot y ^ (i >> 1); pixel x of the row at + 2 x.  Operand lane (i, kg) of K span ks reads unit 4 ks + kg of row i -
-// sixteen bytes = the K slots 8 kg .. 8 kg + 7 - and the sixteen lanes of a ds_read_b128 service group meet sixteen different
-// 16-byte slots of the 256-byte bank row (two rows per bank row x eight slots).
-constexpr int BF_QUAD = 8192, BF_TERM = 2048, BF_ROWB = 128;
+// BF tile layout (aliases PlShared::wt and ::st, 32 KB; constants in pl_phase1.h): quadrant q at byte 8192 q; term t (0: w high,
+// 1: w middle, 2: s high, 3: s middle) at + 2048 t; row (entry) i at + 128 i; the row's eight 16-byte units = the eight pixel rows
+// of the quadrant, unit y stored at slot y ^ (i >> 1); pixel x of the row at + 2 x.  Operand lane (i, kg) of K span ks reads unit
+// 4 ks + kg of row i - sixteen bytes = the K slots 8 kg .. 8 kg + 7 - and the sixteen lanes of a ds_read_b128 service group meet
+// sixteen different 16-byte slots of the 256-byte bank row (two rows per bank row x eight slots).
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access of the
 // wave - here the fire-and-forget atomics of the flush, microseconds under load - which nothing in the workgroup reads.
@@ -104,6 +101,9 @@ __device__ __forceinline__ int fresh_lane() {
 #define PL_STAGE_MARK(K) do {} while (0)
 #endif
 
+#ifndef PL_SCHED
+#define PL_SCHED 1                 // who orders phase 1 of the bf16 shape, see pl_phase1.h (0: the compiler, as in round 5)
+#endif
 constexpr int PL_CAP = 16;         // list entries per chunk = rows of one 16x16x4 matrix instruction
 constexpr int PL_ROW = 64;         // dwords per pixel-block row of an A tile (16 entries x 4 px, XOR-swizzled)
 constexpr int PL_TILE = 16 * PL_ROW;
@@ -112,12 +112,7 @@ constexpr int PL_FS = 68;          // dwords per entry of the flush tile: 32 (64
 constexpr int PL_SP = 260;         // dwords per plane of the staging image (16 x 16 pixels + 4: plane offset of 4 banks)
 constexpr int PL_STAGE_PLANES = 38;
 
-// One staged list entry (shared by the four waves): three broadcast reads per entry in phase 1.
-struct PlRec {
-    float4 q0;   // mean_x, mean_y, conic_a', conic_b'   (conic pre-scaled, see splat_power2)
-    float4 q1;   // conic_c', opacity, red, green
-    float4 q2;   // blue, depth, unused, Gaussian index (bits)
-};
+// (PlRec - one staged list entry, shared by the four waves, three broadcast reads per entry in phase 1 - lives in pl_phase1.h)
 
 // A tiles: element (row i, column c) of a quadrant's tile, with c = 16 u + 4 k + m - the pixel that matrix step
 // t = 4 u + m contracts at K index k - lives in pixel block b = c >> 2 at dword 64 b + 4 (i ^ (b & 7)) + (c & 3): the 16
@@ -496,11 +491,18 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     // records of window w -> LDS (by the three loader waves), the next window's requests go out
     auto store_window = [&](int w) {
         if (q < 3 && w >= 0) {
-            float4 v = part_cur;
-            if (q == 0) { v.z *= CONIC_SCALE_AC; v.w *= CONIC_SCALE_B; }
-            else if (q == 1) { v.x *= CONIC_SCALE_AC; }
-            else { v.w = __uint_as_float(gid_cur); }
-            reinterpret_cast<float4*>(&L.rec[lane])[q] = v;
+            // SplatRec thirds {mean, a, b | c, opacity, r, g | b, depth, ..} -> PlRec {mean, a', b' | c', opacity, id, - | r, g, b, depth}
+            const float4 v = part_cur;
+            PlRec& dst = L.rec[lane];
+            if (q == 0) {
+                dst.q0 = make_float4(v.x, v.y, v.z * CONIC_SCALE_AC, v.w * CONIC_SCALE_B);
+            } else if (q == 1) {
+                *reinterpret_cast<float2*>(&dst.q1.x) = make_float2(v.x * CONIC_SCALE_AC, v.y);
+                *reinterpret_cast<float2*>(&dst.q2.x) = make_float2(v.z, v.w);
+            } else {
+                dst.q1.z = __uint_as_float(gid_cur);
+                *reinterpret_cast<float2*>(&dst.q2.z) = make_float2(v.x, v.y);
+            }
         }
         gid_cur = gid_nxt;
         part_cur = load_part(w - 1, gid_cur);
@@ -533,9 +535,9 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 if constexpr (GEO) {
                     const float4 i0 = rr.q0, i1 = rr.q1;
                     *reinterpret_cast<float4*>(info + 60) = i0;
-                    *reinterpret_cast<float4*>(info + 64) = make_float4(i1.x, i1.y, rr.q2.w, 0.f);
+                    *reinterpret_cast<float4*>(info + 64) = make_float4(i1.x, i1.y, i1.z, 0.f);
                 } else {
-                    info[64] = rr.q2.w;
+                    info[64] = rr.q1.z;
                 }
             }
             if (pos_hi - 15 < my_max && !PL_DEV_SKIP(2)) {
@@ -543,36 +545,36 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 auto phase1 = [&](auto nec, auto prefc) {
                     constexpr int NE = decltype(nec)::value;
                     constexpr bool PREF = decltype(prefc)::value;
-                    float4 n0[NE], n1[NE];
-                    float2 n2[NE];
+                    float4 n0[NE], n2[NE];
+                    float2 n1[NE];
                     float w_even = 0.f;       // BF, later windows: the even entry's weight waits for its odd neighbour
                     (void)w_even;
                     if constexpr (PREF) {
 #pragma unroll
                         for (int k = 0; k < NE; k++) {
-                            n0[k] = rc[k].q0; n1[k] = rc[k].q1;
-                            if constexpr (GEO) n2[k] = *reinterpret_cast<const float2*>(&rc[k].q2);
+                            n0[k] = rc[k].q0; n1[k] = *reinterpret_cast<const float2*>(&rc[k].q1);
+                            if constexpr (GEO) n2[k] = rc[k].q2;
                         }
                     }
 #pragma unroll
                     for (int p = 0; p < 16 / NE; p++) {
-                        float4 e0[NE], e1[NE];
-                        float2 e2[NE];
+                        float4 e0[NE], e2[NE];
+                        float2 e1[NE];
                         if constexpr (PREF) {
 #pragma unroll
                             for (int k = 0; k < NE; k++) { e0[k] = n0[k]; e1[k] = n1[k]; e2[k] = n2[k]; }
                             if (p < 16 / NE - 1) {
 #pragma unroll
                                 for (int k = 0; k < NE; k++) {
-                                    n0[k] = rc[NE * (p + 1) + k].q0; n1[k] = rc[NE * (p + 1) + k].q1;
-                                    if constexpr (GEO) n2[k] = *reinterpret_cast<const float2*>(&rc[NE * (p + 1) + k].q2);
+                                    n0[k] = rc[NE * (p + 1) + k].q0; n1[k] = *reinterpret_cast<const float2*>(&rc[NE * (p + 1) + k].q1);
+                                    if constexpr (GEO) n2[k] = rc[NE * (p + 1) + k].q2;
                                 }
                             }
                         } else {
 #pragma unroll
                             for (int k = 0; k < NE; k++) {
-                                e0[k] = rc[NE * p + k].q0; e1[k] = rc[NE * p + k].q1;
-                                if constexpr (GEO) e2[k] = *reinterpret_cast<const float2*>(&rc[NE * p + k].q2);
+                                e0[k] = rc[NE * p + k].q0; e1[k] = *reinterpret_cast<const float2*>(&rc[NE * p + k].q1);
+                                if constexpr (GEO) e2[k] = rc[NE * p + k].q2;
                             }
                         }
                         PL_COUNT(6, NE);
@@ -590,7 +592,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                             static_assert(ALPHA_MAX == 0.99f, "literal below");
                             asm("v_cndmask_b32_e64 %0, 0, %2, %3\n\tv_min_f32_e32 %1, 0x3f7d70a4, %0" : "=&v"(au[k]), "=v"(al[k]) : "v"(v), "s"(okm));
                             f[k] = __builtin_amdgcn_rcpf(1.f - al[k]);                                 // exactly 1 for skipped pairs
-                            if constexpr (GEO) qd[k] = fmaf(e1[k].z, dR, fmaf(e1[k].w, dG, fmaf(e2[k].x, dB, e2[k].y * dD)));
+                            if constexpr (GEO) qd[k] = fmaf(e2[k].x, dR, fmaf(e2[k].y, dG, fmaf(e2[k].z, dB, e2[k].w * dD)));
                         }
 #pragma unroll
                         for (int k = 0; k < NE; k++) {
@@ -632,7 +634,12 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                         }
                     }
                 };
-                phase1(std::integral_constant<int, P1_NE>{}, std::integral_constant<bool, P1_PREF>{});
+                if constexpr (BF) {
+                    const P1Pixel px{pxf, pyf, last, dR, dG, dB, dD};
+                    tm = pl_phase1_bf16<GEO, PL_SCHED>(rc, px, pos_hi, T, S, bf_tiles, bf_sofs);
+                } else {
+                    phase1(std::integral_constant<int, P1_NE>{}, std::integral_constant<bool, P1_PREF>{});
+                }
                 tm |= 1u << (16 + q);
             }
             if (tm && lane == 0) atomicOr(&L.touched[parity], tm);
