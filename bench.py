@@ -48,6 +48,12 @@ for p in (ROOT, os.path.join(ROOT, "feature-3dgs_amd")):
         sys.path.insert(0, p)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+# F3DGS_BENCH_STUB=1 (tests/test_bench_launch.py only): the whole multi-rank control flow of this file - re-launch under
+# torch.distributed.run, rank relay, the exchange, every diagnostic leg, the one JSON line - on CPU tensors over gloo with the op
+# replaced by a few torch operations.  The line says "data": "stub" and carries no measurement; it exists so that the first real
+# multi-GPU lease (driver-run, not debuggable) does not die in plumbing.
+STUB = os.environ.get("F3DGS_BENCH_STUB", "0") == "1"
+
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_ACHIEVABLE_GBS = 6290.0   # MI355X_MICROARCH.md "Chip-level parameters": what a float4 copy reaches
 FP32_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz, un-packed fp32 (157.3 with v_pk_fma)
@@ -100,7 +106,32 @@ def scene_stats(scene, dev):
     pad = np.zeros((gy * 16, gx * 16), np.uint32)
     pad[:H, :W] = nc.reshape(H, W)
     N_r = int(pad.reshape(gy, 16, gx, 16).max(axis=(1, 3)).astype(np.int64).sum())
-    return dict(Pv=int((radii > 0).sum()), N=int(n), N_r=N_r, tiles=gx * gy)
+    # (entry, quadrant wave) evaluations of phase 1 of the pixel-lane blend backward on THESE lists: a quadrant wave evaluates the
+    # chunks of sixteen list positions up to its deepest pixel (render_bwd_pl.hip: `pos_hi - 15 < my_max`)
+    qmax = pad.reshape(gy, 2, 8, gx, 2, 8).max(axis=(2, 5)).astype(np.int64)
+    bwd_evals = int((16 * ((qmax + 15) // 16)).sum())
+    return dict(Pv=int((radii > 0).sum()), N=int(n), N_r=N_r, tiles=gx * gy, bwd_evals=bwd_evals)
+
+
+def blend_stream_cycles():
+    """SIMD cycles per (entry, wave) of the blend kernels' inner streams run by themselves at four waves per SIMD
+    (tools/ubench/blend_stream.hip: the code of csrc/pl_phase1.h and csrc/fwd_group.h as the kernels compile it, no barriers, no
+    staging, no flush).  Measured LIVE when the binary is there (built by __graft_entry__.build(); ~3 s), otherwise the committed
+    measurement of this round."""
+    exe = os.path.join(ROOT, "tools", "ubench", "blend_stream")
+    src = None
+    d = None
+    if os.path.exists(exe) and not STUB:
+        try:
+            out = subprocess.run([exe, "json"], capture_output=True, timeout=120, text=True).stdout
+            d = json.loads(out.strip().splitlines()[-1])
+            src = "tools/ubench/blend_stream json, run by this process on this GPU"
+        except Exception:      # noqa: BLE001
+            d = None
+    if d is None:
+        nm, d = _committed(("r06_blend_stream.json",))
+        src = f"profiles/{nm} (committed measurement; the binary was not available here)" if d else None
+    return d, src
 
 
 def cpu_baseline(cfg_kw):
@@ -223,9 +254,43 @@ def _committed(name_candidates):
     return None, None
 
 
+def _stub_leaves(scene, dev):
+    import torch
+    P = scene["P"]
+    t = lambda x: x.to(dev).clone()
+    return dict(means3D=t(scene["means3D"]).requires_grad_(), means2D=torch.zeros(P, 3, device=dev, requires_grad=True),
+                opacities=t(scene["opacities"]).requires_grad_(), shs=t(scene["shs"]).requires_grad_(),
+                semantic_feature=t(scene["semantic_feature"]).requires_grad_(),
+                scales=t(scene["scales"]).requires_grad_(), rotations=t(scene["rotations"]).requires_grad_())
+
+
+def _stub_step(scene, dev, dist=None, n_views=1):
+    """STUB mode: every leaf gets a gradient from a few torch operations; the exchange is the real one (dp.dp_step / dp_step_views)."""
+    import dp
+    leaves = _stub_leaves(scene, dev)
+    reduce_keys = ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")
+    sub = {k: leaves[k] for k in reduce_keys}
+
+    def fwd(vid):
+        return sum((v * v).sum() * (1.0 + 0.1 * vid) for v in leaves.values())
+
+    def step(i):
+        for v in leaves.values():
+            v.grad = None
+        if n_views > 1:
+            dp.dp_step_views(lambda j: fwd(j), lambda h: h.backward(), sub, range(n_views), overlap=False, n_streams=1, accumulate=False)
+        elif dist is None:
+            fwd(0).backward()
+        else:
+            dp.dp_step(lambda vid: fwd(vid).backward(), sub, [0], overlap=False)
+    return step, leaves
+
+
 def make_step(scene, dev, pool=4, dist=None, overlap=True):
     """Returns (step(i), leaves): one forward+backward (+ gradient exchange) with the i-th upstream gradient set."""
     import torch
+    if STUB:
+        return _stub_step(scene, dev, dist=dist)
 
     import diff_gaussian_rasterization as dgr
     import dp
@@ -274,6 +339,8 @@ def make_step_views(scene, yaws, dev, pool=4, dist=None, overlap=True, pipelined
     backward pass.  pipelined=False: the same views strictly one after the other on one stream, one gradient tensor per view
     (what dp.dp_step did with several views until round 3) - the comparison leg."""
     import torch
+    if STUB:
+        return _stub_step(scene, dev, dist=dist, n_views=len(yaws))
 
     import diff_gaussian_rasterization as dgr
     import dp
@@ -493,7 +560,7 @@ def main():
     if world == 0 and args.gpus > 1:
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not STUB:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to report fewer")
         raise SystemExit(respawn_under_torchrun(args))
     world = max(world, 1)
@@ -505,18 +572,35 @@ def main():
 
     import numpy as np
     import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if STUB:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if STUB:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    from diff_gaussian_rasterization import _C
     from synth import CONFIGS, make_scene
+    if STUB:
+        class _C:      # noqa: N801  (the op's option / profile surface, inert)
+            _opts = {"feature_mfma": 1, "bwd_bf16": -1, "bwd_bf16_max_ratio": 16, "bwd_pl": -1, "tile_cull": 1, "profile": 0}
+            set_option = staticmethod(lambda k, v: _C._opts.__setitem__(k, v))
+            get_option = staticmethod(lambda k: _C._opts.get(k, 0))
+            profile_reset = staticmethod(lambda: None)
+            profile_read = staticmethod(lambda: [("render_fwd", 1.0, 1), ("render_bwd", 1.0, 1), ("preprocess", 0.5, 1), ("preprocess_bwd", 0.5, 1)])
+        CONFIGS = {k: dict(P=1500, width=64, height=48, C=8, with_depth_grad=False) for k in CONFIGS}
+    else:
+        from diff_gaussian_rasterization import _C
 
     if args.valu:
         _C.set_option("feature_mfma", 0)
@@ -542,8 +626,8 @@ def main():
         step, leaves = make_step(scene, dev, dist=dist, overlap=not args.no_overlap)
 
     def timed(n_steps, per_step_events):       # (`step` is looked up at call time)
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)] if per_step_events else None
-        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)] if per_step_events and not STUB else None
+        sync()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
@@ -553,7 +637,7 @@ def main():
             step(i)
         if evs:
             evs[n_steps].record()
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -561,7 +645,7 @@ def main():
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
-        per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps)] if evs else None
+        per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps)] if evs else ([1e3 * el / n_steps] * n_steps if per_step_events else None)
         return el, per
 
     if args.comm_only:
@@ -571,31 +655,67 @@ def main():
         for v in leaves.values():
             v.grad = torch.zeros_like(v)
         grads = {k: leaves[k].grad for k in ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")}
-        for _ in range(args.warmup):
-            dp.all_reduce_gaussian_grads(grads)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            dp.all_reduce_gaussian_grads(grads)
-        torch.cuda.synchronize()
-        dist.barrier()
-        el = time.perf_counter() - t0
         nbytes = sum(g.numel() * 4 for g in grads.values())
+
+        def time_group(group):
+            for _ in range(args.warmup):
+                dp.all_reduce_gaussian_grads(grads, group=group)
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dp.all_reduce_gaussian_grads(grads, group=group)
+            sync()
+            dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        el = time_group(None)
+        # The same exchange on communicators created under other NCCL_ALGO / NCCL_PROTO settings (RCCL reads them when a
+        # communicator is initialised): xGMI is a point-to-point mesh, and a ring all-reduce is bound by ONE link (SURVEY.md 5:
+        # ~29 ms against ~4 ms for c4) - this table says what the library picked and what the alternatives cost on this node.
+        sweep = {}
+        if not STUB or os.environ.get("F3DGS_BENCH_STUB_SWEEP", "1") == "1":
+            saved = {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO")}
+            for algo, proto in ((None, None), ("Ring", None), ("Tree", None), ("Ring", "Simple"), ("Ring", "LL128"), ("Tree", "Simple")):
+                if algo is None:
+                    continue
+                os.environ["NCCL_ALGO"] = algo
+                if proto:
+                    os.environ["NCCL_PROTO"] = proto
+                else:
+                    os.environ.pop("NCCL_PROTO", None)
+                label = f"NCCL_ALGO={algo}" + (f",NCCL_PROTO={proto}" if proto else "")
+                try:
+                    g = dist.new_group(backend="gloo" if STUB else "nccl")
+                    t = time_group(g)
+                    sweep[label] = {"ms": 1e3 * t / args.steps, "algbw_GBps": nbytes / (t / args.steps) / 1e9}
+                    dist.destroy_process_group(g)
+                except Exception as exc:      # noqa: BLE001  (a setting the library refuses must not cost the line)
+                    sweep[label] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         if rank == 0:
             print(json.dumps({"metric": "gradient all-reduce only (no rendering)", "value": 1e3 * el / args.steps, "unit": "ms",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": False,
                               "bytes_per_rank": nbytes, "algbw_GBps": nbytes / (el / args.steps) / 1e9,
+                              "by_setting": sweep, "data": "stub" if STUB else "synthetic",
                               "config": {"workload": f"{args.config}: (59+{C}) floats x {P} Gaussians"}}), flush=True)
         dist.destroy_process_group()
         return
 
     stats = None
-    if rank == 0:
+    if rank == 0 and STUB:
+        stats = dict(Pv=P, N=4 * P, N_r=2 * P, tiles=12, bwd_evals=8 * P)
+    elif rank == 0:
         # N_r of SURVEY.md 8(d) is defined on the reference's (bounding-rectangle) instance lists
         _C.set_option("tile_cull", 0)
         stats = scene_stats(scene, dev)
         _C.set_option("tile_cull", 1)
+        stats["bwd_evals"] = scene_stats(scene, dev)["bwd_evals"]      # of the lists the product walks
     for i in range(args.warmup):
         step(i)
     # events-off reference run (same K steps): shows what the events of the timed region cost
@@ -614,6 +734,35 @@ def main():
     el_stages, per_step = timed(args.steps, per_step_events=True)
     prof = {name: (ms, calls) for name, ms, calls in _C.profile_read()}
     _C.set_option("profile", 0)
+
+    # What ran: the blend backward's per-Gaussian sums go through bf16 matrix instructions (two-term operands, f32 accumulation)
+    # when the pixel-lane kernel with its bf16 shape is selected - read from the library's options, not assumed.
+    mf = _C.get_option("feature_mfma") != 0
+    opt_bf16 = _C.get_option("bwd_bf16")         # 1 always, 0 never, -1 by the frame's conditioning (the library's default)
+    if STUB:
+        bwd_bf16_active = True
+    else:       # what the last backward call of the runs above actually contracted with
+        bwd_bf16_active = bool(_C.last_backward_contraction() == 1)
+    fp32_exact = None
+    if bwd_bf16_active and not V:
+        # the same K steps with every contraction of the blend backward on exact-fp32 matrix instructions (option bwd_bf16 = 0):
+        # the figure to hold against a reference that computes in fp32 throughout
+        _C.set_option("bwd_bf16", 0)
+        try:
+            for i in range(max(3, args.warmup // 2)):
+                step(i)
+            _C.set_option("profile", 2)
+            _C.profile_reset()
+            el_x, _ = timed(args.steps, per_step_events=False)
+            bx = {name: (ms, calls) for name, ms, calls in _C.profile_read()}
+            fp32_exact = {"ms_per_step": 1e3 * el_x / args.steps,
+                          "render_bwd_ms": (bx["render_bwd"][0] / max(1, bx["render_bwd"][1])) if "render_bwd" in bx else None,
+                          "render_fwd_ms": (bx["render_fwd"][0] / max(1, bx["render_fwd"][1])) if "render_fwd" in bx else None}
+        finally:
+            _C.set_option("profile", 0)
+            _C.set_option("bwd_bf16", opt_bf16)
+        for i in range(2):
+            step(i)
 
     views_breakdown = None
     if V:
@@ -651,12 +800,12 @@ def main():
                  for k in ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")}
         for _ in range(3):
             dp.all_reduce_gaussian_grads(grads)
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             dp.all_reduce_gaussian_grads(grads)
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -670,9 +819,12 @@ def main():
         # 1/N of the rows, all-gather of the updated parameters (half the gradient bytes; tests/test_dp_gloo.py: bit-identical
         # parameters at world size 2).  What the first multi-GPU lease needs to decide between them.
         try:
-            from fused_adam import FusedAdam
             keys6 = ("means3D", "shs", "semantic_feature", "opacities", "scales", "rotations")
-            mk = lambda t: FusedAdam([{"params": [t[k]], "lr": 1e-5} for k in keys6], lr=0.0, eps=1e-15)
+            if STUB:
+                mk = lambda t: torch.optim.Adam([{"params": [t[k]], "lr": 1e-5} for k in keys6], lr=0.0, eps=1e-15)
+            else:
+                from fused_adam import FusedAdam
+                mk = lambda t: FusedAdam([{"params": [t[k]], "lr": 1e-5} for k in keys6], lr=0.0, eps=1e-15)
             opt_a = mk({k: leaves[k] for k in keys6})
 
             def step_a(i):
@@ -699,6 +851,25 @@ def main():
                                                     "the parameters (dp.ShardedOptimizer; not overlapped)"})
         except Exception as exc:     # diagnostic legs must never cost the bench line
             dp_breakdown["train_step_note"] = f"sharded-optimizer legs failed: {type(exc).__name__}: {exc}"
+            step = _step
+        # Two views per GPU and step (what `--views-per-iter 2N` reports as its own line): the exchange is per STEP, so its share
+        # halves - the third column of DESIGN.md 6's table (c3 6.7x, c4 6.3x by the model) from the same lease.
+        try:
+            yaws2 = [5.0 * (2 * rank + j) for j in range(2)]
+            step2, _lv2 = make_step_views(scene, yaws2, dev, dist=dist, overlap=not args.no_overlap)
+            step = step2
+            for i in range(3):
+                step(i)
+            el_2v, _ = timed(args.steps, per_step_events=False)
+            step = _step
+            del _lv2
+            dp_breakdown.update({"two_views_per_gpu_ms_per_step": 1e3 * el_2v / args.steps,
+                                 "two_views_per_gpu_mpix_s": 2 * world * W * H / 1e6 / (el_2v / args.steps),
+                                 "two_views_per_gpu_note": f"{2 * world} views per step, two per GPU, pipelined over two streams, feature gradient "
+                                                           "accumulated in place, ONE exchange per step (bench.py --views-per-iter "
+                                                           f"{2 * world} gives the full line)"})
+        except Exception as exc:     # noqa: BLE001
+            dp_breakdown["two_views_per_gpu_note"] = f"leg failed: {type(exc).__name__}: {exc}"
             step = _step
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -763,15 +934,70 @@ def main():
                 pass
         per = sorted(per_step)
         pct = lambda q: per[min(len(per) - 1, int(q * len(per)))]
+        if args.valu or not mf:
+            blend_label = "vector pipe only (option feature_mfma = 0)"
+        elif C == 0:
+            blend_label = "RGB only: both blend kernels on the vector pipe (no feature contraction)"
+        else:
+            blend_label = ("forward: feature contraction on exact-fp32 matrix instructions; backward: " +
+                           ("every per-Gaussian sum on bf16 matrix instructions with two-term operands (f32 accumulation; option bwd_bf16 = 1; "
+                            "gradients within 1e-4 |g| + 1e-5 max|g| of the exact-fp32 contraction, tests/test_gpu_parity.py)"
+                            if bwd_bf16_active else "every per-Gaussian sum on exact-fp32 matrix instructions (option bwd_bf16 = 0)"))
+        dtype_label = "f32 (blend-backward sums: bf16 x 2-term products, f32 accumulate)" if bwd_bf16_active else "f32"
+        views_here = per_rank if V else 1                      # views one rank renders per step
+        alg_step = alg["total"] * views_here                   # algorithmic bytes ONE GPU moves per step
+        alg_step_min = alg["total_min"] * views_here
+        # compute roofline of the dominant kernel: what the vector pipe (and the LDS traffic of the same stream) allows phase 1 of
+        # the pixel-lane blend backward, measured by running that stream alone (tools/ubench/blend_stream.hip)
+        roofline_compute = None
+        if dom == "render_bwd" and bwd_bf16_active and not V:
+            cyc, cyc_src = blend_stream_cycles()
+            if cyc:
+                n_simd = 4 * (256 if STUB else torch.cuda.get_device_properties(dev).multi_processor_count)
+                c1 = cyc["first_window_sched1"][3]
+                cw = cyc["later_window_sched1"][3]
+                later = max(0, (C - 32 + 63) // 64)
+                evals = stats["bwd_evals"]
+                floor_ms = evals * (c1 + later * cw) / (n_simd * 2.4e9) * 1e3
+                roofline_compute = {
+                    "kernel": "render_bwd", "bound": "vector-instruction issue + LDS of phase 1 (every wave of a SIMD in phase 1 all the time)",
+                    "floor_ms": floor_ms, "achieved_ms": dom_ms, "frac": floor_ms / dom_ms,
+                    "evaluations_per_launch": evals, "evaluation": "(list entry, quadrant wave of 64 pixel lanes), first channel window",
+                    "simd_cycles_per_evaluation": c1, "simd_cycles_per_evaluation_later_window": cw, "later_windows": later,
+                    "simds": n_simd, "clock_GHz": 2.4, "cycles_source": cyc_src,
+                    "note": "floor = evaluations x SIMD cycles per evaluation at four waves per SIMD / (SIMDs x clock); phase 1 is 2/3 of the "
+                            "kernel's vector instructions - staging, the matrix phase and the flush are NOT in the floor (DESIGN.md 3.5)"}
+                fw = cyc.get("forward_c32_with_matrix")
+                if fw and C == 32:
+                    fwd_ms = blend["render_fwd"][0] / max(1, blend["render_fwd"][1]) if "render_fwd" in blend else stage_ms.get("render_fwd")
+                    sqv = ((profiled or {}).get("valu_issue") or {}).get("render_fwd", {}).get("valu_instructions_per_launch")
+                    if sqv and fwd_ms:
+                        ev_f = sqv / 26.0          # 52 vector instructions per entry pair
+                        roofline_compute["render_fwd"] = {
+                            "floor_ms": ev_f * fw[3] / (n_simd * 2.4e9) * 1e3, "achieved_ms": fwd_ms,
+                            "frac": ev_f * fw[3] / (n_simd * 2.4e9) * 1e3 / fwd_ms, "simd_cycles_per_evaluation": fw[3],
+                            "simd_cycles_per_evaluation_vector_only": cyc["forward_c32_vector_only"][3],
+                            "evaluations_per_launch": ev_f,
+                            "evaluations_source": "committed SQ_INSTS_VALU of this config / 26 vector instructions per (entry, wave) "
+                                                  "(profiled.valu_issue; a separate run)"}
         out = {
             "metric": f"rendered Mpix/s of rasterizer fwd+bwd (train-step ms in ms_per_step), {config_label(P, W, H, C)}",
             "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if V else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "blend_kernels": "vector pipe only (option feature_mfma = 0)" if args.valu else
-                             "forward: feature contraction on exact-fp32 matrix instructions; backward: every per-Gaussian sum on bf16 matrix "
-                             "instructions with two-term operands (fp32 accumulation, option bwd_bf16; gradients within 1e-4 |g| + 1e-5 max|g| "
-                             "of the exact-fp32 contraction, tests/test_gpu_parity.py)",
+            "dtype": dtype_label, "data": "stub" if STUB else "synthetic",
+            "blend_kernels": blend_label,
+            "options": {k: _C.get_option(k) for k in ("feature_mfma", "bwd_bf16", "bwd_bf16_max_ratio", "bwd_pl", "tile_cull")},
+            "blend_backward_contraction": "bf16 two-term" if bwd_bf16_active else "exact fp32",
+            "ms_per_step_fp32_exact": fp32_exact["ms_per_step"] if fp32_exact else (ms_per_step if not bwd_bf16_active else None),
+            "fp32_exact": ({**fp32_exact,
+                            "value_mpix_s": world * W * H / 1e6 / (fp32_exact["ms_per_step"] * 1e-3),
+                            "roofline": ({"kernel": "render_bwd", "kernel_ms": fp32_exact["render_bwd_ms"],
+                                          "achieved": alg["render_bwd"] / (fp32_exact["render_bwd_ms"] * 1e-3) / 1e9, "unit": "GB/s",
+                                          "frac": alg["render_bwd"] / (fp32_exact["render_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                         if fp32_exact.get("render_bwd_ms") else None),
+                            "note": "the same K steps with option bwd_bf16 = 0: every contraction of the blend backward on exact-fp32 "
+                                    "matrix instructions (bit-equal to an fmaf chain); the forward is exact fp32 in both"}
+                           if fp32_exact else None),
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {scene['sh_degree']}, feat_dim={C}, "
                                    + (f"{V} views per step ({per_rank} per GPU, rotated 5 degrees apart, pipelined over two streams, "
                                       f"gradients accumulated across the views)" if V else "one view per GPU")
@@ -797,11 +1023,12 @@ def main():
                                  "vector-instruction issue (an exponential, a reciprocal, three threshold tests and ~30 dependent operations "
                                  "per (pixel, Gaussian) pair; DESIGN.md 3.5, profiles/): see `profiled.valu_issue.*`"},
             "profiled": profiled,
-            "roofline_whole_step": {"algorithmic_bytes": alg["total"], "algorithmic_bytes_min": alg["total_min"],
-                                    "achieved": alg["total"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
-                                    "frac": alg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "frac_of_achievable_6290": alg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS,
-                                    "frac_A_min": alg["total_min"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline_compute": roofline_compute,
+            "roofline_whole_step": {"algorithmic_bytes": alg_step, "algorithmic_bytes_min": alg_step_min, "views_per_gpu_and_step": views_here,
+                                    "achieved": alg_step / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s per GPU",
+                                    "frac": alg_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "frac_of_achievable_6290": alg_step / (ms_per_step * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS,
+                                    "frac_A_min": alg_step_min / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "note": "A = SURVEY.md 8(d) algorithmic bytes of the REFERENCE's algorithm (152 B per instance of sort "
                                             "traffic this design does not move); A_min = the same with perfect cross-tile reuse"},
             "dp_breakdown": dp_breakdown,
@@ -809,7 +1036,7 @@ def main():
             "stage_ms": stage_ms,
             "stage_ms_source": "auxiliary run of the same K steps with an event at every stage boundary (not the timed region)",
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not STUB:
             out["cpu_baseline"] = cpu_baseline(cfg_kw)
             out["cpu_reference_path_c1"] = cpu_reference_path_c1(dev)
             nm, red = _committed(("r05_cpu_c3_reduced.json", "r04_cpu_c3_reduced.json"))

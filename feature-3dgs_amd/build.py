@@ -59,10 +59,25 @@ def build_binding(force: bool = False, src_name: str = "binding.cpp", target: st
     return EXT
 
 
+def build_ubench(force: bool = False) -> str:
+    """tools/ubench/blend_stream: the blend kernels' inner streams (csrc/pl_phase1.h, csrc/fwd_group.h) run by themselves -
+    bench.py's `roofline_compute` measures its floor with it on the GPU it runs on.  A measurement tool, not part of the product."""
+    root = os.path.join(HERE, "..")
+    src = os.path.join(root, "tools", "ubench", "blend_stream.hip")
+    exe = os.path.join(root, "tools", "ubench", "blend_stream")
+    deps = [src] + [os.path.join(CSRC, h) for h in ("pl_phase1.h", "fwd_group.h", "render_common.h", "common.h")]
+    if not force and _newer(exe, deps):
+        return exe
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mcode-object-version=5",
+                           "-fno-slp-vectorize", f"-I{CSRC}", src, "-o", exe])
+    return exe
+
+
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_binding(force)
     build_binding(force, "binding_knn.cpp", KNN_EXT)      # simple_knn._C
+    build_ubench(force)
 
 
 if __name__ == "__main__":

@@ -6,11 +6,13 @@
 // the 4-byte read-back of num_rendered (same place as rasterizer_impl.cu:283).
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <initializer_list>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -29,6 +31,34 @@ thread_local void* g_rows_ready_ctx = nullptr;
 thread_local int g_rows_ready_chunks = 1;
 thread_local int g_feature_accumulate = 0;
 thread_local LowresGrad g_lowres;      // consumed by the next f3dgs_backward of this thread
+std::atomic<int> g_last_bwd_bf16{-1};  // contraction of the process's last blend backward (PyTorch runs it on an autograd thread): 1 bf16 two-term, 0 exact fp32, -1 none yet
+
+// What f3dgs_forward learned about a frame that the matching f3dgs_backward needs on the HOST: the largest axis ratio among
+// the frame's visible Gaussians (option bwd_bf16 = -1 chooses the contraction precision by it).  The two calls share nothing
+// but the caller's state buffers - and may run on different host threads (PyTorch's autograd engine runs the backward pass on a
+// thread of its own) - so the value is kept here, process-wide, keyed by (device, geometry buffer): the caller hands that buffer
+// back untouched, and a buffer that has been re-used by a later forward call belongs to that call.  A backward call that finds
+// nothing (a buffer copied elsewhere, more than 256 frames in flight) takes the exact contraction.
+struct FrameNote { int device; const void* geom; float axis_ratio; };
+std::mutex g_frames_mu;
+std::vector<FrameNote> g_frames;
+void note_frame(const void* geom, float axis_ratio) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_frames_mu);
+    for (FrameNote& f : g_frames)
+        if (f.device == dev && f.geom == geom) { f.axis_ratio = axis_ratio; return; }
+    if (g_frames.size() >= 256) g_frames.erase(g_frames.begin());
+    g_frames.push_back({dev, geom, axis_ratio});
+}
+bool frame_axis_ratio(const void* geom, float* axis_ratio) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_frames_mu);
+    for (const FrameNote& f : g_frames)
+        if (f.device == dev && f.geom == geom) { *axis_ratio = f.axis_ratio; return true; }
+    return false;
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -195,7 +225,8 @@ const OptionDesc kOptions[] = {
     {"bwd_order", "F3DGS_BWD_ORDER", &Options::bwd_order, 1},
     {"bwd_m44", "F3DGS_BWD_M44", &Options::bwd_m44, 1},
     {"bwd_split16", "F3DGS_BWD_SPLIT16", &Options::bwd_split16, 1},
-    {"bwd_bf16", "F3DGS_BWD_BF16", &Options::bwd_bf16, 1},
+    {"bwd_bf16", "F3DGS_BWD_BF16", &Options::bwd_bf16, -1},
+    {"bwd_bf16_max_ratio", "F3DGS_BWD_BF16_MAX_RATIO", &Options::bwd_bf16_max_ratio, 16},
     {"fwd_wide", "F3DGS_FWD_WIDE", &Options::fwd_wide, 1},
     {"fwd_solo", "F3DGS_FWD_SOLO", &Options::fwd_solo, 1},
     {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},
@@ -277,7 +308,9 @@ CountReadback* count_readback(hipStream_t s) {
 
 extern "C" {
 
-int f3dgs_version(void) { return 30300; }   // 3.3.0 (major * 10000 + minor * 100 + patch): 3.1 seven untested shape knobs removed, f3dgs_option_name; 3.2 f3dgs_set_feature_grad_lowres; 3.3 option bwd_bf16, 16-byte alignment checked
+int f3dgs_version(void) { return 30400; }   // 3.4.0 (major * 10000 + minor * 100 + patch): 3.1 seven untested shape knobs removed, f3dgs_option_name; 3.2 f3dgs_set_feature_grad_lowres; 3.3 option bwd_bf16, 16-byte alignment checked; 3.4 bwd_bf16 = -1 (by the frame's conditioning), f3dgs_last_backward_contraction
+
+int f3dgs_last_backward_contraction(void) { return g_last_bwd_bf16.load(); }
 
 int f3dgs_set_option(const char* name, int value) {
     if (!name) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null option name");
@@ -424,6 +457,13 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     HIP_TRY(hipEventSynchronize(rb.done));
     // [0] instances in our lists, [1] the reference's bounding-rectangle count
     const uint32_t counts[2] = {rb.host[0], rb.host[1]};
+    // [2] the largest axis ratio of a visible Gaussian, float bits (the single-pass flavour of the binning does not produce it:
+    // "unknown" reads as ill-conditioned)
+    {
+        float ar = std::numeric_limits<float>::infinity();
+        if (!onesweep) memcpy(&ar, &rb.host[2], sizeof ar);
+        note_frame(geom_ptr, ar);
+    }
     const uint32_t N = counts[0];
     if (N >= (1u << 30) || counts[1] >= (1u << 31)) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^30 instances");
     if (num_rendered) *num_rendered = (int)counts[1];
@@ -537,10 +577,24 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     // at c4, 3.40 -> 4.07 at c5: its feature-row gathers queue behind 2 - 2.5 GB of writes); profiles/r05_notes.md.
     if (C > 0 && !g_feature_accumulate) HIP_TRY(hipMemsetAsync(dL_dsemantic_feature, 0, (size_t)P * C * sizeof(float), s));
     tm.mark("zero");
-    if (R > 0)
-        launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,
-                               dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, img.tile_len, img.tile_order,
-                               lowres.gx ? &lowres : nullptr, s);
+    // Contraction precision of the blend backward (option bwd_bf16: 1 two-term bf16, 0 exact fp32, -1 by the frame): the
+    // covariance chain behind the blend (backward.cu:144-341) amplifies an error of the blend-level sums by the square of a
+    // Gaussian's axis ratio; measured (profiles/r06_ratio_sweep.txt) the bf16 shape stays within a third of the gradient bound of
+    // the exact shape up to a ratio of 16 and leaves it from 32 on - where two runs of the EXACT shape differ by more than a
+    // bound as well.  So: bf16 while no visible Gaussian of the frame is longer than bwd_bf16_max_ratio (default 16) times its
+    // width, exact fp32 otherwise - and exact when the forward call's note is gone.
+    bool use_bf16 = options().bwd_bf16 > 0;
+    if (options().bwd_bf16 < 0) {
+        float ar = 0.f;
+        // (one part in a thousand of slack: the ratio is formed with one-instruction reciprocals; NaN: false)
+        use_bf16 = frame_axis_ratio(geom_buffer, &ar) && ar <= 1.001f * (float)options().bwd_bf16_max_ratio;
+    }
+    if (R > 0) {
+        const int ran = launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,
+                                               dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, img.tile_len, img.tile_order,
+                                               lowres.gx ? &lowres : nullptr, use_bf16, s);
+        g_last_bwd_bf16.store(ran);
+    }
     if ((rc = check_debug(debug, s, "render backward"))) return rc;
     tm.mark("render_bwd");
     if (g_feature_ready_fn) g_feature_ready_fn(g_feature_ready_ctx, stream);   // dL_dsemantic_feature is final on `s` here

@@ -518,6 +518,8 @@ PYBIND11_MODULE(_C, m) {
           "callable(row_begin, row_end, grads: dict) run inside rasterize_gaussians_backward after each of `chunks` row ranges of the "
           "per-Gaussian gradients is final on the stream; None removes it");
     m.def("set_option", [](const std::string& name, int value) { check_status(f3dgs_set_option(name.c_str(), value), "set_option"); });
+    m.def("last_backward_contraction", []() { return f3dgs_last_backward_contraction(); },
+          "1: the last blend backward of this process contracted on bf16 matrix instructions (two-term operands); 0: exact fp32; -1: none yet");
     m.def("get_option", [](const std::string& name) {
         int v = 0;
         check_status(f3dgs_get_option(name.c_str(), &v), "get_option");

@@ -68,23 +68,28 @@ __global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* __rest
 // stored to the device counters and straight into the host's pinned read-back words.
 template <int THREADS>
 __device__ __forceinline__ void run_totals_job(const TotalsJob& tj) {
-    __shared__ uint32_t shc[2][THREADS / 64];
-    uint32_t v = 0, u = 0;
-    for (int i = threadIdx.x; i < tj.n_partial; i += THREADS) { v += tj.partial[i]; u += tj.partial[tj.n_partial + i]; }
+    __shared__ uint32_t shc[3][THREADS / 64];
+    uint32_t v = 0, u = 0, ar = 0;
+    for (int i = threadIdx.x; i < tj.n_partial; i += THREADS) {
+        v += tj.partial[i]; u += tj.partial[tj.n_partial + i]; ar = max(ar, tj.partial[2 * tj.n_partial + i]);
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         v += (uint32_t)__shfl_xor((int)v, d, 64);
         u += (uint32_t)__shfl_xor((int)u, d, 64);
+        ar = max(ar, (uint32_t)__shfl_xor((int)ar, d, 64));
     }
-    if ((threadIdx.x & 63) == 0) { shc[0][threadIdx.x >> 6] = v; shc[1][threadIdx.x >> 6] = u; }
+    if ((threadIdx.x & 63) == 0) { shc[0][threadIdx.x >> 6] = v; shc[1][threadIdx.x >> 6] = u; shc[2][threadIdx.x >> 6] = ar; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t ref = 0, own = 0;
-        for (int k = 0; k < THREADS / 64; k++) { ref += shc[0][k]; own += shc[1][k]; }
-        tj.counters[0] = own; tj.counters[1] = ref;      // [0] entries of our lists, [1] the reference's count
+        uint32_t ref = 0, own = 0, arm = 0;
+        for (int k = 0; k < THREADS / 64; k++) { ref += shc[0][k]; own += shc[1][k]; arm = max(arm, shc[2][k]); }
+        // [0] entries of our lists, [1] the reference's count, [2] the largest axis ratio of a visible Gaussian (float bits)
+        tj.counters[0] = own; tj.counters[1] = ref; tj.counters[2] = arm;
         if (tj.host) {
             __hip_atomic_store(&tj.host[0], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&tj.host[1], ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&tj.host[2], arm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
         }
     }

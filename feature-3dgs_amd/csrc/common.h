@@ -71,7 +71,7 @@ struct GeomState {
     uint32_t* hist;           // RADIX_BINS * sort_blocks(P) + RADIX_BINS
     uint32_t* scan_tmp;       // scan_blocks(P) + 8      list entries of every chunk of SCAN_CHUNK Gaussians in depth order
     uint32_t* scan_sub;       // 64 x scan_blocks(P)     list entries of every run of 64 Gaussians in depth order
-    uint32_t* ref_partial;    // per preprocess workgroup: bounding-rectangle tile counts, then list-entry counts
+    uint32_t* ref_partial;    // per preprocess workgroup: bounding-rectangle tile counts, then list-entry counts, then the largest axis ratio (float bits)
     uint32_t* counters;       // 16 words: [0] = instances in the (culled) lists, [1] = reference num_rendered
     // -- control words of the single-pass sorts (lookback.h).  depth_hist is zeroed by preprocess_kernel (it is
     //    accumulated by the kernel after it); everything from lb_words on is zeroed by sort_prologue_kernel.
@@ -101,7 +101,7 @@ struct GeomState {
         g.hist = c.take<uint32_t>(DEPTH_RADIX_BINS * sort_blocks(P) + DEPTH_RADIX_BINS);
         g.scan_tmp = c.take<uint32_t>(scan_blocks(P) + 8);
         g.scan_sub = c.take<uint32_t>(64 * scan_blocks(P));
-        g.ref_partial = c.take<uint32_t>(2 * ((P + 255) / 256) + 2);
+        g.ref_partial = c.take<uint32_t>(3 * ((P + 255) / 256) + 3);
         g.counters = c.take<uint32_t>(16);
         g.depth_hist = c.take<uint32_t>(4 * 256);
         g.big_ctl = c.take<uint32_t>(4 + BIGQ_CAP);
@@ -177,7 +177,8 @@ struct Options {
     int bwd_order;       // blend backward: workgroups take the tiles longest walk first (default 1)
     int bwd_m44;         // pixel-lane blend backward: the colour / depth sums on 4 x 4 matrix blocks (default 1)
     int bwd_split16;     // pixel-lane blend backward, up to 16 channels: feature and moment blocks split over the waves by quadrants (default 1)
-    int bwd_bf16;        // pixel-lane blend backward: every contraction on bf16 matrix instructions, operands as two bf16 terms (default 1)
+    int bwd_bf16;        // pixel-lane blend backward: every contraction on bf16 matrix instructions, operands as two bf16 terms: 1 always, 0 never (exact fp32), -1 (default) while no visible Gaussian's axis ratio exceeds bwd_bf16_max_ratio
+    int bwd_bf16_max_ratio;   // (default 16)
     int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 0 (C > 4 with bwd_bf16 = 0); needs feature_mfma
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
     int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)
@@ -295,11 +296,13 @@ struct LowresGrad {
 };
 // `tile_len` / `tile_order`: the pixel-lane kernel takes its tiles longest walk first (order built here, one small launch)
 // `dL_dfeat` may be null when `lowres` carries the feature-map gradient (given both, the kernel adds them)
-void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
-                            const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
-                            const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
-                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
-                            hipStream_t s);
+// `bf16`: contractions of the pixel-lane kernel on bf16 matrix instructions with two-term operands (api.hip decides; see option
+// bwd_bf16).  Returns what ran: 1 the pixel-lane kernel in its bf16 shape, 0 anything exact (its fp32 shape, the instance-lane kernel).
+int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
+                           const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
+                           const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
+                           float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
+                           bool bf16, hipStream_t s);
 struct BwdArgs;
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s);     // render_bwd_pl.hip
 void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, hipStream_t s);

@@ -48,8 +48,8 @@ struct P1Pixel {
 // Sixteen entries rc[0..15] (list positions pos_hi, pos_hi - 1, ...) against this lane's pixel.  T, S: transmittance and
 // "colour behind" carried along the walk.  tiles + sofs: this lane's slot in row 0 of the quadrant's w-high plane.
 // Returns the rows (bit e = entry e) that blended at some pixel of the wave.
-// NOLDS (tools/ubench/blend_stream.hip only): the record of rc[0] - read once, made opaque per entry - stands in for every
-// record and the stores are folded into a register: the vector-pipe stream alone.
+// NOLDS (tools/ubench/blend_stream.hip only): four records read once per chunk stand in for all sixteen (one extra vector
+// instruction per entry moves the mean) and the stores are dropped: the vector-pipe stream alone.
 template <bool GEO, int SCHED, bool NOLDS = false>
 __device__ __forceinline__ uint32_t pl_phase1_bf16(const PlRec* rc, const P1Pixel& px, uint32_t pos_hi, float& T, float& S,
                                                    char* tiles, uint32_t sofs) {
@@ -67,30 +67,24 @@ __device__ __forceinline__ uint32_t pl_phase1_bf16(const PlRec* rc, const P1Pixe
     uint32_t h = 0, hl = 0, hh = 0, m = 0;
     (void)nSf; (void)dLa; (void)sv; (void)rs; (void)w_even; (void)hh;
 
-    float4 r_g = make_float4(0.f, 0.f, 0.f, 0.f), r_col = r_g;
-    float2 r_co = make_float2(0.f, 0.f);
     uint32_t sink = 0;
-    if constexpr (NOLDS) { r_g = rc[0].q0; r_co = *reinterpret_cast<const float2*>(&rc[0].q1); r_col = rc[0].q2; }
-    (void)r_g; (void)r_co; (void)r_col; (void)sink;
+    (void)sink;
+    if constexpr (NOLDS) {
+        // four records read once per chunk; an entry re-uses the record of entry e - 4 with its mean moved by one instruction
+        // (so that nothing of the earlier evaluation can be re-used)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { en[k].g = rc[k].q0; en[k].co = *reinterpret_cast<const float2*>(&rc[k].q1); en[k].col = rc[k].q2; }
+    }
     auto load_geo = [&](int e) {
         Ent& x = en[e & 3];
         if constexpr (NOLDS) {
-            x.g = r_g; x.co = r_co;
-            asm volatile("" : "+v"(x.g.x), "+v"(x.g.y), "+v"(x.g.z), "+v"(x.g.w), "+v"(x.co.x), "+v"(x.co.y));
+            x.g.x += 0.015625f;
         } else {
             x.g = rc[e].q0; x.co = *reinterpret_cast<const float2*>(&rc[e].q1);
         }
     };
     auto load_col = [&](int e) {
-        if constexpr (GEO) {
-            Ent& x = en[e & 3];
-            if constexpr (NOLDS) {
-                x.col = r_col;
-                asm volatile("" : "+v"(x.col.x), "+v"(x.col.y), "+v"(x.col.z), "+v"(x.col.w));
-            } else {
-                x.col = rc[e].q2;
-            }
-        }
+        if constexpr (GEO && !NOLDS) en[e & 3].col = rc[e].q2;
     };
     // stage B: exponent and exponential, colour dot product - nothing here depends on the walk
     auto stage_b = [&](int k, int e) {

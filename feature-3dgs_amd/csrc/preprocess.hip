@@ -276,7 +276,10 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     extern __shared__ __attribute__((aligned(16))) float sh_tile[];      // M3C: four wave-private tiles of 64 x PF_ROW floats
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // the digit histograms of the depth sort are accumulated by the NEXT kernel: zero them here (1024 words)
+    // the digit histograms of the depth sort are accumulated by the NEXT kernel: zero them here (1024 words), and with them the
+    // slot states of the emit kernel's big-splat queue - four workgroups of 256 threads clear exactly 4 x 256 words of each
+    // (launch_preprocess starts at least four): a stale state 2 would silently drop a splat's list entries
+    static_assert(BIGQ_CAP == 4 * 256, "slot states zeroed by workgroups 0..3 of this kernel, 256 words each");
     if (blockIdx.x < 4) {
         depth_hist[blockIdx.x * 256 + threadIdx.x] = 0;
         big_ctl[4 + blockIdx.x * 256 + threadIdx.x] = 0;         // the emit kernel's big-splat queue: slot states ...
@@ -296,6 +299,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     const float4 q_in = *rp;
     bool alive = false;
     float px = 0.f, py = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, rad = 0.f, depth = 0.f;
+    float axis_ratio = 0.f;       // of a visible Gaussian: the larger of its 3D scale ratio and its screen-space std-dev ratio
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (i < P) do {
         const V3 pv = xform3(vp.view, p);
@@ -329,6 +333,15 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         if ((x1 - x0) * (y1 - y0) == 0) break;
         depth = pv.z;
         alive = true;
+        // What the blend backward's contraction precision is chosen by (api.hip: option bwd_bf16 = -1): the covariance chain
+        // (cov2D -> cov3D -> scale / rotation, backward.cu:144-341) amplifies an error of the blend-level sums by the square of
+        // this ratio.  lambda_2 = det / lambda_1 (the product of the eigenvalues); NaN / inf (zero scales, det <= 0) read as
+        // "ill-conditioned" on the host.
+        axis_ratio = fmaxf(l1, l2) * __builtin_amdgcn_rsqf(det);
+        if (have_sr) {
+            const float s0 = fabsf(sc_in.x), s1 = fabsf(sc_in.y), s2 = fabsf(sc_in.z);
+            axis_ratio = fmaxf(axis_ratio, fmaxf(s0, fmaxf(s1, s2)) * __builtin_amdgcn_rcpf(fminf(s0, fminf(s1, s2))));
+        }
     } while (false);
 
     // ---- part 2 (M3C): the SH rows of the wave's surviving Gaussians -> the wave's LDS tile, in two HALVES (coefficients 0..7,
@@ -420,20 +433,24 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     // kernel of the depth sort adds the partials up (binning.hip: TotalsJob) and stores the totals into the host's
     // pinned words.  The same goes for the length of our own (culled) instance lists: both totals are known right
     // after this kernel, long before the host needs them (it waits for them while the depth sort runs).
-    __shared__ uint32_t wsum[2][4];
-    uint32_t v = bbox_tiles, u = out_tiles;
+    // Third partial: the largest axis ratio among the workgroup's visible Gaussians, as float bits (non-negative floats order
+    // like their bits; a NaN sorts above everything and reads as "ill-conditioned").
+    __shared__ uint32_t wsum[3][4];
+    uint32_t v = bbox_tiles, u = out_tiles, ar = alive ? __float_as_uint(axis_ratio) & 0x7FFFFFFFu : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         v += (uint32_t)__shfl_xor((int)v, d, 64);
         u += (uint32_t)__shfl_xor((int)u, d, 64);
+        ar = max(ar, (uint32_t)__shfl_xor((int)ar, d, 64));
     }
-    if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = v; wsum[1][threadIdx.x >> 6] = u; }
+    if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = v; wsum[1][threadIdx.x >> 6] = u; wsum[2][threadIdx.x >> 6] = ar; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int nbp = (P + 255) / 256;      // padding workgroups (tiny P) have nothing to report
         if ((int)blockIdx.x < nbp) {
             ref_partial[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
             ref_partial[nbp + blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+            ref_partial[2 * nbp + blockIdx.x] = max(max(wsum[2][0], wsum[2][1]), max(wsum[2][2], wsum[2][3]));
         }
     }
 }
@@ -1063,7 +1080,8 @@ void launch_mark_visible(int P, const float* means3D, const float* view_dev, uin
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const ViewParams& vp, int* radii, GeomState g, int cull, hipStream_t s) {
-    // at least 4 workgroups so that the depth_hist zero-fill above is complete even for tiny P
+    // at least 4 workgroups so that the zero-fill of depth_hist AND of the big-splat queue's slot states (big_ctl) at the top of the
+    // kernel is complete even for tiny P
     const int grid = max(4, (P + 255) / 256);
     if (M == 16 && shs && !colors_precomp)
         hipLaunchKernelGGL(preprocess_kernel<48>, dim3(grid), dim3(256), 4 * 64 * PF_ROW * sizeof(float), s, P, D, M, means3D, scales,

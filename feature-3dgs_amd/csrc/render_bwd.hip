@@ -683,11 +683,11 @@ void launch_one(const BwdArgs& a, hipStream_t s) {
 
 }  // namespace
 
-void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
-                            const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
-                            const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
-                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
-                            hipStream_t s) {
+int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
+                           const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
+                           const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
+                           float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
+                           bool bf16, hipStream_t s) {
     BwdArgs a;
     a.order = nullptr;
     a.glow = nullptr; a.gscale = nullptr; a.gHg = a.gWg = 0; a.gsy = a.gsx = 0.f;
@@ -729,7 +729,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     // (a low-resolution feature-map gradient is taken by the pixel-lane kernel only: the caller has checked feature_mfma)
     // (round 5, with the bf16 contractions - option bwd_bf16 - the pixel-lane kernel wins from the first channel on: c2-sized scenes,
     // instance-lane / pixel-lane: C = 0 0.445 / 0.491, 3 0.567 / 0.509, 4 0.566 / 0.510, 8 0.650 / 0.519)
-    if (low || ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > (opt.bwd_bf16 ? 0 : 4))) && opt.feature_mfma)) {
+    if (low || ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > (bf16 ? 0 : 4))) && opt.feature_mfma)) {
         if (opt.bwd_order && tile_len && tile_order) {
             launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, s);
             a.order = tile_order;
@@ -737,7 +737,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
         a.half = 0;
         a.m44 = opt.bwd_m44;
         a.split16 = opt.bwd_split16;
-        a.bf16 = opt.bwd_bf16;
+        a.bf16 = bf16 ? 1 : 0;
         launch_render_backward_pl(a, C, s);
 #ifdef F3DGS_DEV
         if (a.dev & 8) {
@@ -753,7 +753,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
             report.on = false;
         }
 #endif
-        return;
+        return a.bf16;
     }
     a.half = opt.bwd_half != 0;
     const bool mf = opt.feature_mfma != 0;
@@ -767,7 +767,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
     if (C == 0) {
         a.c0 = 0; a.nc = 0; a.write_base = 1;
         launch_one<0, false>(a, s);
-        return;
+        return 0;
     }
     // channel windows of up to 64; the geometric sums ride along with the first window only
     for (int c0 = 0; c0 < C; c0 += 64) {
@@ -777,6 +777,7 @@ void launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, co
         else if (a.nc <= 32) { if (mf) launch_one<32, true>(a, s); else launch_one<32, false>(a, s); }
         else { if (mf) launch_one<64, true>(a, s); else launch_one<64, false>(a, s); }
     }
+    return 0;
 }
 
 }  // namespace f3dgs

@@ -19,6 +19,7 @@
 #include <cstddef>
 
 #include "render_common.h"
+#include "fwd_group.h"
 
 namespace f3dgs {
 
@@ -258,17 +259,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
 // (same rounding as an fmaf chain) and run concurrently with the VALU alpha evaluation.  Instances are taken
 // two at a time (K = 2): A[i][k] = w of pixel i for instance j+k, built from the two per-lane weights with
 // one v_permlane32_swap; B[k][n] = feature n of instance j+k, one ds_read_b32 per lane.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// One staged (compacted) list entry: a single LDS address per instance, three broadcast reads.
-struct FwdEntry {
-    float4 geo;        // mean_x, mean_y, conic_a, conic_b
-    float4 cd;         // r, g, b, depth
-    float co_c, co_o;  // conic_c, opacity
-    uint32_t pos;      // 1-based list position: n_contrib bookkeeping
-    uint32_t id;       // Gaussian index (feature row)
-};
-static_assert(sizeof(FwdEntry) == 48, "FwdEntry layout");
+// (FwdEntry - one staged, compacted list entry - and the group step of the blend loop live in fwd_group.h)
 
 template <int CH, int CHK>
 struct FwdChunkMF {
@@ -325,15 +316,14 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     const int iwx0 = tx * TILE + (q0_ & 1) * 8, iwx1 = tx * TILE + (q1_ & 1) * 8 + 7;
     const int iwy0 = ty * TILE + (q0_ >> 1) * 8, iwy1 = ty * TILE + (q1_ >> 1) * 8 + 7;
     const int lx = lane & 7, ly = lane >> 3;
-    float pxf[PPL], pyf[PPL];
     int pix_id[PPL];
     // T carries the pixel's "finished" flag in its sign bit (T > 0 while the pixel is still blending; -T_final
     // afterwards): a finished pixel then fails the test_T >= T_MIN check by itself and no per-lane boolean has
     // to live in a register.
     bool inside[PPL];
-    float T[PPL], col[PPL][3], dep[PPL];
-    uint32_t last[PPL];
-    f32x16 acc[PPL][2][NB];
+    FwdPixels<CH, PPL> px;
+    auto& pxf = px.pxf; auto& pyf = px.pyf; auto& T = px.T; auto& col = px.col; auto& dep = px.dep; auto& last = px.last;
+    auto& acc = px.acc;
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const int q = wave * PPL + p;
@@ -471,102 +461,8 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
         }
         __builtin_amdgcn_wave_barrier();
 
-        for (int j = 0; j < cnt; j += GI) {
-            float4 g0[GI], cdv[GI];
-            float2 g1[GI];
-            uint32_t pos_e[GI];
-            float Bv[NP][NB];
-#pragma unroll
-            for (int e = 0; e < GI; e++) {
-                const int je = j + e;
-                g0[e] = ck.ent[je].geo;
-                if constexpr (BASE && !CDB) cdv[e] = ck.ent[je].cd;
-                const float4 tail = *reinterpret_cast<const float4*>(&ck.ent[je].co_c);
-                g1[e] = make_float2(tail.x, tail.y);
-                pos_e[e] = __float_as_uint(tail.z);
-            }
-#pragma unroll
-            for (int k = 0; k < NP; k++) {
-                // B rows: instance j+2k for lanes 0-31, j+2k+1 for lanes 32-63 (a missing instance is a null entry: w = 0
-                // against a row of zeros)
-                const int e0 = 2 * k;
-                const int rsel = j + e0 + (lane >> 5);
-                if constexpr (CH == 16) {
-                    Bv[k][0] = reinterpret_cast<const float*>(&ck)[rsel * b_stride + b_off];
-                } else {
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) Bv[k][nb] = ck.feat[rsel * CH + (lane & 31) + 32 * nb];
-                }
-            }
-            // a quadrant whose 64 pixels are all saturated is skipped as a whole (wave-uniform branch)
-            bool slot_live[PPL];
-#pragma unroll
-            for (int p = 0; p < PPL; p++) slot_live[p] = BASE ? __any(T[p] > 0.0f) : true;
-            float w[GI][PPL];
-            unsigned long long blend_mask = 0ull;       // (a wave-uniform mask, not a per-lane flag: the flag would cross the
-                                                        //  slot_live branch as a 0/1 register and be compared again)
-#pragma unroll
-            for (int p = 0; p < PPL; p++) {
-                if (!slot_live[p]) {
-#pragma unroll
-                    for (int e = 0; e < GI; e++) w[e][p] = 0.0f;
-                    continue;
-                }
-                float araw[GI];
-                bool valid[GI];
-#pragma unroll
-                for (int e = 0; e < GI; e++) {
-                    const float dx = g0[e].x - pxf[p], dy = g0[e].y - pyf[p];
-                    const float power = splat_power2(dx, dy, g0[e].z, g0[e].w, g1[e].x);
-                    araw[e] = fminf(ALPHA_MAX, g1[e].y * __builtin_amdgcn_exp2f(power));
-                    valid[e] = !(power > 0.0f) && !(araw[e] < ALPHA_MIN);
-                    if constexpr (!BASE) valid[e] = valid[e] && pos_e[e] <= last[p];
-                }
-#pragma unroll
-                for (int e = 0; e < GI; e++) {
-                    const float test_T = T[p] * (1.0f - araw[e]);      // negative once the pixel is finished
-                    const bool below = BASE && test_T < T_MIN;
-                    const bool ok = valid[e] & !below;
-                    const bool term = valid[e] & below;                 // (re-)marks finished pixels
-                    const float wv = ok ? araw[e] * T[p] : 0.0f;
-                    w[e][p] = wv;
-                    if constexpr (BASE) T[p] = ok ? test_T : (term ? -fabsf(T[p]) : T[p]);
-                    else T[p] = ok ? test_T : T[p];
-                    if constexpr (BASE) {
-                        last[p] = ok ? pos_e[e] : last[p];
-                        if constexpr (!CDB) {
-                            col[p][0] = fmaf(cdv[e].x, wv, col[p][0]);
-                            col[p][1] = fmaf(cdv[e].y, wv, col[p][1]);
-                            col[p][2] = fmaf(cdv[e].z, wv, col[p][2]);
-                            dep[p] = fmaf(cdv[e].w, wv, dep[p]);
-                        }
-                    }
-                }
-                // any weight of the pixel non-zero?  The weights are >= 0: one compare per entry pair (w0 != -w1), and a compare is
-                // what the ballot wants to see - from a combination of lane masks it goes through a 0/1 register and a second compare
-                bool nz = w[0][p] != -w[1][p];
-#pragma unroll
-                for (int e = 2; e < GI; e += 2) nz = nz || (w[e][p] != -w[e + 1][p]);
-                blend_mask |= __builtin_amdgcn_ballot_w64(nz);
-            }
-            if (blend_mask != 0ull && !FW_DEV_SKIP(256)) {
-#pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    const int e0 = 2 * k;
-#pragma unroll
-                    for (int p = 0; p < PPL; p++) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w[e0][p]),
-                                                                         __float_as_int(w[e0 + 1][p]), false, false);
-                        const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
-#pragma unroll
-                        for (int nb = 0; nb < NB; nb++) {
-                            acc[p][0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv[k][nb], acc[p][0][nb], 0, 0, 0);
-                            acc[p][1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv[k][nb], acc[p][1][nb], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
+        for (int j = 0; j < cnt; j += GI)
+            fwd_blend_group<CH, PPL, GI, BASE>(ck.ent, ck.feat, reinterpret_cast<const float*>(&ck), j, lane, b_stride, b_off, FW_DEV_SKIP(256), px);
     }
 
     const size_t HW = (size_t)a.W * a.H;

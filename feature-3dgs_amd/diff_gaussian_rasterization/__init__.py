@@ -33,6 +33,7 @@ except ImportError as exc:  # fail loudly — a silent fallback would void every
 
 _backward_done_hook = None
 _rows_done_hook = None
+_feature_ready_hook = None      # what set_feature_grad_hook installed (kept so that a bypassing backward call can put it back)
 
 
 def set_feature_grad_hook(on_ready, on_done=None) -> None:
@@ -40,8 +41,9 @@ def set_feature_grad_hook(on_ready, on_done=None) -> None:
     pass as soon as that tensor is final on the current stream (the per-Gaussian stage still follows);
     `on_done()` runs when the extension call has returned, before autograd sees the gradients.  `None` removes
     both.  See feature-3dgs_amd/dp.py: FeatureGradOverlap."""
-    global _backward_done_hook
+    global _backward_done_hook, _feature_ready_hook
     _C.set_feature_grad_hook(on_ready)
+    _feature_ready_hook = on_ready
     _backward_done_hook = on_done if on_ready is not None else None
 
 
@@ -57,9 +59,18 @@ def set_grad_rows_hook(on_rows, chunks: int = 4, on_done=None) -> None:
 
 
 _accum_leaf = None       # (data_ptr, numel) of the leaf whose .grad the accumulator is, or None: not checked
+_accum_buffer = None     # the buffer itself (a bypassing backward call restores it)
+_accum_strict = True     # a backward call whose feature input is not the leaf: raise (True) or take the autograd path (False)
+_accum_bypassed = 0      # backward calls that took the autograd path since the accumulator was set
 
 
-def set_feature_grad_accumulator(buffer: Optional[torch.Tensor], leaf: Optional[torch.Tensor] = None) -> None:
+def accumulator_bypassed() -> int:
+    """Backward calls since the last set_feature_grad_accumulator(..., strict=False) whose `semantic_feature` input was not
+    the accumulator's leaf and which therefore returned their feature gradient to autograd the normal way."""
+    return _accum_bypassed
+
+
+def set_feature_grad_accumulator(buffer: Optional[torch.Tensor], leaf: Optional[torch.Tensor] = None, strict: bool = True) -> None:
     """Several views per optimiser step (not in the reference): while `buffer` - a contiguous float32 tensor with the P x C
     elements of `semantic_feature`, normally the leaf's zero-initialised `.grad` - is set, every backward call ADDS its
     feature gradient into it (no per-view gradient tensor, zero-fill or add) and reports no gradient for `semantic_feature`
@@ -68,9 +79,12 @@ def set_feature_grad_accumulator(buffer: Optional[torch.Tensor], leaf: Optional[
     The op's gradient goes straight into `buffer`, past the autograd chain: that is only right when the op's
     `semantic_feature` input IS the tensor `buffer` is the gradient of.  Pass that tensor as `leaf` and every backward call
     checks it (same storage, and an autograd leaf at forward time); a transformed, masked or copied feature tensor then
-    raises instead of silently receiving nothing."""
-    global _accum_leaf
+    raises instead of silently receiving nothing - or, with `strict=False` (what dp_step_views uses when it was not TOLD to
+    accumulate), that call leaves the accumulator and the in-backward feature hook alone and hands its gradient to autograd,
+    which carries it through the chain into the same `leaf.grad` (`accumulator_bypassed()` counts such calls)."""
+    global _accum_leaf, _accum_buffer, _accum_strict, _accum_bypassed
     _accum_leaf = None if (buffer is None or leaf is None) else (leaf.data_ptr(), leaf.numel())
+    _accum_buffer, _accum_strict, _accum_bypassed = buffer, bool(strict), 0
     _C.set_feature_grad_accumulator(buffer)
 
 
@@ -176,11 +190,21 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color,
                 grad_out_feature, grad_depth, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
                 binningBuffer, imgBuffer, rs.debug)
+        bypass = False
         if _accum_leaf is not None and semantic_feature.numel() != 0 and (
                 ctx.feat_src[:2] != _accum_leaf or not ctx.feat_src[2]):
-            raise RuntimeError("set_feature_grad_accumulator(buffer, leaf): this op's semantic_feature input is not that leaf "
-                               "(a transformed, masked or copied tensor?) - adding the op's gradient into leaf.grad would skip "
-                               "the autograd chain between them; use accumulate=False / remove the accumulator")
+            if _accum_strict:
+                raise RuntimeError("set_feature_grad_accumulator(buffer, leaf): this op's semantic_feature input is not that leaf "
+                                   "(a transformed, masked or copied tensor?) - adding the op's gradient into leaf.grad would skip "
+                                   "the autograd chain between them; use accumulate=False / remove the accumulator")
+            # strict=False: this call goes the autograd way - no accumulator, and no in-backward reduction of what would only be
+            # this view's gradient
+            global _accum_bypassed
+            bypass = True
+            _accum_bypassed += 1
+            _C.set_feature_grad_accumulator(None)
+            if _feature_ready_hook is not None:
+                _C.set_feature_grad_hook(None)
         offer = _lowres_offers.pop(ctx.call_serial, None)
         if offer is not None:       # this call's feature-map gradient (or part of it) waits at the loss's resolution
             _C.set_feature_grad_lowres(offer[0], offer[1])
@@ -191,6 +215,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         finally:
             if offer is not None:
                 _C.set_feature_grad_lowres(None)
+            if bypass:
+                _C.set_feature_grad_accumulator(_accum_buffer)
+                if _feature_ready_hook is not None:
+                    _C.set_feature_grad_hook(_feature_ready_hook)
         if grad_semantic_feature.numel() == 0 and semantic_feature.numel() != 0:
             grad_semantic_feature = None        # accumulated into the buffer of set_feature_grad_accumulator
         if _backward_done_hook is not None:
@@ -243,4 +271,4 @@ class GaussianRasterizer(nn.Module):
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "cpu_deep_copy_tuple",
-           "set_feature_grad_hook", "set_grad_rows_hook", "set_feature_grad_accumulator"]
+           "set_feature_grad_hook", "set_grad_rows_hook", "set_feature_grad_accumulator", "accumulator_bypassed"]

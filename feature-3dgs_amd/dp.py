@@ -424,6 +424,19 @@ class ShardedOptimizer:
         self._pending = False
 
     @torch.no_grad()
+    def refresh_from_params(self, names: Optional[Iterable[str]] = None) -> None:
+        """The shards are CLONES of my rows: an in-place edit of the full parameters from outside the optimizer - the reference's
+        `reset_opacity` / `replace_tensor_to_optimizer` (scene/gaussian_model.py:185-190, 284-297), a manual clamp - would be
+        overwritten by the next `gather()`.  Call this after such an edit (on every rank): my rows of `params[name]` are copied
+        into the shards again.  The optimizer state of the edited tensors is the caller's business, as it is in the reference
+        (which zeroes the moments of a replaced tensor): `self.optimizer.state[self.shards[name]]`.  Row counts must not have
+        changed - densification needs a new ShardedOptimizer (`full_state` / `load_full_state`)."""
+        for k in (list(names) if names is not None else list(self.shards)):
+            if self.params[k].shape[0] != self.P:
+                raise ValueError(f"parameter '{k}' now has {self.params[k].shape[0]} rows, the sharding was built for {self.P}")
+            self.shards[k].data.copy_(self.params[k].detach()[self.lo:self.hi])
+
+    @torch.no_grad()
     def full_state(self) -> Dict[str, Dict[str, torch.Tensor]]:
         """name -> {state key -> full (P, ...) tensor} (per-row state tensors gathered from all ranks; scalars such as Adam's
         `step` as they are): what an unsharded optimizer would hold, e.g. for the reference's densification code."""
@@ -431,8 +444,11 @@ class ShardedOptimizer:
         for k, p in self.shards.items():
             st = self.optimizer.state.get(p, {})
             full = {}
-            for name, val in st.items():
-                if isinstance(val, torch.Tensor) and val.dim() >= 1 and val.shape[0] == p.shape[0]:
+            # per-row state is what has the SHARD's shape (Adam: exp_avg, exp_avg_sq; `step` is a scalar); keys in sorted order:
+            # every gather below is a collective and all ranks must issue the same sequence
+            for name in sorted(st):
+                val = st[name]
+                if isinstance(val, torch.Tensor) and val.dim() >= 1 and tuple(val.shape) == tuple(p.shape):
                     dst = torch.zeros((self.P,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
                     all_gather_params({"x": val}, {"x": dst}, group=self.group) if self.world > 1 else dst[self.lo:self.hi].copy_(val)
                     full[name] = dst
@@ -449,7 +465,7 @@ class ShardedOptimizer:
                 continue
             st = self.optimizer.state[p]
             for name, val in state[k].items():
-                if isinstance(val, torch.Tensor) and val.dim() >= 1 and val.shape[0] == self.P:
+                if isinstance(val, torch.Tensor) and val.dim() >= 1 and tuple(val.shape) == (self.P,) + tuple(p.shape[1:]):
                     st[name] = val[self.lo:self.hi].clone()
                 else:
                     st[name] = val.clone() if isinstance(val, torch.Tensor) else val
@@ -581,7 +597,8 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
     on_gpu = dev.type == "cuda"
     feat = leaves.get(feature_key)
     have_feat = feat is not None and feat.numel() > 0
-    if accumulate is None:
+    auto = accumulate is None
+    if auto:
         accumulate = on_gpu and have_feat and V > 0
     dgr = None
     if accumulate or (overlap and on_gpu):
@@ -592,16 +609,26 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
         feat.grad = torch.zeros_like(feat)
         # (`leaf=feat`: every backward call checks that the op's feature input IS this leaf - a model that feeds the op a
         # transformed / masked / copied feature tensor gets an error instead of a gradient that skipped its autograd chain)
-        dgr.set_feature_grad_accumulator(feat.grad, feat)
+        # `accumulate=None` (not asked for, switched on because it is usually right): a backward call whose feature input turns
+        # out NOT to be the leaf takes the autograd path instead of raising (strict=False) - autograd then adds into the same
+        # zero-initialised feat.grad through the model's own chain
+        dgr.set_feature_grad_accumulator(feat.grad, feat, strict=not auto)
     active = _active(group)
     ov = None
     # The leaves were created on the caller's stream and their gradients arrive from the side streams below: intended (the
     # backward passes are ordered among themselves with events, and the caller's stream waits for the last of them) - the
     # warning about it is silenced for the duration of this step only.
+    # (process-wide switch: its previous state is read where torch exposes it and put back afterwards; another thread that
+    # runs backward passes meanwhile sees the warning silenced for that long)
     quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    warn_was = getattr(torch._C, "_warn_on_accumulate_grad_stream_mismatch", None)
+    warn_was = bool(warn_was()) if callable(warn_was) else True
     pipelined = on_gpu and V > 1 and n_streams >= 2
     if not pipelined:
         quiet = None
+    # the in-backward all-reduce of the LAST view's feature gradient is the step's exchange only if that tensor is the step's
+    # sum: one view per rank, or the running sum of the accumulator
+    use_ov = overlap and active and have_feat and (accumulate or V == 1)
     try:
         if quiet is not None:
             quiet(False)
@@ -619,7 +646,7 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
                 with torch.cuda.stream(st):
                     if prev_done is not None:
                         st.wait_event(prev_done)         # backward passes add into the same gradients: one after the other
-                    if last and overlap and active and have_feat and dgr is not None:
+                    if last and use_ov and dgr is not None:
                         ov = FeatureGradOverlap(group)
                         with ov:
                             backward(handle)
@@ -635,7 +662,7 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
         else:
             for i, vid in enumerate(view_ids):
                 handle = forward(vid)
-                if i == V - 1 and overlap and active and have_feat and on_gpu and dgr is not None:
+                if i == V - 1 and use_ov and on_gpu and dgr is not None:
                     ov = FeatureGradOverlap(group)
                     with ov:
                         backward(handle)
@@ -643,7 +670,7 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
                     backward(handle)
     finally:
         if quiet is not None:
-            quiet(True)
+            quiet(warn_was)
         if accumulate:
             dgr.set_feature_grad_accumulator(None)
     # the SAME key list on every rank (see dp_step)

@@ -88,10 +88,16 @@ const char* f3dgs_last_error(void);
  *   "bwd_half"       instance-lane blend backward: 1 (default) chunks of 32 instances against two pixel halves,
  *                    0 chunks of 64
  *   "bwd_order"      blend backward: 1 (default) workgroups take the tiles longest walk first
- *   "bwd_bf16"       pixel-lane blend backward: 1 (default) every per-Gaussian sum contracts on bf16 matrix instructions
+ *   "bwd_bf16"       pixel-lane blend backward: 1 every per-Gaussian sum contracts on bf16 matrix instructions
  *                    (v_mfma_f32_16x16x32_bf16, fp32 accumulation) with each fp32 operand split into two bf16 terms -
  *                    a relative error of a few 1e-6 per product against the 1e-3 tolerance of the gradients; 0: exact-fp32
- *                    matrix instructions (16x slower per multiply-add, and they block the vector pipe of their SIMD)
+ *                    matrix instructions (16x slower per multiply-add, and they block the vector pipe of their SIMD);
+ *                    -1 (default): by the frame - bf16 while no visible Gaussian is longer than "bwd_bf16_max_ratio" times
+ *                    its width (3D scales and screen-space footprint; f3dgs_forward notes the largest ratio per geometry
+ *                    buffer, f3dgs_backward looks it up), exact fp32 otherwise and when the note is gone: the covariance
+ *                    chain behind the blend amplifies an error of the blend-level sums by the square of that ratio
+ *                    (measured: within a third of the gradient bound up to 16, outside it from 32 on)
+ *   "bwd_bf16_max_ratio"  (default 16) the axis ratio up to which bwd_bf16 = -1 takes the bf16 contraction
  *   "bwd_m44"        fp32 shape of the pixel-lane blend backward (bwd_bf16 = 0): 1 (default) the colour / depth sums contract on 4 x 4 matrix blocks
  *                    (v_mfma_f32_4x4x1_16B_f32) instead of a 16-column block of which four are used
  *   "bwd_split16"    fp32 shape of the pixel-lane blend backward (bwd_bf16 = 0) with up to 16 feature channels, and its later channel windows of up to 32: 1 (default)
@@ -103,6 +109,11 @@ const char* f3dgs_last_error(void);
  */
 int f3dgs_set_option(const char* name, int value);
 int f3dgs_get_option(const char* name, int* value /* host pointer, out */);
+
+/* Which contraction the last f3dgs_backward of this PROCESS (any thread: PyTorch runs the backward pass on an autograd thread)
+ * ran its blend stage with: 1 the pixel-lane kernel in its two-term bf16 shape, 0 an exact-fp32 shape (pixel-lane fp32 or the
+ * instance-lane kernel), -1 no backward call yet.  A diagnostic for tests and benchmarks. */
+int f3dgs_last_backward_contraction(void);
 /* Enumeration: the name of option `index` (0, 1, ...), NULL past the end. */
 const char* f3dgs_option_name(int index);
 
@@ -344,6 +355,19 @@ size_t f3dgs_knn_scratch_bytes(int P);
 int f3dgs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* scratch, void* stream /* hipStream_t */);
 
 /*
+ * ---- Side channels of f3dgs_backward: threading contract -----------------------------------------------------------
+ * The four setters below and f3dgs_set_feature_grad_lowres change how the f3dgs_backward calls OF THE CALLING HOST THREAD
+ * behave.  All five are thread-local: they are invisible to, and unaffected by, any other thread.
+ *   - the two callbacks and the accumulate switch are STICKY: they stay armed for every later call of the thread until reset
+ *     (NULL / 0).  A caller arms them around exactly the calls it means (dp.py: a `with` block per backward pass);
+ *   - f3dgs_set_feature_grad_lowres is ONE-SHOT: it is consumed - and cleared - by the next f3dgs_backward of the thread,
+ *     whether that call succeeds or fails.
+ * A second trainer in the same process therefore runs on its OWN thread (one thread per device is the supported shape:
+ * the instance-count read-back words are kept per (thread, device, stream) as well) and arms its own channels there;
+ * nothing needs a lock.  Two trainers that share a thread - interleaving their backward calls on it - must re-arm or
+ * clear the channels between calls themselves: the library cannot tell the calls apart.  The process-wide OPTIONS
+ * (f3dgs_set_option) are the only state shared between threads; they are read once at the top of each call.
+ *
  * Optional notification inside f3dgs_backward (no counterpart in the reference): `fn(ctx, stream)` is called on
  * the calling host thread right after the blend backward has been ENQUEUED on `stream`, i.e. at the point of
  * the stream from which dL_dsemantic_feature is final while the per-Gaussian stage still follows.  A

@@ -367,3 +367,36 @@ def test_sharded_optimizer_world_size_one():
         sh.step({k: g[k].clone() for k in KEYS})
     for k in KEYS:
         assert torch.equal(pa[k], pb[k]), k
+
+
+def test_sharded_optimizer_refresh_from_params_keeps_an_outside_edit():
+    """the shards are clones - an in-place edit of the full parameters from outside the optimizer (the reference's
+    reset_opacity, scene/gaussian_model.py:185-190) is overwritten by the next gather unless `refresh_from_params` carries it
+    into the shards.  One process (the world-size-2 path is test_sharded_optimizer_equals_the_all_reduce_path)."""
+    import dp
+    torch.manual_seed(0)
+    P = 37
+    params = {"opacity": torch.randn(P, 1), "xyz": torch.randn(P, 3)}
+    ref = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    mk = lambda t: torch.optim.Adam([{"params": [t[k]], "lr": 1e-2} for k in sorted(t)], lr=0.0, eps=1e-15)
+    sh = dp.ShardedOptimizer(params, mk)
+    opt = mk(ref)
+    for it in range(3):
+        grads = {k: torch.randn_like(v) for k, v in params.items()}
+        for k in ref:
+            ref[k].grad = grads[k].clone()
+        opt.step()
+        sh.step(grads)
+        if it == 0:       # the outside edit, on both sides
+            with torch.no_grad():
+                ref["opacity"].clamp_(max=0.01)
+                params["opacity"].clamp_(max=0.01)
+            sh.refresh_from_params(["opacity"])
+    for k in params:
+        assert torch.equal(params[k], ref[k].detach()), k
+    # without the refresh the edit is lost at the next gather
+    sh2 = dp.ShardedOptimizer({k: v.clone() for k, v in params.items()}, mk)
+    with torch.no_grad():
+        sh2.params["opacity"].fill_(7.0)
+    sh2.step({k: torch.zeros_like(v) for k, v in params.items()})
+    assert float(sh2.params["opacity"].max()) < 7.0

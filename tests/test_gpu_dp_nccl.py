@@ -247,6 +247,14 @@ def test_in_place_accumulation_refuses_a_transformed_feature_input():
     with pytest.raises(RuntimeError, match="not that leaf"):
         dp.dp_step_views(forward, backward, leaves, [0, 1], accumulate=True)
     torch.cuda.synchronize()
+    # not ASKED to accumulate (the default of dp_train_step): the step notices at the first backward call that the op was fed
+    # something else than the leaf and lets autograd carry every view's gradient through the model's chain
+    grads = dp.dp_step_views(forward, backward, leaves, [0, 1], accumulate=None)
+    torch.cuda.synchronize()
+    assert dgr.accumulator_bypassed() == 0            # (reset when the step released the accumulator)
+    want2 = _want_sum([0, 1], dev)["semantic_feature"]
+    err = np.abs(grads["semantic_feature"].cpu().numpy() - 2.0 * want2).max()
+    assert err <= 1e-4 * np.abs(want2).max() * 2.0, err
     # opt out: the gradient takes the autograd chain (d(2 f) = 2) and equals twice the direct one
     grads = dp.dp_step_views(forward, backward, leaves, [0, 1], accumulate=False)
     torch.cuda.synchronize()

@@ -174,7 +174,25 @@ LEAF_OF = dict(CHAIN_GRADS, dL_dmeans2D="means2D", dL_dopacity="opacities", dL_d
                dL_dcolors="colors_precomp", dL_dcov3D="cov3D_precomp")
 
 
-def _adjudicate_gradients(scene, ref_side, over, gst, g_ref, g_prod, pc, pv, max_gaussians=64):
+# The conditioning allowance of adjudicate.gradient_verdict applies to the covariance chain only (cov2D -> cov3D -> scale /
+# rotation, backward.cu:144-341): these are the tensors it may excuse, and only on the harsh inputs.
+KAPPA_GRADS = {"dL_dscales", "dL_drotations", "dL_dcov3D"}
+KAPPA_CAP = 1e5           # (largest / smallest scale)^2 beyond 1 : 316 earns nothing more: 6 bounds at most
+
+
+def _kappa(scene, i, k, pv, harsh):
+    """Condition number the verdict may use for tensor k of Gaussian i: 1 (no allowance) for every blend-level tensor, for
+    BASELINE-shaped inputs, for precomputed covariances and for a Gaussian with a zero (or denormal) scale axis."""
+    if not harsh or pv or k not in KAPPA_GRADS:
+        return 1.0
+    sc_i = scene["scales"][i].double().abs()
+    lo = float(sc_i.min())
+    if not lo > 1e-30:
+        return 1.0
+    return min(float(sc_i.max()) / lo, KAPPA_CAP ** 0.5) ** 2
+
+
+def _adjudicate_gradients(scene, ref_side, over, gst, g_ref, g_prod, pc, pv, max_gaussians=64, harsh=False):
     """The north-star bar on every gradient element - |prod - ref| <= 1e-3 |ref| + 1e-5 max|ref| - with nothing added; every
     Gaussian that holds an element ABOVE it goes to the fp64 adjudicator (tests/adjudicate.py), as the pixels above a bar do:
     the product must be inside the bar of the exact value or no further outside it than the reference is.  (Needle-shaped
@@ -189,6 +207,9 @@ def _adjudicate_gradients(scene, ref_side, over, gst, g_ref, g_prod, pc, pv, max
     for k, (mx, worst, mx_self, worst_self) in gst.items():
         if worst <= 1.0 and mx <= 1e-3:
             continue
+        # inputs of the BASELINE family hold the bar as it stands - no adjudication, no allowance
+        assert harsh, (f"{k}: worst element {worst:.2f}x its bound (max relative {mx:.2e}) against the strict reference build on an input "
+                       f"of the synthetic family; reference run-to-run: {worst_self:.2f}x")
         a, b = g_ref[k].double(), g_prod[k].double()
         scale = float(a.abs().max()) + 1e-30
         ratio = ((b - a).abs() / (1e-3 * a.abs() + 1e-5 * scale)).reshape(P, -1).amax(dim=1)
@@ -222,8 +243,7 @@ def _adjudicate_gradients(scene, ref_side, over, gst, g_ref, g_prod, pc, pv, max
             p_ = g_prod[k][i].reshape(-1).double().cpu().numpy()
             if k == "dL_dmeans2D":        # (the op's third column is always zero)
                 tp, tr = np.concatenate([tp[:2], [0.0]])[:len(p_)], np.concatenate([tr[:2], [0.0]])[:len(p_)]
-            sc_i = scene["scales"][i].double().abs()
-            kappa = 1.0 if pv else float((sc_i.max() / sc_i.min().clamp_min(1e-30)).clamp(max=1e6)) ** 2
+            kappa = _kappa(scene, int(i), k, pv, harsh)
             ok, e_p, e_r = adj.gradient_verdict(tp, p_, tr, r_, float(g_ref[k].abs().max()), kappa)
             assert ok, (f"gaussian {i} {k}: product {e_p:.2f} bounds from the fp64 value, reference {e_r:.2f} ({mode}); "
                         f"scales {scene['scales'][i].tolist()}")
@@ -243,7 +263,7 @@ def _grad_names(pc, pv, same_width):
 
 
 def _compare(scene, C_ref, pc=False, pv=False, check_state=True, self_noise=True, return_grads=False, against_default=True,
-             max_adjudicated=64):
+             max_adjudicated=64, harsh=False):
     """The three-way comparison of the module docstring; returns a dict of measured numbers (also asserted)."""
     W, H, P, C = scene["image_width"], scene["image_height"], scene["P"], scene["C"]
     npix = W * H
@@ -265,7 +285,7 @@ def _compare(scene, C_ref, pc=False, pv=False, check_state=True, self_noise=True
     assert st["n_contrib_equal_off_flips"]
     st["adjudication"] = _adjudicate(strict, prod, over, pc, pv, same)       # every pixel above a bar, flip or not
     gst, g_ref, g_prod = _backward_stats(strict, prod, over, names, self_noise)
-    st["gradient_adjudication"] = _adjudicate_gradients(scene, strict, over, gst, g_ref, g_prod, pc, pv, max_adjudicated)
+    st["gradient_adjudication"] = _adjudicate_gradients(scene, strict, over, gst, g_ref, g_prod, pc, pv, max_adjudicated, harsh)
     st["grads"] = gst
     stats["vs_strict"] = st
     if not return_grads:
@@ -387,11 +407,110 @@ def _build(case):
 def test_forward_backward_vs_reference(case, record_property):
     scene = _build(case)
     st = _compare(scene, case.get("Cref", case["C"]), case.get("pc", False), case.get("pv", False), self_noise=case.get("noise", True),
-                  against_default=case.get("dflt", True), max_adjudicated=case.get("adjud", 64))
+                  against_default=case.get("dflt", True), max_adjudicated=case.get("adjud", 64), harsh="harsh" in case)
     torch.cuda.empty_cache()
     for k, v in st.items():
         record_property(k, str(v))
     print(case["id"], st)
+
+
+NEEDLE_CASES = [c for c in CASES if c.get("harsh") == "heavy_tail"]
+
+
+def _needle_errors(scene, case, strict, g_ref, over):
+    """One product run on a needle scene: per tensor of the covariance chain and per blend-level tensor, the worst error of the
+    PRODUCT in units of the north-star bound against the fp64 gradient (full fp64 backward over the tiles of every Gaussian
+    above the bound, as the main test adjudicates them) - and the reference's on the same Gaussians."""
+    P, C = scene["P"], scene["C"]
+    names = _grad_names(False, False, True)
+    prod = _Side("prod", scene, C, False, False)
+    keep = torch.from_numpy((~over).reshape(1, scene["image_height"], scene["image_width"])).to(DEV)
+    g_prod = prod.backward(keep)
+    ids = set()
+    for k in names:
+        a, b = g_ref[k].double(), g_prod[k].double()
+        ratio = ((b - a).abs() / (1e-3 * a.abs() + 1e-5 * (float(a.abs().max()) + 1e-30))).reshape(P, -1).amax(dim=1)
+        ids |= set(torch.nonzero(ratio > 1.0).flatten().cpu().numpy().tolist())
+    out = {"gaussians_above_bound": len(ids)}
+    if not ids:
+        return out, g_prod
+    ids = np.array(sorted(ids))
+    up = tuple((scene[k] * keep.cpu()).contiguous() for k in ("dL_dcolor", "dL_dfeature", "dL_ddepth"))
+    full = adj.gradient_truth(scene, ids, up, False, False, DEV)
+    assert full is not None, "needle scenes are sized for the tile-restricted fp64 backward"
+    for k in sorted(names):
+        leaf = LEAF_OF[k]
+        if leaf not in full:
+            continue
+        scale = float(g_ref[k].abs().max())
+        e_p = e_r = 0.0
+        for n, i in enumerate(ids):
+            t = full[leaf][n].reshape(-1)
+            p_ = g_prod[k][i].reshape(-1).double().cpu().numpy()
+            r_ = g_ref[k][i].reshape(-1).double().cpu().numpy()
+            if k == "dL_dmeans2D":
+                t = np.concatenate([t[:2], [0.0]])[:len(p_)]
+            e_p = max(e_p, float((np.abs(p_ - t) / (1e-3 * np.abs(t) + 1e-5 * scale)).max()))
+            e_r = max(e_r, float((np.abs(r_ - t) / (1e-3 * np.abs(t) + 1e-5 * scale)).max()))
+        out[k] = (e_p, e_r)
+    return out, g_prod
+
+
+@pytest.mark.parametrize("case", NEEDLE_CASES, ids=lambda c: c["id"])
+def test_needles_take_the_exact_contraction_and_the_allowance_is_not_the_splits(case, option, record_property):
+    """the conditioning allowance of the gradient verdict was introduced in the round that also moved the
+    blend backward's contractions to two-term bf16 operands.  Which of the two needs it?  Five runs per setting (the sums are
+    atomics in a varying order) of the needle scenes with option bwd_bf16 = -1 (the default: by the frame), 1 (bf16 forced) and
+    0 (exact fp32); per run the worst distance of the product from the fp64 gradient, in bounds, over the Gaussians above the
+    bound.  Measured in round 6 (profiles/r06_needles.txt): forced onto these scenes the bf16 shape stands 1 - 14 bounds further
+    from the fp64 rotation gradient than the exact shape (everything else within half a bound; the reference: 10 - 29 bounds) -
+    the split WAS part of what the allowance covered.  Hence the default: a frame that holds a Gaussian with an axis ratio above
+    16 takes the exact contraction.  Asserted: the default runs the exact shape here and stands within half a bound of the
+    forced exact runs on every tensor; forced bf16 stands within half a bound on every tensor OUTSIDE the covariance chain."""
+    from diff_gaussian_rasterization import _C
+    scene = _build(case)
+    C = scene["C"]
+    strict = _Side("ref", scene, C, False, False, strict=True)
+    probe = _Side("prod", scene, C, False, False)
+    _st, _flips, over = _forward_stats(strict, probe, True)
+    keep = torch.from_numpy((~over).reshape(1, scene["image_height"], scene["image_width"])).to(DEV)
+    g_ref = strict.backward(keep)
+    del probe
+    runs = {-1: [], 1: [], 0: []}
+    for setting in (-1, 1, 0):
+        option("bwd_bf16", setting)
+        for _ in range(5):
+            res, _g = _needle_errors(scene, case, strict, g_ref, over)
+            assert _C.last_backward_contraction() == (1 if setting == 1 else 0), "the default must take the exact contraction on needles"
+            runs[setting].append(res)
+            del _g
+    keys = sorted({k for rs in runs.values() for r in rs for k in r if k != "gaussians_above_bound"})
+    label = {-1: "default (-1)", 1: "bf16 forced ", 0: "exact fp32  "}
+    lines = [f"{case['id']}: worst distance from the fp64 gradient in units of 1e-3 |g| + 1e-5 max|g| over the Gaussians above the bound; "
+             f"five runs per setting; (product, reference on the same Gaussians)"]
+    worst = {}
+    for setting in (-1, 1, 0):
+        for n, r in enumerate(runs[setting]):
+            lines.append(f"  bwd_bf16 {label[setting]} run {n}: above bound {r['gaussians_above_bound']:4d}  " +
+                         "  ".join(f"{k[3:]} {r[k][0]:.2f}/{r[k][1]:.2f}" for k in keys if k in r))
+        worst[setting] = {k: max((r[k][0] for r in runs[setting] if k in r), default=0.0) for k in keys}
+    for setting in (-1, 1, 0):
+        lines.append(f"  worst run, {label[setting]}: " + "  ".join(f"{k[3:]} {worst[setting][k]:.2f}" for k in keys))
+    text = "\n".join(lines)
+    print(text)
+    os.makedirs(os.path.join(ru.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ru.ROOT, "gpurun_out", f"r06_needles_{case['id']}.txt"), "w") as f:
+        f.write(text + "\n")
+    record_property("needle_attribution", text)
+    median = {st: {k: float(np.median([r[k][0] for r in runs[st] if k in r] or [0.0])) for k in keys} for st in runs}
+    lines.append("  (the default IS the exact shape on these scenes: its runs differ from the forced exact runs by the order of the atomic sums only)")
+    for k in keys:
+        # same kernel, different order of the atomic sums: medians, not the worst of five
+        assert median[-1][k] <= median[0][k] + 0.5, (f"{k}: the default's median run is {median[-1][k]:.2f} bounds from the fp64 gradient, the "
+                                                     f"exact shape's {median[0][k]:.2f}")
+        if k not in KAPPA_GRADS:
+            assert worst[1][k] <= worst[0][k] + 0.5, (f"{k} (not a tensor of the covariance chain): forced bf16 {worst[1][k]:.2f} bounds from the "
+                                                      f"fp64 gradient, exact {worst[0][k]:.2f}")
 
 
 def test_non_finite_positions_vanish_as_in_the_reference():

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pl_phase1.h"
+#include "fwd_group.h"
 
 using namespace f3dgs;
 
@@ -47,7 +48,66 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (T + S == 12345.678f || tm == 0x12345u) out[threadIdx.x] = T + S;
 }
 
+// The blend forward's group step (csrc/fwd_group.h: two entries per step, 32 channels, one quadrant per wave - the c3 shape)
+// over a chunk of 32 staged entries that all reach the quadrant and blend at every pixel, again and again.
+template <bool MFMA>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) stream_fwd(int chunks, unsigned long long* cyc, float* out, float seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    struct Chunk { FwdEntry ent[32]; float feat[32 * 32]; };
+    Chunk& ck = reinterpret_cast<Chunk*>(smem)[q];
+    if (lane < 32) {
+        const float k = (float)lane;
+        FwdEntry e;
+        e.geo = make_float4(3.0f + 0.1f * k, 4.0f - 0.05f * k, 0.02f * CONIC_SCALE_AC, 0.004f * CONIC_SCALE_B);
+        e.cd = make_float4(0.3f, 0.5f, 0.7f, 4.0f + k);
+        e.co_c = 0.03f * CONIC_SCALE_AC; e.co_o = 0.02f;
+        e.pos = (uint32_t)lane + 1; e.id = (uint32_t)lane;
+        ck.ent[lane] = e;
+    }
+    for (int i = lane; i < 32 * 32; i += 64) ck.feat[i] = 1e-3f * (float)(i & 63);
+    __syncthreads();
+    FwdPixels<32, 1> px;
+    px.pxf[0] = (float)(lane & 7) + seed; px.pyf[0] = (float)(lane >> 3);
+    px.T[0] = 1.f; px.col[0][0] = px.col[0][1] = px.col[0][2] = 0.f; px.dep[0] = 0.f; px.last[0] = 0;
+    for (int h = 0; h < 2; h++) for (int r = 0; r < 16; r++) px.acc[0][h][0][r] = 0.f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int c = 0; c < chunks; c++) {
+        px.T[0] = 1.0f + seed;
+#pragma unroll 1
+        for (int j = 0; j < 32; j += 2) fwd_blend_group<32, 1, 2, true>(ck.ent, ck.feat, reinterpret_cast<const float*>(&ck), j, lane, 0, 0, !MFMA, px);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) cyc[blockIdx.x * 4 + q] = t1 - t0;
+    float sum = px.T[0] + px.col[0][0] + px.col[0][1] + px.col[0][2] + px.dep[0] + (float)px.last[0];
+    for (int h = 0; h < 2; h++) for (int r = 0; r < 16; r++) sum += px.acc[0][h][0][r];
+    if (sum == 12345.678f) out[threadIdx.x] = sum;
+}
+
 struct Res { double ticks, simd; };
+
+template <bool MFMA>
+Res run_fwd(int wps, int n_cu, unsigned long long* d_cyc, float* d_out) {
+    const int chunks = 2000;
+    const size_t lds = 160 * 1024 / wps - 256;
+    auto kern = stream_fwd<MFMA>;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(kern, dim3(n_cu * wps), dim3(256), lds, 0, 20, d_cyc, d_out, 0.f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL(kern, dim3(n_cu * wps), dim3(256), lds, 0, chunks, d_cyc, d_out, 0.f);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    std::vector<unsigned long long> h((size_t)n_cu * wps * 4);
+    CHECK(hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost));
+    double tot = 0;
+    for (auto v : h) tot += (double)v;
+    Res r;
+    r.ticks = tot / h.size() / ((double)chunks * 32);
+    r.simd = ms * 1e-3 * 2.4e9 / ((double)chunks * 32 * wps);
+    return r;
+}
 
 template <bool GEO, int SCHED, bool NOLDS>
 Res run(int wps, int n_cu, unsigned long long* d_cyc, float* d_out) {
@@ -90,12 +150,19 @@ int main(int argc, char** argv) {
         r[0][0][1][wps - 1] = run<false, 0, true>(wps, n_cu, d_cyc, d_out);
         r[0][1][1][wps - 1] = run<false, 1, true>(wps, n_cu, d_cyc, d_out);
     }
+    Res rf[2][4];
+    for (int wps = 1; wps <= 4; wps++) { rf[0][wps - 1] = run_fwd<false>(wps, n_cu, d_cyc, d_out); rf[1][wps - 1] = run_fwd<true>(wps, n_cu, d_cyc, d_out); }
     if (json) {
         printf("{\"device\": \"%s\", \"cus\": %d, \"unit\": \"SIMD cycles per (entry, wave of 64 pixel lanes) at 2.4 GHz, wall clock\"", prop.name, n_cu);
         const char* gn[2] = {"later_window", "first_window"};
         for (int g = 0; g < 2; g++) for (int s = 0; s < 2; s++) for (int n = 0; n < 2; n++) {
             printf(", \"%s_sched%d%s\": [", gn[g], s, n ? "_nolds" : "");
             for (int w = 0; w < 4; w++) printf("%s%.2f", w ? ", " : "", r[g][s][n][w].simd);
+            printf("]");
+        }
+        for (int mf = 0; mf < 2; mf++) {
+            printf(", \"forward_c32_%s\": [", mf ? "with_matrix" : "vector_only");
+            for (int w = 0; w < 4; w++) printf("%s%.2f", w ? ", " : "", rf[mf][w].simd);
             printf("]");
         }
         printf("}\n");
@@ -106,6 +173,12 @@ int main(int argc, char** argv) {
     for (int g = 1; g >= 0; g--) for (int n = 0; n < 2; n++) for (int s = 0; s < 2; s++) {
         printf("%-36s %-22s schedule %d:", gn[g], n ? "vector stream only" : "with its LDS traffic", s);
         for (int w = 0; w < 4; w++) printf("  %d/SIMD: %6.1f | %6.1f", w + 1, r[g][s][n][w].ticks, r[g][s][n][w].simd);
+        printf("\n");
+    }
+    printf("Group step of the blend forward alone (32 channels, every entry blending at every pixel); per (entry, wave)\n");
+    for (int mf = 0; mf < 2; mf++) {
+        printf("%-36s %-22s            :", "forward, first window", mf ? "with the fp32 matrix instructions" : "vector pipe only");
+        for (int w = 0; w < 4; w++) printf("  %d/SIMD: %6.1f | %6.1f", w + 1, rf[mf][w].ticks, rf[mf][w].simd);
         printf("\n");
     }
     return 0;

@@ -21,12 +21,13 @@ constexpr int NI = 32;   // instructions per block
 
 // kinds
 enum Kind { FMA, MUL_S, EXP, RCP, CMP_VCC, CMP_SGPR, CND_VCC, CND_SGPR, CND_SGPR_FRESH, MIN_LIT, CVT_PK, LSHL, AND_LIT, SUB, XOR_, DS_W16, DS_W16HI, DS_W32,
-            DS_R128, DS_R64, CMP3_CND, MED3, MAX_, SALU_AND, NOP_, MBCNT, PERM, CMPX, V_MOV, TRIPLE_ARITH, SLEEP_, PK_FMA, PK_MUL, NKIND };
+            DS_R128, DS_R64, CMP3_CND, MED3, MAX_, SALU_AND, NOP_, MBCNT, PERM, CMPX, V_MOV, TRIPLE_ARITH, SLEEP_, PK_FMA, PK_MUL, V_MUL, V_FMAC, CND_E64_VCC, CND_VCC_WRITTEN, DS_ADD_F32, V_ADD_U32, NKIND };
 static const char* kind_name[NKIND] = {"v_fma_f32", "v_mul_f32 (sgpr operand)", "v_exp_f32", "v_rcp_f32", "v_cmp_lt_f32 -> vcc", "v_cmp_lt_f32_e64 -> sgpr pair",
     "v_cndmask_b32 (vcc, never written)", "v_cndmask_b32_e64 (sgpr pair, never written)", "v_cmp -> s_and_b64 x2 -> v_cndmask (phase-1 masking, per cndmask: 3 cmp + 2 salu + 1 cnd)",
     "v_min_f32 (literal)", "v_cvt_pk_bf16_f32", "v_lshlrev_b32", "v_and_b32 (literal)", "v_sub_f32", "v_xor_b32", "ds_write_b16", "ds_write_b16_d16_hi", "ds_write_b32",
     "ds_read_b128 (broadcast)", "ds_read_b64 (broadcast)", "v_cmp x3 (vcc chain via v_cmp + s_and) + cndmask, 8 per block", "v_med3_f32", "v_max_f32", "s_and_b64", "s_nop 0",
-    "v_mbcnt_lo", "v_perm_b32", "v_cmpx_lt_f32 (exec restored per block)", "v_mov_b32", "six plain vector instructions on one chain (per block of six)", "s_sleep 1 (calibration: 64 clocks each)", "v_pk_fma_f32", "v_pk_mul_f32"};
+    "v_mbcnt_lo", "v_perm_b32", "v_cmpx_lt_f32 (exec restored per block)", "v_mov_b32", "six plain vector instructions on one chain (per block of six)", "s_sleep 1 (calibration: 64 clocks each)", "v_pk_fma_f32", "v_pk_mul_f32", "v_mul_f32", "v_fmac_f32", "v_cndmask_b32_e64 (vcc as the pair, never written)",
+    "v_cndmask_b32 (vcc written by s_mov_b64 in front of the block)", "ds_add_f32 (no return, distinct addresses)", "v_add_u32"};
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) k(int rounds, float* out, unsigned long long* cyc, float s_in) {
@@ -172,6 +173,32 @@ __global__ void __launch_bounds__(1024) k(int rounds, float* out, unsigned long 
             OPP(0) OPP(1) OPP(2) OPP(3) OPP(0) OPP(1) OPP(2) OPP(3) OPP(0) OPP(1) OPP(2) OPP(3) OPP(0) OPP(1) OPP(2) OPP(3)
 #undef OPP
             x0 = p0.x; x1 = p0.y; x2 = p1.x; x3 = p1.y; x4 = p2.x; x5 = p2.y; x6 = p3.x; x7 = p3.y;
+        } else if constexpr (KIND == V_MUL) {
+#define OP(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(XR(i)) : "v"(y));
+            B32(OP)
+#undef OP
+        } else if constexpr (KIND == V_FMAC) {
+#define OP(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(XR(i)) : "v"(y), "v"(z));
+            B32(OP)
+#undef OP
+        } else if constexpr (KIND == CND_E64_VCC) {
+#define OP(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(XR(i)) : "v"(y));
+            B32(OP)
+#undef OP
+        } else if constexpr (KIND == CND_VCC_WRITTEN) {
+            asm volatile("s_mov_b64 vcc, %0" :: "s"(mask) : "vcc");
+#define OP(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(XR(i)) : "v"(y));
+            B32(OP)
+#undef OP
+        } else if constexpr (KIND == DS_ADD_F32) {
+#define OP(i) asm volatile("ds_add_f32 %0, %1 offset:" #i "*256" :: "v"(lds_w * 2), "v"(XR(i)) : "memory");
+            B32(OP)
+#undef OP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if constexpr (KIND == V_ADD_U32) {
+#define OP(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(XR(i)) : "v"(y));
+            B32(OP)
+#undef OP
         } else if constexpr (KIND == NOP_) {
 #define OP(i) asm volatile("s_nop 0");
             B32(OP)
@@ -210,7 +237,7 @@ template <int KIND>
 void run(int per_block, float* d_out, unsigned long long* d_cyc, int n_cu) {
     printf("%-100s", kind_name[KIND]);
     for (int wps = 1; wps <= 4; wps++) {
-        const int threads = 256 * wps, rounds = 20000;
+        const int threads = 256 * wps, rounds = 10000;
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
         hipLaunchKernelGGL((k<KIND>), dim3(n_cu), dim3(threads), 160 * 1024, 0, 50, d_out, d_cyc, 1.0001f);
@@ -264,11 +291,17 @@ int main() {
     run<XOR_>(NI, d_out, d_cyc, n_cu);
     run<MBCNT>(NI, d_out, d_cyc, n_cu);
     run<PERM>(NI, d_out, d_cyc, n_cu);
+    run<V_MUL>(NI, d_out, d_cyc, n_cu);
+    run<V_FMAC>(NI, d_out, d_cyc, n_cu);
+    run<V_ADD_U32>(NI, d_out, d_cyc, n_cu);
+    run<CND_E64_VCC>(NI, d_out, d_cyc, n_cu);
+    run<CND_VCC_WRITTEN>(NI, d_out, d_cyc, n_cu);
     run<SALU_AND>(NI, d_out, d_cyc, n_cu);
     run<NOP_>(NI, d_out, d_cyc, n_cu);
     run<DS_W16>(NI, d_out, d_cyc, n_cu);
     run<DS_W16HI>(NI, d_out, d_cyc, n_cu);
     run<DS_W32>(NI, d_out, d_cyc, n_cu);
+    run<DS_ADD_F32>(NI, d_out, d_cyc, n_cu);
     run<DS_R128>(NI, d_out, d_cyc, n_cu);
     run<DS_R64>(NI, d_out, d_cyc, n_cu);
     return 0;
