@@ -39,7 +39,7 @@ std::atomic<int> g_last_bwd_bf16{-1};  // contraction of the process's last blen
 // thread of its own) - so the value is kept here, process-wide, keyed by (device, geometry buffer): the caller hands that buffer
 // back untouched, and a buffer that has been re-used by a later forward call belongs to that call.  A backward call that finds
 // nothing (a buffer copied elsewhere, more than 256 frames in flight) takes the exact contraction.
-struct FrameNote { int device; const void* geom; float axis_ratio; };
+struct FrameNote { int device; const void* geom; float axis_ratio; };      // axis_ratio: 0 no visible Gaussian with a long axis, 1 some
 std::mutex g_frames_mu;
 std::vector<FrameNote> g_frames;
 void note_frame(const void* geom, float axis_ratio) {
@@ -204,6 +204,7 @@ void fill_view(ViewParams& vp, const float* view, const float* proj, const float
     vp.W = W; vp.H = H;
     vp.gx = (W + TILE - 1) / TILE; vp.gy = (H + TILE - 1) / TILE;
     vp.scale_modifier = mod;
+    vp.max_axis_ratio = 0.f;
 }
 
 // option "tile_cull" = 0 keeps the reference's bounding-rectangle instance lists (bit-identical intermediate
@@ -407,6 +408,8 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     int rc = F3DGS_OK;
     ViewParams vp;
     fill_view(vp, viewmatrix, projmatrix, cam_pos, background, tan_fovx, tan_fovy, width, height, scale_modifier);
+    // (one part in a thousand of slack on the ratio: a scene built with scales of exactly 16 : 1 stays on the bf16 side)
+    vp.max_axis_ratio = 1.001f * (float)options().bwd_bf16_max_ratio;
     const size_t tiles = (size_t)vp.gx * vp.gy;
 
     size_t geom_bytes = 0, img_bytes = 0, bin_bytes = 0;
@@ -457,13 +460,9 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     HIP_TRY(hipEventSynchronize(rb.done));
     // [0] instances in our lists, [1] the reference's bounding-rectangle count
     const uint32_t counts[2] = {rb.host[0], rb.host[1]};
-    // [2] the largest axis ratio of a visible Gaussian, float bits (the single-pass flavour of the binning does not produce it:
-    // "unknown" reads as ill-conditioned)
-    {
-        float ar = std::numeric_limits<float>::infinity();
-        if (!onesweep) memcpy(&ar, &rb.host[2], sizeof ar);
-        note_frame(geom_ptr, ar);
-    }
+    // [2] != 0: a visible Gaussian of the frame is longer than bwd_bf16_max_ratio times its width (the single-pass flavour of the
+    // binning does not produce the word: "unknown" reads as "yes")
+    note_frame(geom_ptr, (onesweep || rb.host[2] != 0u) ? 1.f : 0.f);
     const uint32_t N = counts[0];
     if (N >= (1u << 30) || counts[1] >= (1u << 31)) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^30 instances");
     if (num_rendered) *num_rendered = (int)counts[1];
@@ -585,9 +584,8 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     // width, exact fp32 otherwise - and exact when the forward call's note is gone.
     bool use_bf16 = options().bwd_bf16 > 0;
     if (options().bwd_bf16 < 0) {
-        float ar = 0.f;
-        // (one part in a thousand of slack: the ratio is formed with one-instruction reciprocals; NaN: false)
-        use_bf16 = frame_axis_ratio(geom_buffer, &ar) && ar <= 1.001f * (float)options().bwd_bf16_max_ratio;
+        float long_axis = 1.f;       // what the forward call of this frame noted (against bwd_bf16_max_ratio as it was THEN)
+        use_bf16 = frame_axis_ratio(geom_buffer, &long_axis) && long_axis == 0.f;
     }
     if (R > 0) {
         const int ran = launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,

@@ -84,7 +84,7 @@ __device__ __forceinline__ void run_totals_job(const TotalsJob& tj) {
     if (threadIdx.x == 0) {
         uint32_t ref = 0, own = 0, arm = 0;
         for (int k = 0; k < THREADS / 64; k++) { ref += shc[0][k]; own += shc[1][k]; arm = max(arm, shc[2][k]); }
-        // [0] entries of our lists, [1] the reference's count, [2] the largest axis ratio of a visible Gaussian (float bits)
+        // [0] entries of our lists, [1] the reference's count, [2] != 0: some visible Gaussian has a long axis (preprocess_kernel)
         tj.counters[0] = own; tj.counters[1] = ref; tj.counters[2] = arm;
         if (tj.host) {
             __hip_atomic_store(&tj.host[0], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -71,7 +71,7 @@ struct GeomState {
     uint32_t* hist;           // RADIX_BINS * sort_blocks(P) + RADIX_BINS
     uint32_t* scan_tmp;       // scan_blocks(P) + 8      list entries of every chunk of SCAN_CHUNK Gaussians in depth order
     uint32_t* scan_sub;       // 64 x scan_blocks(P)     list entries of every run of 64 Gaussians in depth order
-    uint32_t* ref_partial;    // per preprocess workgroup: bounding-rectangle tile counts, then list-entry counts, then the largest axis ratio (float bits)
+    uint32_t* ref_partial;    // per preprocess workgroup: bounding-rectangle tile counts, then list-entry counts, then 1 if a visible Gaussian of the workgroup has a long axis
     uint32_t* counters;       // 16 words: [0] = instances in the (culled) lists, [1] = reference num_rendered
     // -- control words of the single-pass sorts (lookback.h).  depth_hist is zeroed by preprocess_kernel (it is
     //    accumulated by the kernel after it); everything from lb_words on is zeroed by sort_prologue_kernel.
@@ -200,6 +200,7 @@ struct ViewParams {
     float tanx, tany, fx, fy;
     int W, H, gx, gy;
     float scale_modifier;
+    float max_axis_ratio;   // forward only: preprocess reports whether a visible Gaussian is longer than this times its width
 };
 
 // preprocess.hip (built with -ffp-contract=off)

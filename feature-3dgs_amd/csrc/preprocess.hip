@@ -299,7 +299,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     const float4 q_in = *rp;
     bool alive = false;
     float px = 0.f, py = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, rad = 0.f, depth = 0.f;
-    float axis_ratio = 0.f;       // of a visible Gaussian: the larger of its 3D scale ratio and its screen-space std-dev ratio
+    bool long_axis = false;       // a visible Gaussian longer than vp.max_axis_ratio times its width (3D scales or screen-space footprint)
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (i < P) do {
         const V3 pv = xform3(vp.view, p);
@@ -335,12 +335,14 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         alive = true;
         // What the blend backward's contraction precision is chosen by (api.hip: option bwd_bf16 = -1): the covariance chain
         // (cov2D -> cov3D -> scale / rotation, backward.cu:144-341) amplifies an error of the blend-level sums by the square of
-        // this ratio.  lambda_2 = det / lambda_1 (the product of the eigenvalues); NaN / inf (zero scales, det <= 0) read as
-        // "ill-conditioned" on the host.
-        axis_ratio = fmaxf(l1, l2) * __builtin_amdgcn_rsqf(det);
+        // the Gaussian's axis ratio.  Screen space: sqrt(lambda_1 / lambda_2) with lambda_2 = det / lambda_1 (the product of the
+        // eigenvalues), i.e. lambda_1^2 > ratio^2 det; 3D: largest scale > ratio x smallest.  Written so that a NaN (det <= 0,
+        // non-finite scales) reads as "too long"; a zero scale does as well.
+        const float mr = vp.max_axis_ratio, lmax = fmaxf(l1, l2);
+        long_axis = !(lmax * lmax <= (mr * mr) * det);
         if (have_sr) {
             const float s0 = fabsf(sc_in.x), s1 = fabsf(sc_in.y), s2 = fabsf(sc_in.z);
-            axis_ratio = fmaxf(axis_ratio, fmaxf(s0, fmaxf(s1, s2)) * __builtin_amdgcn_rcpf(fminf(s0, fminf(s1, s2))));
+            long_axis = long_axis || !(fmaxf(s0, fmaxf(s1, s2)) <= mr * fminf(s0, fminf(s1, s2))) || fminf(s0, fminf(s1, s2)) == 0.f;
         }
     } while (false);
 
@@ -433,15 +435,14 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     // kernel of the depth sort adds the partials up (binning.hip: TotalsJob) and stores the totals into the host's
     // pinned words.  The same goes for the length of our own (culled) instance lists: both totals are known right
     // after this kernel, long before the host needs them (it waits for them while the depth sort runs).
-    // Third partial: the largest axis ratio among the workgroup's visible Gaussians, as float bits (non-negative floats order
-    // like their bits; a NaN sorts above everything and reads as "ill-conditioned").
+    // Third partial: does the workgroup hold a visible Gaussian with a long axis (one ballot per wave).
     __shared__ uint32_t wsum[3][4];
-    uint32_t v = bbox_tiles, u = out_tiles, ar = alive ? __float_as_uint(axis_ratio) & 0x7FFFFFFFu : 0u;
+    uint32_t v = bbox_tiles, u = out_tiles;
+    const uint32_t ar = __ballot(alive && long_axis) != 0ull ? 1u : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         v += (uint32_t)__shfl_xor((int)v, d, 64);
         u += (uint32_t)__shfl_xor((int)u, d, 64);
-        ar = max(ar, (uint32_t)__shfl_xor((int)ar, d, 64));
     }
     if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = v; wsum[1][threadIdx.x >> 6] = u; wsum[2][threadIdx.x >> 6] = ar; }
     __syncthreads();

@@ -93,8 +93,9 @@ const char* f3dgs_last_error(void);
  *                    a relative error of a few 1e-6 per product against the 1e-3 tolerance of the gradients; 0: exact-fp32
  *                    matrix instructions (16x slower per multiply-add, and they block the vector pipe of their SIMD);
  *                    -1 (default): by the frame - bf16 while no visible Gaussian is longer than "bwd_bf16_max_ratio" times
- *                    its width (3D scales and screen-space footprint; f3dgs_forward notes the largest ratio per geometry
- *                    buffer, f3dgs_backward looks it up), exact fp32 otherwise and when the note is gone: the covariance
+ *                    its width (3D scales and screen-space footprint; f3dgs_forward notes per geometry buffer whether
+ *                    the frame holds such a Gaussian - against the ratio in force at that call -, f3dgs_backward looks it
+ *                    up), exact fp32 otherwise and when the note is gone: the covariance
  *                    chain behind the blend amplifies an error of the blend-level sums by the square of that ratio
  *                    (measured: within a third of the gradient bound up to 16, outside it from 32 on)
  *   "bwd_bf16_max_ratio"  (default 16) the axis ratio up to which bwd_bf16 = -1 takes the bf16 contraction

@@ -425,8 +425,9 @@ def test_contraction_precision_follows_the_conditioning_of_the_frame(shape, rati
     worst = {k: _bound_distance(g_auto[k], g0[k]) for k in g_auto if g_auto[k] is not None and g_auto[k].size}
     noise = {k: _bound_distance(g0b[k], g0[k]) for k in worst}
     print(shape, ratio, "auto vs exact:", {k: round(v, 3) for k, v in worst.items()}, "exact vs exact again:", {k: round(v, 3) for k, v in noise.items()})
-    for k in worst:
-        assert worst[k] <= 0.5 + 2.0 * noise[k], (k, worst[k], noise[k])
+    if want_bf16:      # (otherwise both are runs of the exact kernel, a bound or more apart on such input by the order of the atomic sums alone)
+        for k in worst:
+            assert worst[k] <= 0.5 + 2.0 * noise[k], (k, worst[k], noise[k])
     # the threshold is an option: raised, the needles take the bf16 shape; lowered to 1, nothing does
     if ratio > 1:
         option("bwd_bf16_max_ratio", 100000 if not want_bf16 else 1)

@@ -10,7 +10,7 @@ rm -rf $B && mkdir -p $D $B/include && cp -p $ROOT/include/*.h $B/include/
 cp -p $ROOT/feature-3dgs_amd/csrc/*.{hip,h,cpp} $ROOT/feature-3dgs_amd/csrc/Makefile $D/
 # objects of files this experiment does not touch (same flags): taken from the in-tree build when they are newer than their source
 for o in $ROOT/feature-3dgs_amd/csrc/*.o; do cp -p $o $D/; done
-touch $D/render_bwd_pl.hip $D/render_fwd.hip $D/render_bwd.hip
+for f in ${EXP_TOUCH:-render_bwd_pl.hip render_fwd.hip render_bwd.hip}; do touch $D/$f; done
 make -C $D -j8 "$@" libf3dgs_hip.so > $B/build.log 2>&1 || { tail -30 $B/build.log; exit 1; }
 mkdir -p $ROOT/exp && cp $D/libf3dgs_hip.so $ROOT/exp/libf3dgs_hip_$NAME.so
 echo "built exp/libf3dgs_hip_$NAME.so"

@@ -1,3 +1,4 @@
+"""Development aid (needs a GPU): which scenes the forward pass flags as holding a long-axis Gaussian (counters[2])."""
 import os, sys, ctypes
 ROOT="/root/repo"
 for p in (ROOT, ROOT+"/feature-3dgs_amd", ROOT+"/tests"): sys.path.insert(0,p)
@@ -9,7 +10,7 @@ lib = tp._lib()
 def ratio(sc):
     res = tp._raw_forward(sc)
     c = tp._read(lib, "counters", sc, res, np.uint32, 16)
-    return float(np.array([c[2]],np.uint32).view(np.float32)[0])
+    return int(c[2])        # 1: the frame holds a visible Gaussian longer than bwd_bf16_max_ratio (16) times its width
 for shape in ("needle","disc"):
     for r in (1,4,8,12,15,16,32):
         print(shape, r, ratio(tp._needle_scene(r, shape)))

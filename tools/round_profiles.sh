@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: collect everything that goes under profiles/ for one round (run through gpurun; output in gpurun_out/<tag>).
-#   tools/round_profiles.sh r05 [quick]
-TAG=${1:-r05}
+#   tools/round_profiles.sh r06 [quick]
+TAG=${1:-r06}
 QUICK=${2:-}
 export TMPDIR=/tmp
 ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
@@ -22,6 +22,11 @@ timeout 200 python tools/feature_loss_bench.py > $OUT/${TAG}_feature_loss.txt 2>
 timeout 200 python tools/lowres_step_bench.py c4 20 > $OUT/${TAG}_lowres_step.txt 2>&1
 timeout 200 python tools/lowres_step_bench.py c3 20 >> $OUT/${TAG}_lowres_step.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -w tools/pipe_probe.hip -o /tmp/pipe_probe 2>/dev/null && timeout 60 /tmp/pipe_probe > $OUT/${TAG}_pipe_probe.txt 2>&1
+# instruction costs and the blend kernels' inner streams by themselves (round 6)
+hipcc --offload-arch=gfx950 -O3 -mcode-object-version=5 -w tools/ubench/inst_rate.hip -o /tmp/inst_rate 2>/dev/null && timeout 120 /tmp/inst_rate > $OUT/${TAG}_inst_rate.txt 2>&1
+timeout 60 tools/ubench/blend_stream > $OUT/${TAG}_blend_stream.txt 2>&1
+timeout 60 tools/ubench/blend_stream json > $OUT/${TAG}_blend_stream.json 2>/dev/null
+timeout 120 python tools/ratio_sweep.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_ratio_sweep.txt
 python tools/kernel_resources.py > $OUT/${TAG}_kernel_resources.txt 2>&1
 if [ -z "$QUICK" ]; then
 # 1c. SURVEY 8(d): the reduced c3-shaped PyTorch-CPU run (minutes of host time)
@@ -31,17 +36,21 @@ timeout 600 python -m pytest tests/test_gpu_vs_ref.py -q -s -k "full_size or eig
 fi
 # 2. kernel trace of the SAME command as the bench (rocprofv3 --kernel-trace --stats)
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python $ROOT/bench.py --no-cpu-baseline > $OUT/kt_bench.json 2> $OUT/kt.err
+F3DGS_BENCH_NO_UBENCH=1 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python $ROOT/bench.py --no-cpu-baseline > $OUT/kt_bench.json 2> $OUT/kt.err
 cd $ROOT
 python tools/rocprof_summary.py $OUT/kt $OUT/${TAG}_kernel_trace_c3.md
 # 3. counters, separate passes (no tracing in the same run)
 cd /tmp
 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY \
   -d $OUT/pmc_sq --output-format csv -- python $ROOT/tools/quick_bench.py c3 4 > $OUT/pmc_sq.log 2>&1
+# LDS side of the blend kernels (round 6: the pixel-lane backward is co-limited by vector issue and LDS)
+timeout 200 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS \
+  -d $OUT/pmc_lds --output-format csv -- python $ROOT/tools/quick_bench.py c3 4 > $OUT/pmc_lds.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- python $ROOT/tools/quick_bench.py c3 4 > $OUT/pmc_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write --output-format csv -- python $ROOT/tools/quick_bench.py c3 4 > $OUT/pmc_write.log 2>&1
 cd $ROOT
 python tools/pmc_summary.py $OUT/${TAG}_pmc_sq_counters.json $OUT/pmc_sq
+python tools/pmc_summary.py $OUT/${TAG}_pmc_lds_counters.json $OUT/pmc_lds
 python tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_raw.json $OUT/pmc_fetch $OUT/pmc_write
 python tools/pmc_summary.py --traffic $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_hbm_raw.json
 # 3b. decision bias of the product on borderline blend decisions (c4, the two views where round 4 saw the largest product-vs-fp64 medians)
@@ -50,5 +59,5 @@ for v in 4 5; do timeout 200 python tools/adjudicate_probe.py c4 $v strict 2>&1 
 fi
 # 4. work statistics of the blend kernels (lane utilisation)
 timeout 200 python tools/pair_stats.py c3 > $OUT/${TAG}_pair_stats_c3.txt 2>&1
-rm -rf $OUT/kt $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/kt $OUT/pmc_sq $OUT/pmc_lds $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT
