@@ -228,6 +228,7 @@ const OptionDesc kOptions[] = {
     {"bwd_split16", "F3DGS_BWD_SPLIT16", &Options::bwd_split16, 1},
     {"bwd_bf16", "F3DGS_BWD_BF16", &Options::bwd_bf16, -1},
     {"bwd_bf16_max_ratio", "F3DGS_BWD_BF16_MAX_RATIO", &Options::bwd_bf16_max_ratio, 16},
+    {"bwd_wide8", "F3DGS_BWD_WIDE8", &Options::bwd_wide8, 1},
     {"fwd_wide", "F3DGS_FWD_WIDE", &Options::fwd_wide, 1},
     {"fwd_solo", "F3DGS_FWD_SOLO", &Options::fwd_solo, 1},
     {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},

@@ -179,6 +179,7 @@ struct Options {
     int bwd_split16;     // pixel-lane blend backward, up to 16 channels: feature and moment blocks split over the waves by quadrants (default 1)
     int bwd_bf16;        // pixel-lane blend backward: every contraction on bf16 matrix instructions, operands as two bf16 terms: 1 always, 0 never (exact fp32), -1 (default) while no visible Gaussian's axis ratio exceeds bwd_bf16_max_ratio
     int bwd_bf16_max_ratio;   // (default 16)
+    int bwd_wide8;       // pixel-lane blend backward, bf16 shape: later channel windows of up to 128 channels on eight waves per tile where more than 64 channels remain (default 1)
     int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 0 (C > 4 with bwd_bf16 = 0); needs feature_mfma
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
     int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)

@@ -120,16 +120,21 @@ constexpr int PL_STAGE_PLANES = 38;
 // (i, k) - one 16-byte read per u - meets the other lanes of its 16-lane service group ({0-3, 12-15, 20-27}, ...) on sixteen
 // different 4-bank groups, and the phase-1 stores (the 64 pixels of one row: sixteen blocks) are 2-way conflicted at most.
 // The XOR touches address bits 4..6 only: a row's address is (lane base) ^ (16 row), one instruction per entry.
-struct PlShared {
+constexpr int PL_FS8 = 136;        // eight-wave later windows: 128 feature sums + 8 of splat data
+template <int FS>
+struct PlSharedT {
     float wt[4][PL_TILE];       // per quadrant: blend weights
     float st[4][PL_TILE];       //               s = op G dL/dalpha
     PlRec rec[PL_WIN];          // one window of records: read by phase 1 only (the flush has its own copy in the flush tile)
-    float ftile[PL_CAP * PL_FS];   // the chunk's sums, entry-major, as they leave for global memory; slots 60..67: splat data
+    float ftile[PL_CAP * FS];   // the chunk's sums, entry-major, as they leave for global memory; the last 8 slots: splat data
     uint32_t wave_max[4];
     uint32_t touched[2];        // per chunk parity: rows that blended somewhere in the tile
     uint32_t pad[2];
 };
+typedef PlSharedT<PL_FS> PlShared;
+typedef PlSharedT<PL_FS8> PlShared8;
 static_assert(sizeof(PlShared) * 4 <= 160 * 1024, "four workgroups per CU");
+static_assert(sizeof(PlShared8) * 2 <= 160 * 1024, "two eight-wave workgroups per CU");
 static_assert(PL_STAGE_PLANES * PL_SP * 4 <= sizeof(PlShared), "staging image fits the aliased area");
 constexpr int PL_TAPS_OFS = PL_STAGE_PLANES * PL_SP * 4;      // bytes: tap lists of the tile's rows and columns (low-resolution gradient)
 static_assert(PL_TAPS_OFS + 32 * sizeof(float4) + 34 * sizeof(int) <= sizeof(PlShared), "tap lists fit behind the staging image");
@@ -139,15 +144,24 @@ static_assert(PL_TAPS_OFS + 32 * sizeof(float4) + 34 * sizeof(int) <= sizeof(PlS
 // GEO = false: a later channel window of up to 64 channels: sixteen per wave.
 // P1_NE / P1_PREF: entries per phase-1 group, records of the next group prefetched.
 // M44: the colour wave of the first window contracts on sixteen 4 x 4 blocks (v_mfma_f32_4x4x1_16B_f32).
-template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false, bool BF = false>
+// NWV = 8 (round 6; bf16 shape, later windows only): EIGHT waves per tile - a window of up to 128 channels, sixteen per wave.
+//   Every later window re-evaluates the blend weights of the whole list (phase 1); with twice the columns per window half as many
+//   windows do.  Waves 0..3 are the quadrant waves of phase 1 (and take channels 0..63 in phase 2), waves 4..7 only contract
+//   (channels 64..127) and flush; two workgroups per CU (the same sixteen waves per CU as four workgroups of four).
+template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false, bool BF = false, int NWV = 4>
 __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     static_assert(!BF || (P1_NE == 1 && !M44), "the bf16 shape takes its entries one at a time and has no 4 x 4 colour path");
+    static_assert(NWV == 4 || (NWV == 8 && BF && !GEO), "eight waves: later windows of the bf16 shape only");
+    constexpr int NTH = 64 * NWV;                    // threads per workgroup
+    constexpr int FS = NWV == 8 ? PL_FS8 : PL_FS;    // dwords per row of the flush tile
+    constexpr int FROWS = PL_CAP / NWV;              // rows of a chunk each wave flushes
+    constexpr int GID_SLOT = GEO ? 66 : FS - 4;      // where a row's Gaussian index waits for the flush (GEO: behind its splat data)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    PlShared& L = *reinterpret_cast<PlShared*>(smem);
+    PlSharedT<FS>& L = *reinterpret_cast<PlSharedT<FS>*>(smem);
     float* const stage = reinterpret_cast<float*>(smem);      // staging image: aliases everything, used before the walk only
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: quadrant in phase 1, column block in phase 2
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: quadrant in phase 1 (waves 0..3), column block in phase 2
     const bool split16 = !BF && GEO && a.split16 && a.nc <= 16;      // wave-uniform: see the operand read-out below
     // later windows of up to 32 channels (the last window of 64 + 32 or 3 x 64 + 32 remaining channels: two waves would idle): wave q
     // takes channel block q & 1 at the quadrants 2 (q >> 1), 2 (q >> 1) + 1 - two partial sums per entry, added in the flush
@@ -162,7 +176,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
     const size_t HW = (size_t)a.W * a.H;
     const int tx0 = tx * TILE, ty0 = ty * TILE;
-    const int qx = (q & 1) * 8, qy = (q >> 1) * 8;
+    const int qx = (q & 1) * 8, qy = ((q >> 1) & 1) * 8;
     // (lane-derived indices are rebuilt where they are used - staging read-out, walk set-up - instead of living across the staging)
 
     // ---- staging: every plane of the tile with full-row requests -> LDS [plane][16 rows][16 px]; then the per-pixel state
@@ -179,7 +193,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
         const bool vec = (a.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.dL_dfeat) | reinterpret_cast<uintptr_t>(a.dL_dpix) |
                                               reinterpret_cast<uintptr_t>(a.dL_ddepth) | reinterpret_cast<uintptr_t>(a.final_T) |
                                               reinterpret_cast<uintptr_t>(a.n_contrib)) & 15) == 0;
-        const int rounds = (GEO || a.nc <= 32) ? 1 : 2;
+        const int rounds = GEO ? 1 : (a.nc + 31) / 32;
         for (int rd = 0; rd < rounds; rd++) {
             // planes of this round: 32 feature planes (channels 32 rd ..), then - first round only - the pixel planes:
             // GEO: dL/dR, dL/dG, dL/dB, dL/ddepth, final_T, n_contrib;  otherwise: final_T, n_contrib
@@ -190,12 +204,12 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             const int tid = fresh_lane() + 64 * q;
             // all requests of a thread first (branch-free: a lane that has nothing to fetch reads a valid address and drops the
             // value), then the LDS stores: one memory latency per round instead of one per plane
-            constexpr int NIT = (38 * 64 + 255) / 256;
+            constexpr int NIT = (38 * 64 + NTH - 1) / NTH;
             float4 sv[NIT];
             if (vec) {
 #pragma unroll
                 for (int it = 0; it < NIT; it++) {
-                    const int f = it * 256 + tid;
+                    const int f = it * NTH + tid;
                     const int pl = f >> 6, row = (f >> 2) & 15, xq = f & 3;
                     const int y = ty0 + row, x = tx0 + 4 * xq;
                     const int ch = 32 * rd + pl;
@@ -209,7 +223,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 }
             } else {
                 for (int it = 0; it < NIT; it++) {          // images whose rows are not 16-byte aligned: element by element
-                    const int f = it * 256 + tid;
+                    const int f = it * NTH + tid;
                     const int pl = f >> 6, row = (f >> 2) & 15, xq = f & 3;
                     const int y = ty0 + row, x = tx0 + 4 * xq;
                     const int ch = 32 * rd + pl;
@@ -230,7 +244,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             }
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
-                const int f = it * 256 + tid;
+                const int f = it * NTH + tid;
                 const int pl = f >> 6, row = (f >> 2) & 15, xq = f & 3;
                 if (f < (32 + npix) * 64) *reinterpret_cast<float4*>(&stage[pl * PL_SP + row * 16 + 4 * xq]) = sv[it];
             }
@@ -279,14 +293,15 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                     const float* const gbase = a.glow + a.c0 + 32 * rd;
                     const uint32_t C_ = (uint32_t)a.C, Wg_ = (uint32_t)a.gWg;
                     const uint32_t inv = (65536u + (uint32_t)ncol - 1u) / (uint32_t)ncol;      // i / ncol = (i inv) >> 16 for i < 256
+                    constexpr int HWV = NTH / 32;          // half waves of the workgroup: two items each per pass
 #pragma unroll 1
-                    for (int i0 = tid >> 5; i0 < items; i0 += 16) {
+                    for (int i0 = tid >> 5; i0 < items; i0 += 2 * HWV) {
                         float v[2][4], wy0[2], wy1[2], wx0[2], wx1[2];
                         int sp[2];
                         bool live[2];
 #pragma unroll
                         for (int u = 0; u < 2; u++) {
-                            const int it = i0 + 8 * u;
+                            const int it = i0 + HWV * u;
                             live[u] = it < items && ch_ok;
                             const int itc = it < items ? it : i0;
                             const int ri = (int)(((uint32_t)itc * inv) >> 16), ci = itc - ri * ncol;
@@ -314,7 +329,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             PL_STAGE_MARK(0);
             __syncthreads();
             PL_STAGE_MARK(1);
-            if (rd == 0) {
+            if (rd == 0 && q < 4) {
                 const int ln = fresh_lane();
                 const int sp = (qy + (ln >> 3)) * 16 + qx + (ln & 7);
                 constexpr int pb = 32 - (GEO ? 0 : 4);        // plane of dL/dR (GEO); final_T at pb + 4, n_contrib at pb + 5
@@ -456,7 +471,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     const bool use_s = GEO && q == 3;
     __syncthreads();                                // every read of the staging image is done: the area is re-used from here on
     PL_STAGE_MARK(3);
-    if (lane == 0) L.wave_max[q] = my_max;
+    if (lane == 0 && q < 4) L.wave_max[q] = my_max;
     if (tid < 2) L.touched[tid] = 0;
     __syncthreads();
     PL_STAGE_MARK(4);
@@ -527,20 +542,20 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
             // of the next pair in flight while a pair is computed.  A quadrant whose pixels all ended behind the chunk skips it.
             const uint32_t pos_hi = k0 + (uint32_t)(PL_WIN - 1 - 16 * j);      // list position of row 0
             uint32_t tm = 0;      // rows that blended somewhere in this quadrant; bit 16 + q: the quadrant's tiles are live
-            if (lane < 4) {
-                // what the flush of this wave's four rows needs of their splats, kept beside the sums: the record window may
+            if (lane < FROWS) {
+                // what the flush of this wave's rows needs of their splats, kept beside the sums: the record window may
                 // be replaced while the chunk is flushed
-                const PlRec& rr = rec[16 * j + 4 * q + lane];
-                float* const info = &L.ftile[(4 * q + lane) * PL_FS];
+                const PlRec& rr = rec[16 * j + FROWS * q + lane];
+                float* const info = &L.ftile[(FROWS * q + lane) * FS];
                 if constexpr (GEO) {
                     const float4 i0 = rr.q0, i1 = rr.q1;
                     *reinterpret_cast<float4*>(info + 60) = i0;
                     *reinterpret_cast<float4*>(info + 64) = make_float4(i1.x, i1.y, i1.z, 0.f);
                 } else {
-                    info[64] = rr.q1.z;
+                    info[GID_SLOT] = rr.q1.z;
                 }
             }
-            if (pos_hi - 15 < my_max && !PL_DEV_SKIP(2)) {
+            if (q < 4 && pos_hi - 15 < my_max && !PL_DEV_SKIP(2)) {
                 const PlRec* rc = &rec[16 * j];
                 auto phase1 = [&](auto nec, auto prefc) {
                     constexpr int NE = decltype(nec)::value;
@@ -660,7 +675,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                     const int col = lane2 & 15, kk = lane2 >> 4;
                     // operand read base of lane (row col, K group kk): unit 4 ks + kk at slot (4 ks + kk) ^ (row >> 1)
                     const uint32_t r0 = (uint32_t)(col * BF_ROWB + ((kk ^ (col >> 1)) & 7) * 16), r1 = r0 ^ 64u;
-                    const int fs_row0 = (4 * kk) * PL_FS;
+                    const int fs_row0 = (4 * kk) * FS;
                     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
                     auto a_read = [&](int qd, int term, int ks, uint32_t (&dst)[4]) {
                         const uint4 v = *reinterpret_cast<const uint4*>(bf_tiles + qd * BF_QUAD + term * BF_TERM + (ks ? r1 : r0));
@@ -683,7 +698,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                             }
                             if (col < 6) {
 #pragma unroll
-                                for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + 36 + 6 * qd + col] = acc0[r] + acc1[r];
+                                for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * FS + 36 + 6 * qd + col] = acc0[r] + acc1[r];
                             }
                         }
                     } else {
@@ -707,7 +722,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                         const int slot = (GEO && q == 2) ? 32 + col : 16 * q + col;
                         if (!(GEO && q == 2) || col < 4) {
 #pragma unroll
-                            for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * PL_FS + slot] = acc0[r] + (acc1[r] + acc2[r]);
+                            for (int r = 0; r < 4; r++) L.ftile[fs_row0 + r * FS + slot] = acc0[r] + (acc1[r] + acc2[r]);
                         }
                     }
                 }
@@ -858,9 +873,8 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 
             // ---- flush: wave q owns rows 4 q .. 4 q + 3 of the chunk
             if ((tt & 0xFFFFu) != 0 && !PL_DEV_SKIP(16)) {
-                const uint32_t m4 = (tt >> (4 * q)) & 0xFu;
-                float* const F = &L.ftile[(4 * q) * PL_FS];
-                constexpr int GID_SLOT = GEO ? 66 : 64;
+                const uint32_t m4 = (tt >> (FROWS * q)) & ((1u << FROWS) - 1u);
+                float* const F = &L.ftile[(FROWS * q) * FS];
                 const int lane = fresh_lane();
                 if (m4 != 0) {
                     if constexpr (GEO) {
@@ -916,11 +930,15 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                         }
                     } else if (!PL_DEV_SKIP(1)) {
 #pragma unroll
-                        for (int rw = 0; rw < 4; rw++) {
-                            float v = F[rw * PL_FS + lane];
-                            if (split32) v += F[rw * PL_FS + 32 + (lane & 31)];     // the other pair of quadrants
-                            const uint32_t gg = __float_as_uint(F[rw * PL_FS + GID_SLOT]);
-                            if (((m4 >> rw) & 1u) && lane < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + lane, v);
+                        for (int rw = 0; rw < FROWS; rw++) {
+                            const uint32_t gg = __float_as_uint(F[rw * FS + GID_SLOT]);
+#pragma unroll
+                            for (int hf = 0; hf < NWV / 4; hf++) {          // 64 channels per instruction
+                                const int ch = lane + 64 * hf;
+                                float v = F[rw * FS + ch];
+                                if (split32) v += F[rw * FS + 32 + (lane & 31)];     // the other pair of quadrants
+                                if (((m4 >> rw) & 1u) && ch < a.nc) unsafeAtomicAdd(a.dL_dfeature + (size_t)gg * a.C + a.c0 + ch, v);
+                            }
                         }
                     }
                 }
@@ -940,6 +958,10 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false, bool BF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel(BwdArgs a) {
     render_backward_pl_body<GEO, P1_NE, P1_PREF, M44, BF>(a);
+}
+// later windows of more than 64 channels, bf16 shape: eight waves per tile (see NWV in the body)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel8(BwdArgs a) {
+    render_backward_pl_body<false, 1, true, false, true, 8>(a);
 }
 
 // Tiles by descending walk length, XCD by XCD: workgroup b runs on XCD b % 8 (xcd_remap) and every XCD keeps its contiguous
@@ -1012,9 +1034,20 @@ void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s) {
     // c5 4.65 -> 4.59 - the later window grows from 32 to 48 channels and takes a second staging round)
     a.c0 = 0; a.nc = min(32, C); a.write_base = 1;
     launch_pl<true>(a, s);
-    for (int c0 = 32; c0 < C; c0 += 64) {
-        a.c0 = c0; a.nc = min(64, C - c0); a.write_base = 0;
-        launch_pl<false>(a, s);
+    // later windows: 64 channels on four waves; with the bf16 shape up to 128 channels on eight waves where more than 64 remain
+    // (option bwd_wide8, default 1) - every window re-evaluates the blend weights of the whole list
+    const bool wide8 = a.bf16 && options().bwd_wide8 != 0;
+    for (int c0 = 32; c0 < C;) {
+        const int left = C - c0;
+        a.c0 = c0; a.write_base = 0;
+        if (wide8 && left > 64) {
+            a.nc = min(128, left);
+            hipLaunchKernelGGL(render_backward_pl_kernel8, dim3(a.gx * a.gy), dim3(512), sizeof(PlShared8), s, a);
+        } else {
+            a.nc = min(64, left);
+            launch_pl<false>(a, s);
+        }
+        c0 += a.nc;
     }
 }
 

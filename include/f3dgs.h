@@ -99,6 +99,9 @@ const char* f3dgs_last_error(void);
  *                    chain behind the blend amplifies an error of the blend-level sums by the square of that ratio
  *                    (measured: within a third of the gradient bound up to 16, outside it from 32 on)
  *   "bwd_bf16_max_ratio"  (default 16) the axis ratio up to which bwd_bf16 = -1 takes the bf16 contraction
+ *   "bwd_wide8"      bf16 shape of the pixel-lane blend backward, feature widths above 96: 1 (default) later channel windows of
+ *                    up to 128 channels on eight waves per tile (four of them evaluate the blend weights, all eight contract)
+ *                    where more than 64 channels remain - half as many re-evaluations of the lists; 0: 64 channels on four
  *   "bwd_m44"        fp32 shape of the pixel-lane blend backward (bwd_bf16 = 0): 1 (default) the colour / depth sums contract on 4 x 4 matrix blocks
  *                    (v_mfma_f32_4x4x1_16B_f32) instead of a 16-column block of which four are used
  *   "bwd_split16"    fp32 shape of the pixel-lane blend backward (bwd_bf16 = 0) with up to 16 feature channels, and its later channel windows of up to 32: 1 (default)
