@@ -673,6 +673,15 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
         el = time_group(None)
+        # the same exchange without a ring, out of an all-to-all and an all-gather (dp.all_reduce_direct; F3DGS_DP_EXCHANGE=direct
+        # makes it the training step's exchange)
+        dp.EXCHANGE = "direct"
+        try:
+            t_direct = time_group(None)
+            direct = {"ms": 1e3 * t_direct / args.steps, "algbw_GBps": nbytes / (t_direct / args.steps) / 1e9}
+        except Exception as exc:      # noqa: BLE001
+            direct = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        dp.EXCHANGE = "allreduce"
         # The same exchange on communicators created under other NCCL_ALGO / NCCL_PROTO settings (RCCL reads them when a
         # communicator is initialised): xGMI is a point-to-point mesh, and a ring all-reduce is bound by ONE link (SURVEY.md 5:
         # ~29 ms against ~4 ms for c4) - this table says what the library picked and what the alternatives cost on this node.
@@ -704,6 +713,7 @@ def main():
             print(json.dumps({"metric": "gradient all-reduce only (no rendering)", "value": 1e3 * el / args.steps, "unit": "ms",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": False,
                               "bytes_per_rank": nbytes, "algbw_GBps": nbytes / (el / args.steps) / 1e9,
+                              "direct_all_to_all_plus_all_gather": direct,
                               "by_setting": sweep, "data": "stub" if STUB else "synthetic",
                               "config": {"workload": f"{args.config}: (59+{C}) floats x {P} Gaussians"}}), flush=True)
         dist.destroy_process_group()
@@ -812,7 +822,27 @@ def main():
         tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         nbytes = sum(g.numel() * 4 for g in grads.values())
+        comm_direct_ms = None
+        try:          # the same exchange as all-to-all + local sum + all-gather (dp.all_reduce_direct): no ring by construction
+            dp.EXCHANGE = "direct"
+            for _ in range(2):
+                dp.all_reduce_gaussian_grads(grads)
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dp.all_reduce_gaussian_grads(grads)
+            sync()
+            dist.barrier()
+            td = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            comm_direct_ms = 1e3 * float(td.item()) / args.steps
+        except Exception:      # noqa: BLE001
+            comm_direct_ms = None
+        finally:
+            dp.EXCHANGE = "allreduce"
         dp_breakdown = {"compute_only_ms": 1e3 * el_compute / args.steps, "comm_only_ms": 1e3 * float(tt.item()) / args.steps,
+                        "comm_only_direct_ms": comm_direct_ms,
                         "bytes_per_rank": nbytes, "comm_algbw_GBps": nbytes / (float(tt.item()) / args.steps) / 1e9,
                         "note": "same K steps without the exchange (max over ranks), and the bucketed all-reduce alone; "
                                 "ms_per_step below their sum = overlap achieved"}

@@ -104,6 +104,54 @@ class GradBuckets:
 
 
 _DEBUG = os.environ.get("F3DGS_DP_DEBUG", "0") not in ("", "0")     # cross-rank agreement checks (extra collectives)
+# How a collective-sized gradient tensor is summed: "allreduce" (the library's all-reduce, whatever algorithm it picks) or "direct"
+# (all-to-all of the slices + a local sum + all-gather, see all_reduce_direct).  `bench.py --comm-only` times both on the node.
+EXCHANGE = os.environ.get("F3DGS_DP_EXCHANGE", "allreduce")
+
+
+def all_reduce_direct(t: torch.Tensor, group=None, async_op: bool = False):
+    """SUM `t` over all ranks in place WITHOUT a ring: every rank sends slice j of its tensor straight to rank j (one
+    all-to-all: N - 1 point-to-point transfers per rank, one per peer), sums the N slices it received, and the summed slices are
+    all-gathered back.  On a full mesh of point-to-point links (MI355X: seven xGMI links of ~153 GB/s per GPU) every transfer has
+    a link of its own, so the exchange costs 2 (S / N) / link - 4.1 ms for c4's 2.52 GB on eight GPUs - where a ring all-reduce
+    is bound by ONE link: 2 (N - 1) / N x S / link = 29 ms.  The library's all-reduce may or may not pick a
+    direct algorithm; this one is direct by construction, out of collectives every backend has (tested on gloo at world size 2:
+    the sum of two terms is order-free, so the result equals all_reduce bit for bit).  Costs one extra buffer of the tensor's size.
+    Returns a handle with .wait() when `async_op` (the work runs on the collective stream of the backend as usual)."""
+    world = dist.get_world_size(group)
+    flat = t.reshape(-1)
+    n = flat.numel()
+    per = (n + world - 1) // world
+    if per * world != n:
+        send = torch.zeros(per * world, dtype=t.dtype, device=t.device)
+        send[:n].copy_(flat)
+    else:
+        send = flat.contiguous()
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)                    # recv[j * per : (j + 1) * per] = rank j's slice for me
+    mine = recv.view(world, per).sum(dim=0)
+    work = dist.all_gather_into_tensor(send, mine, group=group, async_op=async_op)
+
+    def finish():
+        if send.data_ptr() != flat.data_ptr() or not t.is_contiguous():
+            t.copy_(send[:n].view(t.shape))
+
+    class _Handle:
+        def wait(self_inner):
+            if work is not None:
+                work.wait()
+            finish()
+    if async_op:
+        return _Handle()
+    finish()
+    return None
+
+
+def _sum_tensor(t: torch.Tensor, group=None, async_op: bool = False):
+    """One collective-sized tensor, summed in place by the configured exchange."""
+    if EXCHANGE == "direct":
+        return all_reduce_direct(t, group=group, async_op=async_op)
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
 def _check(grads: Dict[str, torch.Tensor]) -> List[str]:
@@ -140,7 +188,7 @@ def all_reduce_gaussian_grads(grads: Dict[str, torch.Tensor], group=None, bucket
     big = [k for k in keys if grads[k].numel() * 4 >= direct_bytes]
     small = [k for k in keys if k not in big]
     staged = {k: grads[k].contiguous() for k in big if not grads[k].is_contiguous()}
-    works = [dist.all_reduce(staged.get(k, grads[k]), op=dist.ReduceOp.SUM, group=group, async_op=True) for k in big]
+    works = [_sum_tensor(staged.get(k, grads[k]), group=group, async_op=True) for k in big]
     if small:
         if buckets is None:
             buckets = GradBuckets({k: grads[k].shape for k in small}, grads[small[0]].device, bucket_bytes)
@@ -190,9 +238,9 @@ class FeatureGradOverlap:
             ready.record(torch.cuda.current_stream(feature_grad.device))
             self._stream.wait_event(ready)
             with torch.cuda.stream(self._stream):
-                self._work = dist.all_reduce(feature_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._work = _sum_tensor(feature_grad, group=self.group, async_op=True)
         else:
-            self._work = dist.all_reduce(feature_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work = _sum_tensor(feature_grad, group=self.group, async_op=True)
         self._count += 1
 
     def __enter__(self):
@@ -271,10 +319,10 @@ class RowsGradOverlap:
             self._stream.wait_event(ready)
             with torch.cuda.stream(self._stream):
                 for t in parts:
-                    self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self._works.append(_sum_tensor(t, group=self.group, async_op=True))
         else:
             for t in parts:
-                self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._works.append(_sum_tensor(t, group=self.group, async_op=True))
         self._count += 1
 
     def __enter__(self):
@@ -537,7 +585,7 @@ def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.
             # hook fired; a rank whose backward pass did not reach the op (or produced no feature gradient) issues the
             # matching one here, so that its peers' collective is not left without a partner
             if not ov.reduced((feature_key,)):
-                dist.all_reduce(grads[feature_key], op=dist.ReduceOp.SUM, group=group)
+                _sum_tensor(grads[feature_key], group=group)
             if _DEBUG:
                 fired = torch.tensor([float(bool(ov.reduced((feature_key,))))], device=grads[feature_key].device)
                 lo = fired.clone()
@@ -688,6 +736,6 @@ def dp_step_views(forward: Callable[[int], object], backward: Callable[[object],
         if ov is not None and ov.reduced((feature_key,)):
             skip = [feature_key]
         elif accumulate:
-            dist.all_reduce(grads[feature_key], op=dist.ReduceOp.SUM, group=group)
+            _sum_tensor(grads[feature_key], group=group)
             skip = [feature_key]
     return all_reduce_gaussian_grads(grads, group=group, buckets=buckets, skip=skip)

@@ -27,7 +27,7 @@ def test_two_ranks_relaunch_and_relay_one_line():
     assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["unit"] == "Mpix/s" and d["value"] > 0
     assert "dp2" in d["config"]["parallelism"] and "workload" in d["config"]
     b = d["dp_breakdown"]
-    for k in ("compute_only_ms", "comm_only_ms", "bytes_per_rank", "comm_algbw_GBps", "train_step_allreduce_full_adam_ms",
+    for k in ("compute_only_ms", "comm_only_ms", "comm_only_direct_ms", "bytes_per_rank", "comm_algbw_GBps", "train_step_allreduce_full_adam_ms",
               "train_step_sharded_optimizer_ms", "two_views_per_gpu_ms_per_step", "two_views_per_gpu_mpix_s"):
         assert k in b and b[k] is not None, (k, b)
     assert b["bytes_per_rank"] == 1500 * (59 + 8) * 4
@@ -51,6 +51,7 @@ def test_comm_only_sweeps_the_collective_settings():
     assert d["n_gpus"] == 2 and d["unit"] == "ms" and d["bytes_per_rank"] == 1500 * (59 + 8) * 4
     assert set(d["by_setting"]) >= {"NCCL_ALGO=Ring", "NCCL_ALGO=Tree", "NCCL_ALGO=Ring,NCCL_PROTO=Simple"}
     assert all(("ms" in v) or ("error" in v) for v in d["by_setting"].values())
+    assert d["direct_all_to_all_plus_all_gather"]["ms"] > 0
 
 
 def test_asking_for_more_gpus_than_ranks_is_refused():
