@@ -147,6 +147,24 @@ def _solo_worker(rank, port, out_dir):
         oa.step()
         sh.step({k: gr[k].clone() for k in pb})
     res["sharded_ok"] = np.array([float(all(torch.equal(pa[k], pb[k]) for k in pa))])
+    # the direct exchange (all-to-all + local sum + all-gather) through RCCL on the device: with one rank the "sum" is the tensor
+    # itself - ragged length, a row slice, as a handle - and the whole overlapped step with F3DGS_DP_EXCHANGE = direct
+    t1, t2 = torch.randn(1003, 7, device=dev, generator=gen), torch.randn(40, 9, device=dev, generator=gen)
+    w1, w2 = t1.clone(), t2.clone()
+    dp.all_reduce_direct(t1)
+    h = dp.all_reduce_direct(t2[8:24], async_op=True)
+    h.wait()
+    torch.cuda.synchronize()
+    ok = torch.equal(t1, w1) and torch.equal(t2, w2)
+    dp.EXCHANGE = "direct"
+    leaves = _leaves(dev)
+    dp.dp_step(lambda vid: _run_view(vid, leaves, dev), leaves, [0], overlap=True, rows_leaves={"sh": ("shs",)}, rows_chunks=3)
+    torch.cuda.synchronize()
+    dp.EXCHANGE = "allreduce"
+    for k in KEYS:
+        w = res[f"plain_{k}"].astype(np.float64)
+        ok = ok and bool(np.abs(leaves[k].grad.cpu().numpy() - w).max() <= 1e-4 * np.abs(w).max() + 1e-12)
+    res["direct_ok"] = np.array([float(ok)])
     np.savez(os.path.join(out_dir, "solo.npz"), **res)
     dist.destroy_process_group()
 
@@ -167,6 +185,7 @@ def test_rccl_code_paths_on_one_rank(tmp_path):
             assert np.abs(got[f"{mode}_{k}"] - w).max() <= 1e-4 * np.abs(w).max() + 1e-12, (mode, k)
     assert got["rs_ok"][0] == 1.0
     assert got["sharded_ok"][0] == 1.0
+    assert got["direct_ok"][0] == 1.0
 
 
 def _run_views_fb(leaves, dev):
