@@ -1040,6 +1040,9 @@ def main():
                        "parallelism": "single GPU" if world == 1 else
                        f"view-sharded dp{world} + RCCL all-reduce of (59+C) floats per Gaussian"
                        + ("" if args.no_overlap else ", feature and SH all-reduces started inside the backward pass")},
+            # order of the runs in this process: W warm-up steps, K steps without any event (reported as
+            # step_ms.ms_per_step_without_events), THEN the K timed steps of `value` - the same order as in every earlier round
+            "steps_run_before_the_timed_region": args.warmup + args.steps,
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "n": len(per),
                         "source": "HIP event pair per step on the op's stream, rank 0, in the auxiliary run with all stage events",
                         "ms_per_step_without_events": 1e3 * el_plain / args.steps,
