@@ -990,7 +990,13 @@ def main():
                 n_simd = 4 * (256 if STUB else torch.cuda.get_device_properties(dev).multi_processor_count)
                 c1 = cyc["first_window_sched1"][3]
                 cw = cyc["later_window_sched1"][3]
-                later = max(0, (C - 32 + 63) // 64)
+                # later channel windows as render_bwd_pl.hip plans them: 128 channels (eight waves) where more than 64 remain and
+                # option bwd_wide8 is on, else 64
+                later, left = 0, max(0, C - 32)
+                wide8 = (not STUB) and _C.get_option("bwd_wide8") != 0
+                while left > 0:
+                    left -= min(128, left) if (wide8 and left > 64) else min(64, left)
+                    later += 1
                 evals = stats["bwd_evals"]
                 floor_ms = evals * (c1 + later * cw) / (n_simd * 2.4e9) * 1e3
                 roofline_compute = {
