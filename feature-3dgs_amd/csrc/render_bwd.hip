@@ -737,7 +737,7 @@ int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, con
         a.half = 0;
         a.m44 = opt.bwd_m44;
         a.split16 = opt.bwd_split16;
-        a.bf16 = bf16 ? 1 : 0;
+        a.bf16 = bf16 ? 1 : 0;           // of the first window (geometric sums + 32 channels); see launch_render_backward_pl for the later ones
         launch_render_backward_pl(a, C, s);
 #ifdef F3DGS_DEV
         if (a.dev & 8) {

@@ -1034,6 +1034,11 @@ void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s) {
     // c5 4.65 -> 4.59 - the later window grows from 32 to 48 channels and takes a second staging round)
     a.c0 = 0; a.nc = min(32, C); a.write_base = 1;
     launch_pl<true>(a, s);
+    // Later windows carry feature sums only (weights x gradient planes): nothing behind them amplifies an error of the sums, so
+    // with option bwd_bf16 = -1 they contract on bf16 instructions whatever the frame's conditioning made of the FIRST window
+    // (measured: every blend-level tensor within 0.3 of the gradient bound of the exact contraction at any axis ratio,
+    // profiles/r06_ratio_sweep.txt); bwd_bf16 = 0 keeps them exact.
+    if (options().bwd_bf16 < 0) a.bf16 = 1;
     // later windows: 64 channels on four waves; with the bf16 shape up to 128 channels on eight waves where more than 64 remain
     // (option bwd_wide8, default 1) - every window re-evaluates the blend weights of the whole list
     const bool wide8 = a.bf16 && options().bwd_wide8 != 0;

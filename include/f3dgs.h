@@ -97,7 +97,9 @@ const char* f3dgs_last_error(void);
  *                    the frame holds such a Gaussian - against the ratio in force at that call -, f3dgs_backward looks it
  *                    up), exact fp32 otherwise and when the note is gone: the covariance
  *                    chain behind the blend amplifies an error of the blend-level sums by the square of that ratio
- *                    (measured: within a third of the gradient bound up to 16, outside it from 32 on)
+ *                    (measured: within a third of the gradient bound up to 16, outside it from 32 on);
+ *                    the later channel windows of wide features (C > 32: feature sums only, nothing amplifies them) stay on
+ *                    the bf16 contraction under -1 whatever the first window took
  *   "bwd_bf16_max_ratio"  (default 16) the axis ratio up to which bwd_bf16 = -1 takes the bf16 contraction
  *   "bwd_wide8"      bf16 shape of the pixel-lane blend backward, feature widths above 96: 1 (default) later channel windows of
  *                    up to 128 channels on eight waves per tile (four of them evaluate the blend weights, all eight contract)

@@ -389,10 +389,10 @@ def test_bf16_and_fp32_contractions_agree_on_harsh_inputs(kind, P, W, H, option)
         assert split[k] <= 1.0 + 2.0 * noise[k], (k, split[k], noise[k])
 
 
-def _needle_scene(ratio, shape="needle", P=20000, seed=71):
+def _needle_scene(ratio, shape="needle", P=20000, seed=71, C=32):
     """The synthetic family with scales (s, s / ratio, s / ratio) ["needle"] or (s, s, s / ratio) ["disc"]."""
     from synth import make_scene
-    sc = make_scene(P=P, C=32, width=320, height=200, seed=seed, with_depth_grad=True, scale_lo=0.02, scale_hi=0.2)
+    sc = make_scene(P=P, C=C, width=320, height=200, seed=seed, with_depth_grad=True, scale_lo=0.02, scale_hi=0.2)
     s = sc["scales"][:, :1]
     sc["scales"] = (torch.cat([s, s / ratio, s / ratio], dim=1) if shape == "needle" else torch.cat([s, s, s / ratio], dim=1)).contiguous()
     return sc
@@ -433,6 +433,27 @@ def test_contraction_precision_follows_the_conditioning_of_the_frame(shape, rati
         option("bwd_bf16_max_ratio", 100000 if not want_bf16 else 1)
         run_hip(sc)
         assert _C.last_backward_contraction() == (0 if want_bf16 else 1)
+
+
+def test_later_channel_windows_stay_on_the_bf16_contraction_on_needle_frames(option):
+    """Under bwd_bf16 = -1 a frame with needles takes the exact contraction for the FIRST window (the geometric sums feed the
+    covariance chain) - and keeps the bf16 contraction for the later windows of a wide feature: they carry feature sums only,
+    which nothing amplifies.  C = 200 at an axis ratio of 64: the feature gradient of every channel stays within half the
+    gradient bound of the all-exact result (+ what two exact runs differ by), and so does every other blend-level tensor."""
+    from diff_gaussian_rasterization import _C
+    sc = _needle_scene(64, "needle", P=12000, C=200)
+    _o, g_auto = run_hip(sc)
+    assert _C.last_backward_contraction() == 0          # (reported for the first window)
+    option("bwd_bf16", 0)
+    _o, g0 = run_hip(sc)
+    _o, g0b = run_hip(sc)
+    for k in ("dL_dsemantic_feature", "dL_dmeans2D", "dL_dopacity", "dL_dsh"):
+        d, n = _bound_distance(g_auto[k], g0[k]), _bound_distance(g0b[k], g0[k])
+        print(k, round(d, 3), round(n, 3))
+        assert d <= 0.5 + 2.0 * n, (k, d, n)
+    # channels 32.. went through the bf16 windows: not bit-equal to the exact run's, while channels 0..31 differ by the order of the sums only
+    fa, f0 = g_auto["dL_dsemantic_feature"].reshape(-1, 200), g0["dL_dsemantic_feature"].reshape(-1, 200)
+    assert float(np.abs(fa[:, 32:] - f0[:, 32:]).max()) > 0.0
 
 
 @pytest.mark.parametrize("name", ["fwd_solo", "fwd_wide", "bwd_order", "bwd_m44", "bwd_wide8"])
