@@ -755,6 +755,7 @@ def main():
         bwd_bf16_active = True
     else:       # what the last backward call of the runs above actually contracted with
         bwd_bf16_active = bool(_C.last_backward_contraction() == 1)
+    bwd_hybrid = (not STUB) and _C.last_backward_contraction() == 2
     fp32_exact = None
     if bwd_bf16_active and not V:
         # the same K steps with every contraction of the blend backward on exact-fp32 matrix instructions (option bwd_bf16 = 0):
@@ -1027,7 +1028,8 @@ def main():
             "dtype": dtype_label, "data": "stub" if STUB else "synthetic",
             "blend_kernels": blend_label,
             "options": {k: _C.get_option(k) for k in ("feature_mfma", "bwd_bf16", "bwd_bf16_max_ratio", "bwd_pl", "tile_cull")},
-            "blend_backward_contraction": "bf16 two-term" if bwd_bf16_active else "exact fp32",
+            "blend_backward_contraction": "bf16 two-term" if bwd_bf16_active else
+                                          ("hybrid: bf16 feature / colour blocks, exact-fp32 moment block" if bwd_hybrid else "exact fp32"),
             "ms_per_step_fp32_exact": fp32_exact["ms_per_step"] if fp32_exact else (ms_per_step if not bwd_bf16_active else None),
             "fp32_exact": ({**fp32_exact,
                             "value_mpix_s": world * W * H / 1e6 / (fp32_exact["ms_per_step"] * 1e-3),

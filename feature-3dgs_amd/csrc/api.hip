@@ -113,7 +113,7 @@ struct StageTimer {
     bool on;
     bool blend_only;      // option profile = 2: only the two blend kernels are bracketed (4 events per step instead of 11)
     hipEvent_t prev;
-    explicit StageTimer(hipStream_t st) : s(st), on(profiling()), blend_only(options().profile == 2), prev(nullptr) {
+    explicit StageTimer(hipStream_t st, bool allowed = true) : s(st), on(allowed && profiling()), blend_only(options().profile == 2), prev(nullptr) {
         if (on && !blend_only) {
             {
                 std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -232,6 +232,8 @@ const OptionDesc kOptions[] = {
     {"fwd_wide", "F3DGS_FWD_WIDE", &Options::fwd_wide, 1},
     {"fwd_solo", "F3DGS_FWD_SOLO", &Options::fwd_solo, 1},
     {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},
+    {"sync_free", "F3DGS_SYNC_FREE", &Options::sync_free, 0},
+    {"instance_capacity", "F3DGS_INSTANCE_CAPACITY", &Options::instance_capacity, 0},
 #ifdef F3DGS_DEV
     {"dev", "F3DGS_DEV_BITS", &Options::dev, 0},
 #endif
@@ -273,38 +275,72 @@ namespace {
 // the binning of view v + 1 with the blend kernels of view v, dp.py) never share a slot.  The words are allocated portable and
 // mapped, and the kernel that stores the totals receives the DEVICE-side address of the mapping for the device it runs on.
 struct CountReadback {
-    uint32_t* host = nullptr;       // host address (read by this thread)
+    uint32_t* host = nullptr;       // host address (read by this thread): [0] entries of our lists, [1] the reference's count, [2] long-axis flag (kernel-written);
+                                    // [3] entries the last enqueued frame provided for (host-written); [4] sticky: an emit wave of a sync-free frame found no room (kernel-written, cleared by f3dgs_forward_counts)
     uint32_t* dev = nullptr;        // the same words as the current device sees them (written by a kernel)
     hipEvent_t done = nullptr;
     int device = -1;
     hipStream_t stream = nullptr;
+    bool in_graph = false;          // a captured graph holds `dev`: the slot is never recycled
 };
-CountReadback* count_readback(hipStream_t s) {
-    thread_local std::vector<CountReadback> slots;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    for (CountReadback& rb : slots)
-        if (rb.device == dev && rb.stream == s) return &rb;
+// What this thread last read of a device's counts: the provision of the next sync-free frame (option instance_capacity = 0) and the
+// num_rendered a captured call returns (f3dgs.h: the count of a frame replayed from a graph is read with f3dgs_forward_counts).
+struct CountHint { bool known = false; uint32_t own = 0, ref = 0; };
+thread_local CountHint g_count_hint[64];
+thread_local const uint32_t* g_last_forward_words = nullptr;
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusActive;
+}
+// A stream that is being captured into a graph must not allocate: every eager call leaves one SPARE slot per device behind
+// (stream = kSpareSlot), which the first captured call on a new stream takes over.
+const hipStream_t kSpareSlot = reinterpret_cast<hipStream_t>(~uintptr_t(0));
+bool make_count_slot(std::vector<CountReadback>& slots, int dev, hipStream_t s) {
     CountReadback rb;
     void* p = nullptr;
-    if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
     rb.host = static_cast<uint32_t*>(p);
     void* d = nullptr;
     if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || hipEventCreateWithFlags(&rb.done, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipHostFree(p);
-        return nullptr;
+        return false;
     }
     rb.dev = static_cast<uint32_t*>(d);
     rb.device = dev;
     rb.stream = s;
-    if (slots.size() >= 64) {       // a caller that churns through streams: recycle the oldest slot
-        (void)hipEventDestroy(slots.front().done);
-        (void)hipHostFree(slots.front().host);
-        slots.erase(slots.begin());
+    memset(p, 0, 64);
+    if (slots.size() >= 64) {       // a caller that churns through streams: recycle the oldest slot no graph holds
+        for (size_t i = 0; i < slots.size(); i++)
+            if (!slots[i].in_graph && slots[i].stream != kSpareSlot) {
+                (void)hipEventDestroy(slots[i].done);
+                (void)hipHostFree(slots[i].host);
+                slots.erase(slots.begin() + (long)i);
+                break;
+            }
     }
     slots.push_back(rb);
-    return &slots.back();
+    return true;
+}
+// (the returned pointer is good until this thread's next call of this function)
+CountReadback* count_readback(hipStream_t s, bool may_create) {
+    thread_local std::vector<CountReadback> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    auto find = [&](hipStream_t key) -> CountReadback* {
+        for (CountReadback& rb : slots)
+            if (rb.device == dev && rb.stream == key) return &rb;
+        return nullptr;
+    };
+    if (!may_create) {      // (a stream under capture: no allocation, no event creation)
+        if (CountReadback* rb = find(s)) return rb;
+        if (CountReadback* spare = find(kSpareSlot)) { spare->stream = s; return spare; }
+        return nullptr;
+    }
+    if (!find(kSpareSlot)) (void)make_count_slot(slots, dev, kSpareSlot);      // (a missing spare only matters to a later capture)
+    if (!find(s) && !make_count_slot(slots, dev, s)) return nullptr;
+    return find(s);
 }
 }  // namespace
 
@@ -426,7 +462,22 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // 4K); larger grids take the three-kernel passes
     const bool onesweep = options().sort_onesweep != 0 && tiles <= 65536;
 
-    StageTimer tm(s);
+    // Option sync_free / a stream under graph capture (f3dgs.h, "Sync-free forward"): the host does not wait for the instance
+    // count between the depth sort and the emission.  The binning buffer is carved for a CAPACITY, the emit kernel and the tile
+    // sort take the count from the device's word, and the count is read behind the LAST launch of the call (too small a
+    // provision: the binning and the blend run once more with the exact length).  Under capture nothing is read at all.
+    const bool capturing = stream_is_capturing(s);
+    const bool sync_free = options().sync_free != 0 && !onesweep;
+    if (capturing && !sync_free)
+        return fail(F3DGS_ERR_UNSUPPORTED, "the stream is being captured into a graph: the forward call reads the instance count on the host "
+                    "unless option sync_free = 1 (and sort_onesweep = 0)");
+    if (capturing && debug) return fail(F3DGS_ERR_UNSUPPORTED, "debug = 1 synchronises after every stage: not inside a graph capture");
+    int dev_index = 0;
+    HIP_TRY(hipGetDevice(&dev_index));
+    if (dev_index < 0 || dev_index >= 64) return fail(F3DGS_ERR_UNSUPPORTED, "device index %d", dev_index);
+    CountHint& hint = g_count_hint[dev_index];
+
+    StageTimer tm(s, !capturing);
     // K1: projection, culling, SH colour, tile counts
     const int cull = tile_cull_enabled();
     launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, vp, radii,
@@ -437,9 +488,14 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // Both instance totals are final here.  Their read-back (the counterpart of rasterizer_impl.cu:283) is
     // requested now and awaited only after the depth sort has been enqueued, so the host round
     // trip hides behind ~0.1 ms of GPU work instead of idling the device.
-    CountReadback* rbp = count_readback(s);
-    if (!rbp) return fail(F3DGS_ERR_ALLOC, "pinned read-back buffer / event creation failed");
+    CountReadback* rbp = count_readback(s, !capturing);
+    if (!rbp)
+        return capturing ? fail(F3DGS_ERR_UNSUPPORTED, "graph capture: run one forward call on this stream (same host thread) before capturing - "
+                                "the pinned count words are allocated on a stream's first call")
+                         : fail(F3DGS_ERR_ALLOC, "pinned read-back buffer / event creation failed");
     CountReadback& rb = *rbp;
+    if (capturing) rb.in_graph = true;
+    g_last_forward_words = rb.host;
     if (onesweep) {
         HIP_TRY(hipMemcpyAsync(rb.host, geom.counters, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(rb.done, s));
@@ -448,7 +504,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // depth sort of the Gaussians (ids start in index order -> ties keep ascending id).  Three-kernel flavour: its
     // first kernel adds up the totals and stores them into the pinned host words itself (no totals / copy launches);
     // rb.done is recorded right behind that kernel.
-    const TotalsJob tj = {geom.ref_partial, (P + 255) / 256, geom.counters, rb.dev, rb.done};
+    const TotalsJob tj = {geom.ref_partial, (P + 255) / 256, geom.counters, rb.dev, capturing ? nullptr : rb.done};
     if (onesweep) launch_depth_sort_onesweep(geom, (size_t)P, s);
     else HIP_TRY(launch_depth_sort(geom.depth_key, geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, geom.hist, &tj, s));
     if ((rc = check_debug(debug, s, "depth sort"))) return rc;
@@ -458,57 +514,91 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // instance offsets in depth order (three-kernel flavour only; the single-pass emit scans on the fly)
     if (!onesweep)
         launch_offset_sums(geom.tiles_touched, order, (size_t)P, geom.scan_tmp, geom.scan_sub, s);
-    HIP_TRY(hipEventSynchronize(rb.done));
-    // [0] instances in our lists, [1] the reference's bounding-rectangle count
-    const uint32_t counts[2] = {rb.host[0], rb.host[1]};
+
+    // [0] instances in our lists, [1] the reference's bounding-rectangle count,
     // [2] != 0: a visible Gaussian of the frame is longer than bwd_bf16_max_ratio times its width (the single-pass flavour of the
     // binning does not produce the word: "unknown" reads as "yes")
-    note_frame(geom_ptr, (onesweep || rb.host[2] != 0u) ? 1.f : 0.f);
-    const uint32_t N = counts[0];
-    if (N >= (1u << 30) || counts[1] >= (1u << 31)) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^30 instances");
-    if (num_rendered) *num_rendered = (int)counts[1];
+    bool known = false;           // the host holds this frame's counts
+    uint32_t N = 0, n_ref = 0, cap = 0;
+    auto read_counts = [&]() -> int {
+        HIP_TRY(hipEventSynchronize(rb.done));
+        N = rb.host[0]; n_ref = rb.host[1];
+        note_frame(geom_ptr, (onesweep || rb.host[2] != 0u) ? 1.f : 0.f);
+        hint.known = true; hint.own = N; hint.ref = n_ref;
+        known = true;
+        if (N >= (1u << 30) || n_ref >= (1u << 31)) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^30 instances");
+        return F3DGS_OK;
+    };
+    if (sync_free && (options().instance_capacity > 0 || hint.known)) {
+        const unsigned long long want = options().instance_capacity > 0 ? (unsigned long long)options().instance_capacity
+                                                                        : (unsigned long long)hint.own + hint.own / 4 + 4096ull;
+        cap = (uint32_t)std::min(want, (1ull << 30) - 1ull);
+    } else if (capturing) {
+        return fail(F3DGS_ERR_UNSUPPORTED, "graph capture: no provision for the instance lists - run one forward call on this thread and device "
+                    "before capturing, or set option instance_capacity");
+    } else {      // the blocking read of the reference (and a sync-free thread's first frame on a device)
+        if ((rc = read_counts())) return rc;
+        cap = N;
+    }
     tm.mark("scan+sync");
-
-    BinState::carve(nullptr, N, &bin_bytes, tiles);
-    char* bin_ptr = binning_resize(binning_ctx, bin_bytes);
-    if (!bin_ptr) return fail(F3DGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
-    BinState bin = BinState::carve(bin_ptr, N, nullptr, tiles);
 
     const int bits = tile_bits((int)tiles);
     const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
-    // result must land in (tile_sorted, point_list) == the "A" side
-    uint32_t* in_tile = (passes % 2 == 0) ? bin.tile_sorted : bin.tile_tmp;
-    uint32_t* in_id = (passes % 2 == 0) ? bin.point_list : bin.id_tmp;
-    if (onesweep) {
-        HIP_TRY(hipMemsetAsync(img.tile_len, 0, tiles * sizeof(uint32_t), s));
-        // emits, builds the tile digit histograms, presets the ranges
-        launch_emit_scan(P, geom, bin, order, vp.gx, vp.gy, cull, in_tile, in_id, N, bin.ranges_enc, s);
-        if ((rc = check_debug(debug, s, "emit"))) return rc;
-        tm.mark("emit");
-        launch_tile_sort_onesweep(geom, bin, N, passes, bin.ranges_enc, s);   // the final pass also records the tile ranges
-        if ((rc = check_debug(debug, s, "tile sort"))) return rc;
-        tm.mark("tile_sort");
-    } else {
-        if (N == 0) {
+    BinState bin;
+    for (;;) {
+        const uint32_t n_carve = known ? N : cap;           // entries the binning buffer holds in this round
+        BinState::carve(nullptr, n_carve, &bin_bytes, tiles);
+        char* bin_ptr = binning_resize(binning_ctx, bin_bytes);
+        if (!bin_ptr) return fail(F3DGS_ERR_ALLOC, "binning buffer allocation of %zu bytes failed", bin_bytes);
+        bin = BinState::carve(bin_ptr, n_carve, nullptr, tiles);
+        rb.host[3] = n_carve;
+        // result must land in (tile_sorted, point_list) == the "A" side
+        uint32_t* in_tile = (passes % 2 == 0) ? bin.tile_sorted : bin.tile_tmp;
+        uint32_t* in_id = (passes % 2 == 0) ? bin.point_list : bin.id_tmp;
+        if (onesweep) {
+            HIP_TRY(hipMemsetAsync(img.tile_len, 0, tiles * sizeof(uint32_t), s));
+            // emits, builds the tile digit histograms, presets the ranges
+            launch_emit_scan(P, geom, bin, order, vp.gx, vp.gy, cull, in_tile, in_id, N, bin.ranges_enc, s);
+            if ((rc = check_debug(debug, s, "emit"))) return rc;
+            tm.mark("emit");
+            launch_tile_sort_onesweep(geom, bin, N, passes, bin.ranges_enc, s);   // the final pass also records the tile ranges
+            if ((rc = check_debug(debug, s, "tile sort"))) return rc;
+            tm.mark("tile_sort");
+        } else if (known && N == 0) {
             // all-ones = "no entry yet" for both halves of the encoded ranges (see BinState::ranges_enc)
             HIP_TRY(hipMemsetAsync(bin.ranges_enc, 0xFF, tiles * sizeof(uint2), s));
             HIP_TRY(hipMemsetAsync(img.tile_len, 0, tiles * sizeof(uint32_t), s));
         } else {
-            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, bin.ranges_enc, img.tile_len, s);   // presets the ranges too
+            // presets the ranges too; a captured frame that finds no room raises the slot's sticky word (the host of an eager frame
+            // learns it from the count)
+            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, bin.ranges_enc, img.tile_len, n_carve,
+                                  capturing ? rb.dev + 4 : nullptr, s);
             if ((rc = check_debug(debug, s, "emit"))) return rc;
             tm.mark("emit");
             // the final pass also records the tile ranges
-            launch_radix_sort_pairs(bin.tile_sorted, bin.point_list, bin.tile_tmp, bin.id_tmp, N, bits, bin.hist, true,
-                                    bin.ranges_enc, s);
+            launch_radix_sort_pairs(bin.tile_sorted, bin.point_list, bin.tile_tmp, bin.id_tmp, n_carve, bits, bin.hist, true,
+                                    bin.ranges_enc, s, known ? nullptr : geom.counters);
             if ((rc = check_debug(debug, s, "tile sort"))) return rc;
             tm.mark("tile_sort");
         }
-    }
 
-    launch_render_forward(vp, C, bin.ranges_enc, img.ranges, bin.point_list, geom.rec, semantic_feature, img.final_T,
-                          img.n_contrib, out_color, out_feature_map, out_depth, img.tile_len, s);
-    if ((rc = check_debug(debug, s, "render"))) return rc;
-    tm.mark("render_fwd");
+        launch_render_forward(vp, C, bin.ranges_enc, img.ranges, bin.point_list, geom.rec, semantic_feature, img.final_T,
+                              img.n_contrib, out_color, out_feature_map, out_depth, img.tile_len, s);
+        if ((rc = check_debug(debug, s, "render"))) return rc;
+        tm.mark("render_fwd");
+        if (known || capturing) break;
+        // sync-free: the count is read HERE, behind the last launch of the call (it was final right behind the first kernel of
+        // the depth sort, so the wait is over by now); a frame that found no room is run again, with the exact length
+        if ((rc = read_counts())) return rc;
+        if (N <= cap) break;
+    }
+    if (capturing) {
+        // nothing of this frame is known to the host: the contraction of the blend backward provides for a long axis, and the
+        // caller gets the last count this thread read on the device (>= 1: the backward call only asks whether anything was listed)
+        note_frame(geom_ptr, 1.f);
+        n_ref = std::max(1u, hint.ref);
+    }
+    if (num_rendered) *num_rendered = (int)n_ref;
     HIP_TRY(hipGetLastError());
     return F3DGS_OK;
 }
@@ -583,15 +673,17 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     // the exact shape up to a ratio of 16 and leaves it from 32 on - where two runs of the EXACT shape differ by more than a
     // bound as well.  So: bf16 while no visible Gaussian of the frame is longer than bwd_bf16_max_ratio (default 16) times its
     // width, exact fp32 otherwise - and exact when the forward call's note is gone.
-    bool use_bf16 = options().bwd_bf16 > 0;
+    // 1: bf16 two-term everywhere; 2: hybrid - bf16 feature / colour blocks, the moment block (what the chain amplifies) on exact
+    // fp32 matrix instructions; 0: exact fp32 everywhere (option bwd_bf16 = 0 only)
+    int contraction = options().bwd_bf16 > 0 ? 1 : 0;
     if (options().bwd_bf16 < 0) {
         float long_axis = 1.f;       // what the forward call of this frame noted (against bwd_bf16_max_ratio as it was THEN)
-        use_bf16 = frame_axis_ratio(geom_buffer, &long_axis) && long_axis == 0.f;
+        contraction = (frame_axis_ratio(geom_buffer, &long_axis) && long_axis == 0.f) ? 1 : 2;
     }
     if (R > 0) {
         const int ran = launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,
                                                dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, img.tile_len, img.tile_order,
-                                               lowres.gx ? &lowres : nullptr, use_bf16, s);
+                                               lowres.gx ? &lowres : nullptr, contraction, s);
         g_last_bwd_bf16.store(ran);
     }
     if ((rc = check_debug(debug, s, "render backward"))) return rc;

@@ -85,7 +85,7 @@ __device__ __forceinline__ void run_totals_job(const TotalsJob& tj) {
         uint32_t ref = 0, own = 0, arm = 0;
         for (int k = 0; k < THREADS / 64; k++) { ref += shc[0][k]; own += shc[1][k]; arm = max(arm, shc[2][k]); }
         // [0] entries of our lists, [1] the reference's count, [2] != 0: some visible Gaussian has a long axis (preprocess_kernel)
-        tj.counters[0] = own; tj.counters[1] = ref; tj.counters[2] = arm;
+        tj.counters[0] = own; tj.counters[1] = ref; tj.counters[2] = arm; tj.counters[3] = 0u;    // ([3]: the emit kernel, later in the frame)
         if (tj.host) {
             __hip_atomic_store(&tj.host[0], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&tj.host[1], ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -98,10 +98,14 @@ __device__ __forceinline__ void run_totals_job(const TotalsJob& tj) {
 template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
                                                                   int shift, uint32_t nb,
-                                                                  uint32_t* __restrict__ hist, TotalsJob tj) {
+                                                                  uint32_t* __restrict__ hist, TotalsJob tj,
+                                                                  const uint32_t* __restrict__ n_dev) {
     constexpr int BINS = 1 << BITS;
     constexpr int CHUNK = SORT_THREADS * ITEMS;
     __shared__ uint32_t h[BINS];
+    // n_dev (sync-free forward): the launch is sized by a CAPACITY n, the item count is the device's word (clamped to the capacity);
+    // workgroups behind the last item write their zero column of the histogram matrix and nothing else
+    if (n_dev) n = min(n, (size_t)*n_dev);
     if (tj.partial && blockIdx.x == 0) run_totals_job<SORT_THREADS>(tj);
     for (int d = threadIdx.x; d < BINS; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
@@ -147,10 +151,14 @@ __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
                      uint32_t nb, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
-                     uint2* __restrict__ ranges_enc) {
+                     uint2* __restrict__ ranges_enc, const uint32_t* __restrict__ n_dev) {
     constexpr int BINS = 1 << BITS;
     constexpr int CHUNK = SORT_THREADS * ITEMS;
     constexpr int BPT = BINS / SORT_THREADS;   // bins per thread in the offset phase
+    if (n_dev) {        // (see radix_hist_kernel) a launch sized by a capacity: the workgroups behind the last item have nothing to move
+        n = min(n, (size_t)*n_dev);
+        if ((size_t)blockIdx.x * CHUNK >= n) return;
+    }
     __shared__ uint32_t cnt[4][BINS];
     __shared__ uint32_t sh[8];
     // REORDER: the chunk is first sorted inside LDS so that the global stores of a wave run over consecutive
@@ -457,10 +465,12 @@ struct SmallSortLds {
 template <bool RANGES>
 __global__ void __launch_bounds__(SMALL_SORT_THREADS)
 small_sort_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-                  uint32_t* __restrict__ vals_out, uint32_t n, int passes, TotalsJob tj, uint2* __restrict__ ranges_enc) {
+                  uint32_t* __restrict__ vals_out, uint32_t n, int passes, TotalsJob tj, uint2* __restrict__ ranges_enc,
+                  const uint32_t* __restrict__ n_dev) {
     extern __shared__ __attribute__((aligned(16))) char small_sort_smem[];
     SmallSortLds& L = *reinterpret_cast<SmallSortLds*>(small_sort_smem);
     constexpr int ITEMS = SMALL_SORT_ITEMS, NW = SMALL_SORT_THREADS / 64;
+    if (n_dev) n = min(n, *n_dev);       // (sync-free forward) n is a capacity, the item count is the device's word
     if (tj.partial) run_totals_job<SMALL_SORT_THREADS>(tj);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -583,27 +593,30 @@ bool small_sort_usable() {
 // the tile sort (twice the instances, and the LDS reorder pays more on longer runs: 0.119 vs 0.128 ms with 8).
 template <int BITS, int ITEMS>
 static hipError_t radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n, int shift,
-                             uint32_t* hist, hipStream_t s, uint2* ranges_enc = nullptr, const TotalsJob* tj = nullptr) {
+                             uint32_t* hist, hipStream_t s, uint2* ranges_enc = nullptr, const TotalsJob* tj = nullptr,
+                             const uint32_t* n_dev = nullptr) {
     hipError_t rc = hipSuccess;
     constexpr int BINS = 1 << BITS;
     static_assert(ITEMS >= SORT_ITEMS, "the histogram buffers are sized for SORT_ITEMS keys per thread");
     const uint32_t nb = (uint32_t)((n + SORT_THREADS * ITEMS - 1) / (SORT_THREADS * ITEMS));
     uint32_t* totals = hist + (size_t)BINS * nb;
     hipLaunchKernelGGL((radix_hist_kernel<BITS, ITEMS>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, n, shift, nb, hist,
-                       tj ? *tj : TotalsJob{nullptr, 0, nullptr, nullptr});
+                       tj ? *tj : TotalsJob{nullptr, 0, nullptr, nullptr}, n_dev);
     if (tj && tj->ready) rc = hipEventRecord(tj->ready, s);        // the totals are final behind this launch
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(BINS), dim3(256), 0, s, hist, nb, totals);
     if (ranges_enc && BITS <= 8)
         hipLaunchKernelGGL((radix_scatter_kernel<BITS, ITEMS, true, true>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko, vo, n,
-                           shift, nb, hist, totals, ranges_enc);
+                           shift, nb, hist, totals, ranges_enc, n_dev);
     else
         hipLaunchKernelGGL((radix_scatter_kernel<BITS, ITEMS, (BITS <= 8), false>), dim3(nb), dim3(SORT_THREADS), 0, s, ki, vi, ko,
-                           vo, n, shift, nb, hist, totals, (uint2*)nullptr);
+                           vo, n, shift, nb, hist, totals, (uint2*)nullptr, n_dev);
     return rc;
 }
 
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
-                             uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s) {
+                             uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s, const uint32_t* n_dev) {
+    // n_dev (sync-free forward, api.hip): `n` is the CAPACITY the buffers were carved for and every launch is sized by it; the
+    // kernels take the item count from the device word (clamped to n)
     // Input is expected in A when (#passes even) == result_in_a, else in B; the caller arranges that.
     const int passes = (nbits + RADIX_BITS - 1) / RADIX_BITS;
     if (n == 0 || passes == 0) return;
@@ -617,10 +630,10 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
         const TotalsJob none = {nullptr, 0, nullptr, nullptr};
         if (ranges_enc)
             hipLaunchKernelGGL(small_sort_kernel<true>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, ki, vi, ko, vo,
-                               (uint32_t)n, passes, none, ranges_enc);
+                               (uint32_t)n, passes, none, ranges_enc, n_dev);
         else
             hipLaunchKernelGGL(small_sort_kernel<false>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, ki, vi, ko, vo,
-                               (uint32_t)n, passes, none, (uint2*)nullptr);
+                               (uint32_t)n, passes, none, (uint2*)nullptr, n_dev);
         return;
     }
     for (int p = 0; p < passes; p++) {
@@ -628,7 +641,7 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
         uint32_t* vi = in_a ? val_a : val_b;
         uint32_t* ko = in_a ? key_b : key_a;
         uint32_t* vo = in_a ? val_b : val_a;
-        (void)radix_pass<RADIX_BITS, 16>(ki, vi, ko, vo, n, p * RADIX_BITS, hist, s, p == passes - 1 ? ranges_enc : nullptr);
+        (void)radix_pass<RADIX_BITS, 16>(ki, vi, ko, vo, n, p * RADIX_BITS, hist, s, p == passes - 1 ? ranges_enc : nullptr, nullptr, n_dev);
         in_a = !in_a;
     }
 }
@@ -647,7 +660,7 @@ hipError_t launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* va
             if (tj->ready) rc = hipEventRecord(tj->ready, s);
         }
         hipLaunchKernelGGL(small_sort_kernel<false>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, keys, (const uint32_t*)nullptr,
-                           key_a, val_a, (uint32_t)n, 4, TotalsJob{nullptr, 0, nullptr, nullptr}, (uint2*)nullptr);
+                           key_a, val_a, (uint32_t)n, 4, TotalsJob{nullptr, 0, nullptr, nullptr}, (uint2*)nullptr, (const uint32_t*)nullptr);
         return rc;
     }
     if (n > 200000) {

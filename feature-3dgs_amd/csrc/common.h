@@ -72,7 +72,7 @@ struct GeomState {
     uint32_t* scan_tmp;       // scan_blocks(P) + 8      list entries of every chunk of SCAN_CHUNK Gaussians in depth order
     uint32_t* scan_sub;       // 64 x scan_blocks(P)     list entries of every run of 64 Gaussians in depth order
     uint32_t* ref_partial;    // per preprocess workgroup: bounding-rectangle tile counts, then list-entry counts, then 1 if a visible Gaussian of the workgroup has a long axis
-    uint32_t* counters;       // 16 words: [0] = instances in the (culled) lists, [1] = reference num_rendered
+    uint32_t* counters;       // 16 words: [0] = instances in the (culled) lists, [1] = reference num_rendered, [2] != 0: a visible Gaussian has a long axis, [3] = entries the binning buffer was carved for (0 until the emit kernel ran)
     // -- control words of the single-pass sorts (lookback.h).  depth_hist is zeroed by preprocess_kernel (it is
     //    accumulated by the kernel after it); everything from lb_words on is zeroed by sort_prologue_kernel.
     uint32_t* depth_hist;     // 4 x 256 digit totals of the depth keys
@@ -184,6 +184,8 @@ struct Options {
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
     int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)
     int sort_onesweep;   // 1: single-pass radix passes with decoupled look-back (measured slower on MI355X; default 0)
+    int sync_free;       // 1: the forward call never waits for the instance count in the middle of its enqueue - binning buffers of a CAPACITY, kernels that read the count on the device, the count checked behind the last launch (one retry) - and can be captured in a HIP graph (default 0)
+    int instance_capacity;   // sync_free: entries of the instance lists to provide for (0, default: 1.25 x the thread's last count on the device + 4096)
 #ifdef F3DGS_DEV
     int dev;             // development builds only (make DEV=1): work-skipping experiments, never in a release library
 #endif
@@ -226,11 +228,16 @@ void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, ui
 // (key_in,val_in) and the *_tmp buffers are clobbered.  key_out/val_out may alias the tmp or in buffers
 // only as arranged by the caller through the pass parity (see binning.hip).
 // `ranges_enc` (optional): the final pass records every tile's [min, max + 1) output positions (BinState::ranges_enc)
+// `n_dev` (optional; the sync-free forward): n is the capacity the buffers were carved for and sizes every launch, the kernels
+// take the item count from this device word (clamped to n)
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
-                             uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s);
+                             uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s, const uint32_t* n_dev = nullptr);
 // also presets `ranges_enc` (all-ones = "no entry yet") for the final tile-sort pass and zeroes `tile_len`
+// `cap`: entries the instance arrays hold; a wave whose range of the list ends behind it stores nothing and raises `overflow`
+// (device-visible host word, may be null).  The capacity is left in GeomState::counters[3] for readers of the binning buffer.
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
-                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, hipStream_t s);
+                           uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, uint32_t cap,
+                           uint32_t* overflow, hipStream_t s);
 // single-pass flavour (option sort_onesweep): offsets by decoupled look-back inside the emit kernel, which also
 // produces the tile digit histograms, presets `ranges` for the final sort pass and zero-fills b.tile_status
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,
@@ -298,13 +305,14 @@ struct LowresGrad {
 };
 // `tile_len` / `tile_order`: the pixel-lane kernel takes its tiles longest walk first (order built here, one small launch)
 // `dL_dfeat` may be null when `lowres` carries the feature-map gradient (given both, the kernel adds them)
-// `bf16`: contractions of the pixel-lane kernel on bf16 matrix instructions with two-term operands (api.hip decides; see option
-// bwd_bf16).  Returns what ran: 1 the pixel-lane kernel in its bf16 shape, 0 anything exact (its fp32 shape, the instance-lane kernel).
+// `contraction` of the pixel-lane kernel (api.hip decides; see option bwd_bf16): 1 bf16 matrix instructions with two-term operands,
+// 2 the hybrid shape (first window: bf16 feature / colour blocks, the moment block in exact fp32), 0 exact fp32.
+// Returns what ran: 1 / 2 the pixel-lane kernel in that shape, 0 anything exact (its fp32 shape, the instance-lane kernel).
 int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
                            const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                            const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
-                           bool bf16, hipStream_t s);
+                           int contraction, hipStream_t s);
 struct BwdArgs;
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s);     // render_bwd_pl.hip
 void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, hipStream_t s);

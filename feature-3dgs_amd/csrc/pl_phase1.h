@@ -50,9 +50,12 @@ struct P1Pixel {
 // Returns the rows (bit e = entry e) that blended at some pixel of the wave.
 // NOLDS (tools/ubench/blend_stream.hip only): four records read once per chunk stand in for all sixteen (one extra vector
 // instruction per entry moves the mean) and the stores are dropped: the vector-pipe stream alone.
-template <bool GEO, int SCHED, bool NOLDS = false>
+// S32 (the hybrid shape of the first window): s leaves as ONE fp32 value - into the quadrant's fp32 tile at s_tile + (s_ofs ^ 16 e),
+// the layout of the exact-fp32 shape (render_bwd_pl.hip: PlShared) - instead of two bf16 terms; w keeps its two terms.
+template <bool GEO, int SCHED, bool NOLDS = false, bool S32 = false>
 __device__ __forceinline__ uint32_t pl_phase1_bf16(const PlRec* rc, const P1Pixel& px, uint32_t pos_hi, float& T, float& S,
-                                                   char* tiles, uint32_t sofs) {
+                                                   char* tiles, uint32_t sofs, char* s_tile = nullptr, uint32_t s_ofs = 0) {
+    static_assert(!S32 || (GEO && !NOLDS), "the fp32 s tile belongs to the first window");
     static_assert(ALPHA_MAX == 0.99f, "literal in the clamp below");
     uint32_t tm = 0;
     struct Ent {
@@ -137,14 +140,18 @@ __device__ __forceinline__ uint32_t pl_phase1_bf16(const PlRec* rc, const P1Pixe
                 case 3: dLa = fmaf(Tb, x.qd, nSf); break;                 // dL/dalpha
                 case 4: S = fmaf(wv, x.qd, S); break;
                 case 5: sv = x.au * dLa; break;
-                case 6: h = pack_bf16(wv, sv); break;                     // low half: w high term, high half: s high term
+                case 6: h = pack_bf16(wv, S32 ? 0.f : sv); break;         // low half: w high term, high half: s high term
                 case 7: hl = h << 16; break;
-                case 8: hh = h & 0xFFFF0000u; break;
+                case 8: if constexpr (!S32) hh = h & 0xFFFF0000u; break;
                 case 9: rw = fmaf(x.al, Tb, -__uint_as_float(hl)); break; // residual of the unrounded product
-                case 10: rs = fmaf(x.au, dLa, -__uint_as_float(hh)); break;
-                case 11: m = pack_bf16(rw, rs); break;
+                case 10: if constexpr (!S32) rs = fmaf(x.au, dLa, -__uint_as_float(hh)); break;
+                case 11: m = pack_bf16(rw, S32 ? 0.f : rs); break;
                 case 12:
-                    if constexpr (NOLDS) {
+                    if constexpr (S32) {
+                        *reinterpret_cast<uint16_t*>(bp) = (uint16_t)h;
+                        *reinterpret_cast<uint16_t*>(bp + BF_TERM) = (uint16_t)m;
+                        *reinterpret_cast<float*>(s_tile + (s_ofs ^ (uint32_t)(16 * e))) = sv;
+                    } else if constexpr (NOLDS) {
                         asm volatile("" : "+v"(h), "+v"(m));      // (the values stay alive; nothing is stored)
                         sink = h;
                     } else {

@@ -687,7 +687,8 @@ int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, con
                            const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                            const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
-                           bool bf16, hipStream_t s) {
+                           int contraction, hipStream_t s) {
+    const bool bf16 = contraction != 0;
     BwdArgs a;
     a.order = nullptr;
     a.glow = nullptr; a.gscale = nullptr; a.gHg = a.gWg = 0; a.gsy = a.gsx = 0.f;
@@ -737,7 +738,7 @@ int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, con
         a.half = 0;
         a.m44 = opt.bwd_m44;
         a.split16 = opt.bwd_split16;
-        a.bf16 = bf16 ? 1 : 0;           // of the first window (geometric sums + 32 channels); see launch_render_backward_pl for the later ones
+        a.bf16 = contraction;            // of the first window (geometric sums + 32 channels); see launch_render_backward_pl for the later ones
         launch_render_backward_pl(a, C, s);
 #ifdef F3DGS_DEV
         if (a.dev & 8) {

@@ -148,9 +148,14 @@ static_assert(PL_TAPS_OFS + 32 * sizeof(float4) + 34 * sizeof(int) <= sizeof(PlS
 //   Every later window re-evaluates the blend weights of the whole list (phase 1); with twice the columns per window half as many
 //   windows do.  Waves 0..3 are the quadrant waves of phase 1 (and take channels 0..63 in phase 2), waves 4..7 only contract
 //   (channels 64..127) and flush; two workgroups per CU (the same sixteen waves per CU as four workgroups of four).
-template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false, bool BF = false, int NWV = 4>
+// S32 (round 6; bf16 shape, first window): the HYBRID shape - feature and colour / depth blocks on bf16 matrix instructions as in the
+//   bf16 shape, the MOMENT block (the sums the covariance chain amplifies) on exact-fp32 matrix instructions from an fp32 tile
+//   of s: what a frame with needle-shaped Gaussians takes under option bwd_bf16 = -1.  Only the moment wave's SIMD is held by
+//   fp32 matrix instructions (2048 cycles per chunk); in the exact shape all four are.
+template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false, bool BF = false, int NWV = 4, bool S32 = false>
 __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     static_assert(!BF || (P1_NE == 1 && !M44), "the bf16 shape takes its entries one at a time and has no 4 x 4 colour path");
+    static_assert(!S32 || (BF && GEO && NWV == 4), "the hybrid shape is a first window of the bf16 shape");
     static_assert(NWV == 4 || (NWV == 8 && BF && !GEO), "eight waves: later windows of the bf16 shape only");
     constexpr int NTH = 64 * NWV;                    // threads per workgroup
     constexpr int FS = NWV == 8 ? PL_FS8 : PL_FS;    // dwords per row of the flush tile
@@ -358,6 +363,15 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                     // (at most six significant bits: exact in bf16); one operand for the four quadrants, kept in Bbf[0]
                     const float k0c = col == 0 ? 1.f : 0.f, k1c = col == 1 ? 1.f : 0.f, k2c = col == 2 ? 1.f : 0.f;
                     const float k3c = col == 3 ? 1.f : 0.f, k4c = col == 4 ? 1.f : 0.f, k5c = col == 5 ? 1.f : 0.f;
+                    if constexpr (S32) {
+                        // hybrid: the fp32 operand of the exact shape - step t of a quadrant's tile contracts pixel (4 (t & 1) + kk,
+                        // t >> 1) at K index kk - kept (as bits) in the registers the bf16 operand would take
+#pragma unroll
+                        for (int t = 0; t < 16; t++) {
+                            const float uu = (float)(4 * (t & 1) + kk) - 3.5f, vv = (float)(t >> 1) - 3.5f;
+                            Bbf[0][t >> 3][t & 7] = __float_as_uint(fmaf(fmaf(k3c, uu, fmaf(k4c, vv, k1c)), uu, fmaf(fmaf(k5c, vv, k2c), vv, k0c)));
+                        }
+                    } else
 #pragma unroll
                     for (int ks = 0; ks < 2; ks++) {
                         const float vv = (float)(4 * ks + kk) - 3.5f;
@@ -651,7 +665,16 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
                 };
                 if constexpr (BF) {
                     const P1Pixel px{pxf, pyf, last, dR, dG, dB, dD};
-                    tm = pl_phase1_bf16<GEO, PL_SCHED>(rc, px, pos_hi, T, S, bf_tiles, bf_sofs);
+                    if constexpr (S32) {
+                        // this lane's slot in row 0 of the quadrant's fp32 s tile, rebuilt per chunk (see wofs_b: nothing lane-derived
+                        // lives across the walk)
+                        const int fl = fresh_lane(), sx = fl & 7, sy = fl >> 3;
+                        const int sc = 16 * (sy >> 1) + 4 * (sx & 3) + 2 * (sy & 1) + (sx >> 2);
+                        const uint32_t s_ofs = (uint32_t)(((sc >> 2) * PL_ROW + ((sc >> 2) & 7) * 4 + (sc & 3)) * 4);
+                        tm = pl_phase1_bf16<GEO, 0, false, true>(rc, px, pos_hi, T, S, bf_tiles, bf_sofs,     // (schedule 0: the pinned pipeline costs this shape 12 spilled registers)
+                                                                        bf_tiles + q * BF_QUAD + 2 * BF_TERM, s_ofs);
+                    } else
+                        tm = pl_phase1_bf16<GEO, PL_SCHED>(rc, px, pos_hi, T, S, bf_tiles, bf_sofs);
                 } else {
                     phase1(std::integral_constant<int, P1_NE>{}, std::integral_constant<bool, P1_PREF>{});
                 }
@@ -686,6 +709,22 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 #pragma unroll
                         for (int qd = 0; qd < 4; qd++) {
                             f32x4 acc0 = zero4, acc1 = zero4;
+                            if constexpr (S32) {
+                                // hybrid: s is an fp32 tile (the exact shape's layout) behind the quadrant's two w planes
+                                if ((tt >> (16 + qd)) & 1u) {
+                                    const float* const st = reinterpret_cast<const float*>(bf_tiles + qd * BF_QUAD + 2 * BF_TERM);
+                                    const int rofs0 = kk * PL_ROW + (col ^ kk) * 4, rofs1 = rofs0 ^ 16;
+#pragma unroll
+                                    for (int u = 0; u < 4; u++) {
+                                        const float4 av = *reinterpret_cast<const float4*>(st + ((u & 1) ? rofs1 : rofs0) + u * 4 * PL_ROW);
+                                        auto B = [&](int t) { return __uint_as_float(Bbf[0][t >> 3][t & 7]); };
+                                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, B(4 * u + 0), acc0, 0, 0, 0);
+                                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, B(4 * u + 1), acc1, 0, 0, 0);
+                                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, B(4 * u + 2), acc0, 0, 0, 0);
+                                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, B(4 * u + 3), acc1, 0, 0, 0);
+                                    }
+                                }
+                            } else
                             if ((tt >> (16 + qd)) & 1u) {
 #pragma unroll
                                 for (int ks = 0; ks < 2; ks++) {
@@ -959,6 +998,10 @@ template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false, bool BF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel(BwdArgs a) {
     render_backward_pl_body<GEO, P1_NE, P1_PREF, M44, BF>(a);
 }
+// first window, hybrid shape (see S32 in the body)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel_hyb(BwdArgs a) {
+    render_backward_pl_body<true, 1, true, false, true, 4, true>(a);
+}
 // later windows of more than 64 channels, bf16 shape: eight waves per tile (see NWV in the body)
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel8(BwdArgs a) {
     render_backward_pl_body<false, 1, true, false, true, 8>(a);
@@ -1014,6 +1057,9 @@ void launch_pl(const BwdArgs& a, hipStream_t s) {
     if (variant == 4) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, false>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
     if (variant == 5) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 2, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
 #endif
+    if constexpr (GEO) {
+        if (a.bf16 == 2) { hipLaunchKernelGGL(render_backward_pl_kernel_hyb, dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
+    }
     if (a.bf16) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true, false, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
     if constexpr (GEO) {
         if (a.m44) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
@@ -1038,7 +1084,7 @@ void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s) {
     // with option bwd_bf16 = -1 they contract on bf16 instructions whatever the frame's conditioning made of the FIRST window
     // (measured: every blend-level tensor within 0.3 of the gradient bound of the exact contraction at any axis ratio,
     // profiles/r06_ratio_sweep.txt); bwd_bf16 = 0 keeps them exact.
-    if (options().bwd_bf16 < 0) a.bf16 = 1;
+    if (options().bwd_bf16 < 0 || a.bf16 == 2) a.bf16 = 1;
     // later windows: 64 channels on four waves; with the bf16 shape up to 128 channels on eight waves where more than 64 remain
     // (option bwd_wide8, default 1) - every window re-evaluates the blend weights of the whole list
     const bool wide8 = a.bf16 && options().bwd_wide8 != 0;

@@ -407,16 +407,17 @@ def _bound_distance(a, b):
                                                    ("needle", 32, False), ("needle", 256, False), ("disc", 64, False)])
 def test_contraction_precision_follows_the_conditioning_of_the_frame(shape, ratio, want_bf16, option):
     """Option bwd_bf16 = -1 (the default): the blend backward contracts on bf16 matrix instructions (two-term operands) while no
-    visible Gaussian of the frame is longer than 16 times its width, and on exact-fp32 matrix instructions otherwise - the
-    covariance chain behind the blend (backward.cu:144-341) amplifies an error of the blend-level sums by the square of that
-    ratio (profiles/r06_ratio_sweep.txt).  Where the bf16 shape is chosen EVERY gradient element is within half the north-star
-    bound (1e-3 |g| + 1e-5 max|g|) of the exact shape's; where it is not, the result IS the exact shape's (up to the order of
-    the atomic sums).  `bwd_bf16_max_ratio` moves the switch."""
+    visible Gaussian of the frame is longer than 16 times its width; otherwise the first window takes the HYBRID shape - the
+    moment block, whose sums the covariance chain behind the blend (backward.cu:144-341) amplifies by the square of that ratio
+    (profiles/r06_ratio_sweep.txt), on exact-fp32 matrix instructions, the feature and colour blocks on bf16 as before.  Where
+    the bf16 shape is chosen EVERY gradient element is within half the north-star bound (1e-3 |g| + 1e-5 max|g|) of the exact
+    shape's; where the hybrid is, the chain's tensors are the exact shape's up to the order of the sums and every other tensor
+    is within half a bound.  `bwd_bf16_max_ratio` moves the switch."""
     from diff_gaussian_rasterization import _C
     sc = _needle_scene(ratio, shape)
     assert _C.get_option("bwd_bf16") == -1 and _C.get_option("bwd_bf16_max_ratio") == 16
     _o, g_auto = run_hip(sc)
-    assert _C.last_backward_contraction() == (1 if want_bf16 else 0)
+    assert _C.last_backward_contraction() == (1 if want_bf16 else 2)     # 2: the hybrid shape (moment block in exact fp32)
     option("bwd_bf16", 0)
     _o, g0 = run_hip(sc)
     assert _C.last_backward_contraction() == 0
@@ -425,14 +426,18 @@ def test_contraction_precision_follows_the_conditioning_of_the_frame(shape, rati
     worst = {k: _bound_distance(g_auto[k], g0[k]) for k in g_auto if g_auto[k] is not None and g_auto[k].size}
     noise = {k: _bound_distance(g0b[k], g0[k]) for k in worst}
     print(shape, ratio, "auto vs exact:", {k: round(v, 3) for k, v in worst.items()}, "exact vs exact again:", {k: round(v, 3) for k, v in noise.items()})
-    if want_bf16:      # (otherwise both are runs of the exact kernel, a bound or more apart on such input by the order of the atomic sums alone)
-        for k in worst:
-            assert worst[k] <= 0.5 + 2.0 * noise[k], (k, worst[k], noise[k])
+    for k in worst:
+        if not want_bf16 and k in ("dL_dscales", "dL_drotations", "dL_dcov3D"):
+            # hybrid against exact: the moment sums are the same fp32 sums in another order - on such input the chain puts that a
+            # bound or more apart, as it does two runs of the exact kernel
+            assert worst[k] <= 1.0 + 4.0 * noise[k], (k, worst[k], noise[k])
+            continue
+        assert worst[k] <= 0.5 + 2.0 * noise[k], (k, worst[k], noise[k])
     # the threshold is an option: raised, the needles take the bf16 shape; lowered to 1, nothing does
     if ratio > 1:
         option("bwd_bf16_max_ratio", 100000 if not want_bf16 else 1)
         run_hip(sc)
-        assert _C.last_backward_contraction() == (0 if want_bf16 else 1)
+        assert _C.last_backward_contraction() == (2 if want_bf16 else 1)
 
 
 def test_later_channel_windows_stay_on_the_bf16_contraction_on_needle_frames(option):
@@ -443,7 +448,7 @@ def test_later_channel_windows_stay_on_the_bf16_contraction_on_needle_frames(opt
     from diff_gaussian_rasterization import _C
     sc = _needle_scene(64, "needle", P=12000, C=200)
     _o, g_auto = run_hip(sc)
-    assert _C.last_backward_contraction() == 0          # (reported for the first window)
+    assert _C.last_backward_contraction() == 2          # (reported for the first window: the hybrid shape)
     option("bwd_bf16", 0)
     _o, g0 = run_hip(sc)
     _o, g0b = run_hip(sc)
