@@ -346,9 +346,11 @@ CountReadback* count_readback(hipStream_t s, bool may_create) {
 
 extern "C" {
 
-int f3dgs_version(void) { return 30400; }   // 3.4.0 (major * 10000 + minor * 100 + patch): 3.1 seven untested shape knobs removed, f3dgs_option_name; 3.2 f3dgs_set_feature_grad_lowres; 3.3 option bwd_bf16, 16-byte alignment checked; 3.4 bwd_bf16 = -1 (by the frame's conditioning), f3dgs_last_backward_contraction
+int f3dgs_version(void) { return 30500; }   // 3.5.0 (major * 10000 + minor * 100 + patch): 3.5 options sync_free / instance_capacity, graph capture, f3dgs_forward_counts; 3.1 seven untested shape knobs removed, f3dgs_option_name; 3.2 f3dgs_set_feature_grad_lowres; 3.3 option bwd_bf16, 16-byte alignment checked; 3.4 bwd_bf16 = -1 (by the frame's conditioning), f3dgs_last_backward_contraction
 
 int f3dgs_last_backward_contraction(void) { return g_last_bwd_bf16.load(); }
+
+const uint32_t* f3dgs_forward_counts(void) { return g_last_forward_words; }
 
 int f3dgs_set_option(const char* name, int value) {
     if (!name) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null option name");
@@ -659,7 +661,9 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     ImageState img = ImageState::carve(const_cast<char*>(image_buffer), HW, tiles, nullptr);
     float* grec = static_cast<float*>(scratch);
 
-    StageTimer tm(s);
+    const bool capturing = stream_is_capturing(s);      // (a step replayed from a graph: no events, no debug synchronisation)
+    if (capturing && debug) return fail(F3DGS_ERR_UNSUPPORTED, "debug = 1 synchronises after every stage: not inside a graph capture");
+    StageTimer tm(s, !capturing);
     HIP_TRY(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
     // (f3dgs_set_feature_grad_accumulate: the caller's buffer already holds the sum over its earlier views)
     // Clearing this buffer ahead of time on a side stream - under the blend forward, forked right in front of it - was measured
@@ -841,12 +845,17 @@ int f3dgs_debug_read(const char* what, int P, int C, int R, int width, int heigh
     const size_t HW = (size_t)width * height, tiles = (size_t)gx * gy;
     GeomState geom = GeomState::carve(const_cast<char*>(geom_buffer), P, nullptr);
     // the binning buffer was carved with the length of OUR instance list (counters[0]), not with R
-    uint32_t n_list = (uint32_t)R;
+    // ... or, by a sync-free forward call, for a capacity: counters[3] holds what the emit kernel was given
+    uint32_t n_list = (uint32_t)R, n_carved = (uint32_t)R;
     if (P > 0 && geom_buffer) {
-        HIP_TRY(hipMemcpyAsync(&n_list, geom.counters, 4, hipMemcpyDeviceToHost, s));
+        uint32_t words[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(words, geom.counters, sizeof words, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        n_list = words[0];
+        n_carved = words[3] ? words[3] : words[0];
+        if (n_list > n_carved) n_list = n_carved;       // (a frame that found no room: nothing behind the capacity was written)
     }
-    BinState bin = BinState::carve(const_cast<char*>(binning_buffer), n_list, nullptr);
+    BinState bin = BinState::carve(const_cast<char*>(binning_buffer), n_carved, nullptr);
     ImageState img = ImageState::carve(const_cast<char*>(image_buffer), HW, tiles, nullptr);
     const std::string w(what);
     const void* src = nullptr;

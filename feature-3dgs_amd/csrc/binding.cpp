@@ -518,6 +518,18 @@ PYBIND11_MODULE(_C, m) {
           "callable(row_begin, row_end, grads: dict) run inside rasterize_gaussians_backward after each of `chunks` row ranges of the "
           "per-Gaussian gradients is final on the stream; None removes it");
     m.def("set_option", [](const std::string& name, int value) { check_status(f3dgs_set_option(name.c_str(), value), "set_option"); });
+    m.def("forward_counts", []() -> py::object {
+        const uint32_t* w = f3dgs_forward_counts();
+        if (!w) return py::none();
+        // (volatile: kernel-written pinned words)
+        const volatile uint32_t* v = w;
+        return py::make_tuple((long long)v[0], (long long)v[1], (long long)v[2], (long long)v[3], (long long)v[4]);
+    }, "(entries of the instance lists, the reference's num_rendered, long-axis flag, entries provided for, sticky no-room word) of the "
+       "calling thread's most recent forward call - final once that frame's work has completed; None before the first call");
+    m.def("forward_counts_address", []() { return (uintptr_t)f3dgs_forward_counts(); },
+          "host address of the five uint32 words of forward_counts() (0 before the first call): a captured step keeps it and reads the words after a replay");
+    m.def("clear_forward_overflow", [](uintptr_t address) { if (address) reinterpret_cast<volatile uint32_t*>(address)[4] = 0u; },
+          "clears the sticky no-room word behind an address returned by forward_counts_address()");
     m.def("last_backward_contraction", []() { return f3dgs_last_backward_contraction(); },
           "1: the last blend backward of this process contracted on bf16 matrix instructions (two-term operands); 0: exact fp32; -1: none yet");
     m.def("get_option", [](const std::string& name) {

@@ -63,7 +63,7 @@ extern "C" {
  * resizeFunctional() of rasterize_points.cu:27-33. */
 typedef char* (*f3dgs_resize_fn)(void* ctx, size_t nbytes);
 
-/* Library / ABI version: major*10000 + minor*100 + patch (3.3.0 -> 30300). */
+/* Library / ABI version: major*10000 + minor*100 + patch (3.5.0 -> 30500). */
 int f3dgs_version(void);
 
 /* Thread-local message of the last error raised on this host thread. */
@@ -111,6 +111,22 @@ const char* f3dgs_last_error(void);
  *                    sums added in the flush), 0 by columns only
  *   "fwd_wide"       blend forward: 1 (default) 128-channel windows where more than 64 channels remain
  *   "fwd_solo"       blend forward: 1 (default) one 64-thread workgroup per quadrant wave
+ *   "sync_free"      0 (default): f3dgs_forward waits for the instance count where the reference does
+ *                    (rasterizer_impl.cu:283; here behind the enqueue of the depth sort) and carves the binning buffer for
+ *                    exactly that length.  1: SYNC-FREE FORWARD - the binning buffer is carved for a provision
+ *                    ("instance_capacity"), the emit kernel and the tile sort read the count on the device, and the host reads
+ *                    it only behind the last launch of the call (it has long been final by then); a frame that found no room
+ *                    runs its binning and blend once more with the exact length before the call returns.  Results are
+ *                    bit-identical to sync_free = 0.  With sync_free = 1 the call may also run on a stream that is being
+ *                    CAPTURED into a HIP graph (hipStreamBeginCapture / torch.cuda.graph): then nothing is read on the host,
+ *                    *num_rendered receives the last count this thread read on the device (at least 1), the blend backward of
+ *                    bwd_bf16 = -1 provides for a long axis (hybrid first window), and a replayed frame that finds no room is
+ *                    VOID: it raises word [4] of f3dgs_forward_counts(), which the owner of the graph checks after a replay
+ *                    (and captures again with more room).  Capturing needs one eager forward call on the same host thread and
+ *                    device beforehand (pinned count words, a provision); "debug", "profile" and "sort_onesweep" are not
+ *                    available inside a capture.
+ *   "instance_capacity"  sync_free = 1: entries of the instance lists to provide for; 0 (default): 1.25 x the last count this
+ *                    thread read on the device + 4096
  * Unknown names return F3DGS_ERR_INVALID_ARGUMENT.
  */
 int f3dgs_set_option(const char* name, int value);
@@ -120,6 +136,12 @@ int f3dgs_get_option(const char* name, int* value /* host pointer, out */);
  * ran its blend stage with: 1 the pixel-lane kernel in its two-term bf16 shape, 0 an exact-fp32 shape (pixel-lane fp32 or the
  * instance-lane kernel), -1 no backward call yet.  A diagnostic for tests and benchmarks. */
 int f3dgs_last_backward_contraction(void);
+/* The pinned host words the most recent f3dgs_forward of this THREAD reports its frame in (kernel-written unless said otherwise;
+ * NULL before the first call): [0] entries of the instance lists, [1] the reference's num_rendered, [2] != 0: a visible Gaussian
+ * has a long axis (option bwd_bf16_max_ratio), [3] entries the binning buffer was carved for (written by the host at enqueue),
+ * [4] sticky - an emit wave of a CAPTURED frame found no room (the caller clears it).  They are final once the frame's work has
+ * completed (synchronise first); a replayed graph writes the words of the call it was captured from. */
+const uint32_t* f3dgs_forward_counts(void);
 /* Enumeration: the name of option `index` (0, 1, ...), NULL past the end. */
 const char* f3dgs_option_name(int index);
 
