@@ -548,6 +548,7 @@ def main():
     ap.add_argument("--views-per-iter", type=int, default=0,
                     help="V views of the same Gaussians per step over all GPUs (V / N per rank, pipelined over two streams, "
                          "gradients accumulated across the views): total work is fixed as N grows - the line says scaling: strong")
+    ap.add_argument("--graph", action="store_true", help="also time the step replayed from a HIP graph (always done for c1)")
     ap.add_argument("--valu", action="store_true",
                     help="library option feature_mfma = 0: every blend kernel on the vector pipe only (the north-star-literal configuration)")
     ap.add_argument("--densify-every", type=int, default=0,
@@ -774,6 +775,37 @@ def main():
         finally:
             _C.set_option("profile", 0)
             _C.set_option("bwd_bf16", opt_bf16)
+        for i in range(2):
+            step(i)
+
+    # The same step replayed from a HIP graph (graph_step.CapturedStep: option sync_free, no host read in the forward call).
+    # Small scenes are bound by the host's enqueue time (c1: ~30 launches of 5 - 40 us); the reference cannot be captured - it
+    # reads num_rendered back in the middle of its forward call (rasterizer_impl.cu:283).  One upstream-gradient set (the
+    # graph's inputs are static); the frame's lists are checked against the provision after the timed replays.
+    graph_replay = None
+    if not STUB and dist is None and not V and (args.graph or args.config == "c1"):
+        try:
+            from graph_step import CapturedStep
+            cs = CapturedStep(lambda: step(0)).capture()
+            for _ in range(max(3, args.warmup)):
+                cs.replay()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                cs.replay()
+            sync()
+            el_g = time.perf_counter() - t0
+            fits = bool(cs.check())
+            cnt = cs.counts()
+            graph_replay = {"ms_per_step": 1e3 * el_g / args.steps, "value_mpix_s": W * H / 1e6 / (el_g / args.steps),
+                            "steps": args.steps, "fits_the_provision": fits,
+                            "list_entries": cnt[0] if cnt else None, "entries_provided_for": cnt[3] if cnt else None,
+                            "blend_backward_contraction": {1: "bf16 two-term", 2: "hybrid (a captured frame is never read by the host: bwd_bf16 = -1 provides for a long axis)",
+                                                           0: "exact fp32"}.get(_C.last_backward_contraction()),
+                            "note": "the whole forward + backward of the op as ONE hipGraphLaunch per step (torch.cuda.graph); eager steps above it in this line"}
+            del cs
+        except Exception as exc:      # noqa: BLE001 (a leg beside the headline: report, never fail the line)
+            graph_replay = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         for i in range(2):
             step(i)
 
@@ -1027,9 +1059,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if V else "weak", "vs_baseline": None,
             "dtype": dtype_label, "data": "stub" if STUB else "synthetic",
             "blend_kernels": blend_label,
-            "options": {k: _C.get_option(k) for k in ("feature_mfma", "bwd_bf16", "bwd_bf16_max_ratio", "bwd_pl", "tile_cull")},
+            "options": {k: _C.get_option(k) for k in ("feature_mfma", "bwd_bf16", "bwd_bf16_max_ratio", "bwd_pl", "tile_cull", "sync_free")},
             "blend_backward_contraction": "bf16 two-term" if bwd_bf16_active else
                                           ("hybrid: bf16 feature / colour blocks, exact-fp32 moment block" if bwd_hybrid else "exact fp32"),
+            "graph_replay": graph_replay,
             "ms_per_step_fp32_exact": fp32_exact["ms_per_step"] if fp32_exact else (ms_per_step if not bwd_bf16_active else None),
             "fp32_exact": ({**fp32_exact,
                             "value_mpix_s": world * W * H / 1e6 / (fp32_exact["ms_per_step"] * 1e-3),

@@ -60,6 +60,24 @@ bool frame_axis_ratio(const void* geom, float* axis_ratio) {
     return false;
 }
 
+// Zero-fill inside a graph capture: hipMemsetAsync is captured as a memset node, and with the HIP runtime this library meets
+// under PyTorch (ROCm 7.0) such nodes fill with the wrong pattern from the graph's SECOND replay on (measured: every row of
+// dL_dsemantic_feature began with 16 bytes of a kernel-argument block; exp/graph_probe2.py).  A kernel node has no such
+// problem, so a captured call clears its buffers with this kernel; eager calls keep hipMemsetAsync (6+ TB/s).
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint4* __restrict__ p, size_t n16, int tail_words) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail_words) reinterpret_cast<uint32_t*>(p + n16)[threadIdx.x] = 0u;
+}
+hipError_t zero_fill(void* p, size_t bytes, bool capturing, hipStream_t s) {
+    if (!capturing || (reinterpret_cast<uintptr_t>(p) & 15) || (bytes & 3)) return hipMemsetAsync(p, 0, bytes, s);
+    if (bytes == 0) return hipSuccess;
+    const size_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((n16 + 255) / 256, 256 * 16));
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, s, static_cast<uint4*>(p), n16, (int)((bytes & 15) / 4));
+    return hipGetLastError();
+}
+
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -574,7 +592,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
             // presets the ranges too; a captured frame that finds no room raises the slot's sticky word (the host of an eager frame
             // learns it from the count)
             launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, bin.ranges_enc, img.tile_len, n_carve,
-                                  capturing ? rb.dev + 4 : nullptr, s);
+                                  known ? nullptr : geom.counters, capturing ? rb.dev + 4 : nullptr, s);
             if ((rc = check_debug(debug, s, "emit"))) return rc;
             tm.mark("emit");
             // the final pass also records the tile ranges
@@ -664,12 +682,12 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     const bool capturing = stream_is_capturing(s);      // (a step replayed from a graph: no events, no debug synchronisation)
     if (capturing && debug) return fail(F3DGS_ERR_UNSUPPORTED, "debug = 1 synchronises after every stage: not inside a graph capture");
     StageTimer tm(s, !capturing);
-    HIP_TRY(hipMemsetAsync(grec, 0, (size_t)P * GREC * sizeof(float), s));
+    HIP_TRY(zero_fill(grec, (size_t)P * GREC * sizeof(float), capturing, s));
     // (f3dgs_set_feature_grad_accumulate: the caller's buffer already holds the sum over its earlier views)
     // Clearing this buffer ahead of time on a side stream - under the blend forward, forked right in front of it - was measured
     // at c4 / c5 in round 5: the fill leaves the backward pass (0.32 -> 0.02 ms) and costs the forward blend MORE (1.95 -> 2.41 ms
     // at c4, 3.40 -> 4.07 at c5: its feature-row gathers queue behind 2 - 2.5 GB of writes); profiles/r05_notes.md.
-    if (C > 0 && !g_feature_accumulate) HIP_TRY(hipMemsetAsync(dL_dsemantic_feature, 0, (size_t)P * C * sizeof(float), s));
+    if (C > 0 && !g_feature_accumulate) HIP_TRY(zero_fill(dL_dsemantic_feature, (size_t)P * C * sizeof(float), capturing, s));
     tm.mark("zero");
     // Contraction precision of the blend backward (option bwd_bf16: 1 two-term bf16, 0 exact fp32, -1 by the frame): the
     // covariance chain behind the blend (backward.cu:144-341) amplifies an error of the blend-level sums by the square of a

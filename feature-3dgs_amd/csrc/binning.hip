@@ -103,9 +103,10 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t
     constexpr int BINS = 1 << BITS;
     constexpr int CHUNK = SORT_THREADS * ITEMS;
     __shared__ uint32_t h[BINS];
-    // n_dev (sync-free forward): the launch is sized by a CAPACITY n, the item count is the device's word (clamped to the capacity);
-    // workgroups behind the last item write their zero column of the histogram matrix and nothing else
-    if (n_dev) n = min(n, (size_t)*n_dev);
+    // n_dev (sync-free forward): the launch is sized by a CAPACITY n, the item count is the device's word; workgroups behind the
+    // last item write their zero column of the histogram matrix and nothing else.  A count above the capacity reads as ZERO: the
+    // emit kernel stored nothing for such a frame (the arrays hold what the allocator left there), the tile ranges stay empty
+    if (n_dev) { const size_t nd = *n_dev; n = nd <= n ? nd : 0; }     // (a frame that does not fit is void: nothing was emitted)
     if (tj.partial && blockIdx.x == 0) run_totals_job<SORT_THREADS>(tj);
     for (int d = threadIdx.x; d < BINS; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
@@ -156,7 +157,8 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     constexpr int CHUNK = SORT_THREADS * ITEMS;
     constexpr int BPT = BINS / SORT_THREADS;   // bins per thread in the offset phase
     if (n_dev) {        // (see radix_hist_kernel) a launch sized by a capacity: the workgroups behind the last item have nothing to move
-        n = min(n, (size_t)*n_dev);
+        const size_t nd = *n_dev;
+        n = nd <= n ? nd : 0;
         if ((size_t)blockIdx.x * CHUNK >= n) return;
     }
     __shared__ uint32_t cnt[4][BINS];
@@ -470,7 +472,7 @@ small_sort_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restri
     extern __shared__ __attribute__((aligned(16))) char small_sort_smem[];
     SmallSortLds& L = *reinterpret_cast<SmallSortLds*>(small_sort_smem);
     constexpr int ITEMS = SMALL_SORT_ITEMS, NW = SMALL_SORT_THREADS / 64;
-    if (n_dev) n = min(n, *n_dev);       // (sync-free forward) n is a capacity, the item count is the device's word
+    if (n_dev) { const uint32_t nd = *n_dev; n = nd <= n ? nd : 0u; }       // (sync-free forward) n is a capacity, the item count is the device's word; a frame that does not fit is void
     if (tj.partial) run_totals_job<SMALL_SORT_THREADS>(tj);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;

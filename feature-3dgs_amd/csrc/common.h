@@ -233,11 +233,12 @@ void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, ui
 void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n, int nbits,
                              uint32_t* hist, bool result_in_a, uint2* ranges_enc, hipStream_t s, const uint32_t* n_dev = nullptr);
 // also presets `ranges_enc` (all-ones = "no entry yet") for the final tile-sort pass and zeroes `tile_len`
-// `cap`: entries the instance arrays hold; a wave whose range of the list ends behind it stores nothing and raises `overflow`
-// (device-visible host word, may be null).  The capacity is left in GeomState::counters[3] for readers of the binning buffer.
+// `cap`: entries the instance arrays hold.  `n_dev` (null: cap IS the list length): the device's count - a frame whose count
+// exceeds cap stores nothing and raises `overflow` (device-visible host word, may be null).  The capacity is left in
+// GeomState::counters[3] for readers of the binning buffer.
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
                            uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, uint32_t cap,
-                           uint32_t* overflow, hipStream_t s);
+                           const uint32_t* n_dev, uint32_t* overflow, hipStream_t s);
 // single-pass flavour (option sort_onesweep): offsets by decoupled look-back inside the emit kernel, which also
 // produces the tile digit histograms, presets `ranges` for the final sort pass and zero-fills b.tile_status
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,

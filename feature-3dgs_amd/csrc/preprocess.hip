@@ -534,10 +534,17 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
                       const SplatRec* __restrict__ rec, int gx, int gy, int cull, uint32_t* __restrict__ inst_tile,
                       uint32_t* __restrict__ inst_id, uint2* __restrict__ ranges_enc, uint32_t* __restrict__ tile_len,
                       uint32_t* __restrict__ big_ctl, uint2* __restrict__ big_items, uint32_t cap, uint32_t* __restrict__ cap_word,
-                      uint32_t* __restrict__ overflow) {
+                      const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ overflow) {
     __shared__ uint32_t s_tile[4][EMIT_CAP];
     __shared__ uint32_t s_id[4][EMIT_CAP];
     if (blockIdx.x == 0 && threadIdx.x == 0) *cap_word = cap;
+    // The arrays hold `cap` entries: the exact list length where the host read it before this launch (n_dev null), a provision
+    // where it did not (sync-free forward: n_dev = the device's count).  A frame that does not fit is VOID - no wave stores
+    // anything, the tile sort takes its count as zero, the tile ranges stay empty - and the host learns it from the count (for
+    // frames replayed from a graph: from the sticky `overflow` word) and runs the frame again with room.
+    const bool no_room = n_dev && *n_dev > cap;
+    if (no_room && overflow && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // all-ones = "no entry yet" for both halves of the encoded tile ranges (BinState::ranges_enc; the final sort pass,
     // two launches further on, lowers them with atomicMin); zero for the tiles' walk lengths (raised by the blend forward)
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < (uint32_t)(gx * gy); t += gridDim.x * 256) {
@@ -563,13 +570,7 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
     const uint32_t inc = wave_incl_scan(cnt, lane);
     const uint32_t off0 = base + inc - cnt;
     const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
-    // The arrays hold `cap` entries: the exact list length where the host read it before this launch, a provision where it did not
-    // (sync-free forward).  A wave whose range ends behind the capacity stores nothing - the frame is void, the host learns it
-    // from the count (and, for frames replayed from a graph, from the sticky `overflow` word) and runs it again with room.
-    if (base + total > cap || base + total < base) {
-        if (overflow && lane == 0 && total != 0) __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
+    if (no_room || base + total > cap || base + total < base) return;      // (the second test never fires on consistent counts)
     // A splat of more than EMIT_BIG tiles (a Gaussian close to the camera plane of a rotated view: thousands of tiles, up to the
     // whole grid) would keep ONE lane looping for all of them while 63 idle: it is emitted by a whole wave (emit_big_splat) - by
     // whichever wave of the launch gets to it first (emit_big_steal).  A wave that holds such splats (wave-uniform ballot; rare)
@@ -1105,10 +1106,10 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
 
 void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
                            uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, uint32_t cap,
-                           uint32_t* overflow, hipStream_t s) {
+                           const uint32_t* n_dev, uint32_t* overflow, hipStream_t s) {
     hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.scan_tmp, g.scan_sub,
                        g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc, tile_len, g.big_ctl, g.big_items,
-                       cap, g.counters + 3, overflow);
+                       cap, g.counters + 3, n_dev, overflow);
 }
 
 void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,

@@ -91,7 +91,7 @@ def test_sync_free_step_has_the_blocking_steps_gradients(name, option):
                 continue
             scale = np.abs(v).max() + 1e-30
             noise = np.abs(g0b[k] - v).max() / scale
-            assert np.abs(g[k] - v).max() / scale <= 4 * noise + 1e-6, k
+            assert np.abs(g[k] - v).max() / scale <= 4 * noise + 1e-5, k
 
 
 def _static_step(scene, dev="cuda:0"):
@@ -133,9 +133,11 @@ def _snapshot(outs, grads):
 
 def _close(got, want, again, what):
     for k, v in want.items():
+        if v.size == 0:
+            continue
         scale = np.abs(v).max() + 1e-30
         noise = np.abs(again[k] - v).max() / scale
-        assert np.abs(got[k] - v).max() / scale <= 4 * noise + 1e-6, (what, k)
+        assert np.abs(got[k] - v).max() / scale <= 4 * noise + 1e-5, (what, k)      # (1e-5 max|g|: the absolute part of the gradient bound)
 
 
 @pytest.mark.parametrize("name", ["small", "small-features", "mid"])
@@ -214,6 +216,8 @@ def test_a_captured_backward_provides_for_a_long_axis():
     assert step.check()
     _o, g_got = _snapshot({}, grads)
     for k, v in g_want.items():      # the two shapes agree to well inside the gradient tolerance on a benign scene
+        if v.size == 0:
+            continue
         bound = 1e-3 * np.abs(v) + 1e-5 * np.abs(v).max()
         assert (np.abs(g_got[k] - v) <= 0.5 * bound + 1e-30).all(), k
 
