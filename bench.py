@@ -800,7 +800,8 @@ def main():
             graph_replay = {"ms_per_step": 1e3 * el_g / args.steps, "value_mpix_s": W * H / 1e6 / (el_g / args.steps),
                             "steps": args.steps, "fits_the_provision": fits,
                             "list_entries": cnt[0] if cnt else None, "entries_provided_for": cnt[3] if cnt else None,
-                            "blend_backward_contraction": {1: "bf16 two-term", 2: "hybrid (a captured frame is never read by the host: bwd_bf16 = -1 provides for a long axis)",
+                            "blend_backward_contraction": {1: "bf16 two-term", 2: "hybrid",
+                                                           3: "chosen on the device by the frame's long-axis word (bf16 two-term here unless a visible Gaussian has a long axis: then hybrid); both first-window kernels are launched, one runs",
                                                            0: "exact fp32"}.get(_C.last_backward_contraction()),
                             "note": "the whole forward + backward of the op as ONE hipGraphLaunch per step (torch.cuda.graph); eager steps above it in this line"}
             del cs

@@ -39,7 +39,7 @@ std::atomic<int> g_last_bwd_bf16{-1};  // contraction of the process's last blen
 // thread of its own) - so the value is kept here, process-wide, keyed by (device, geometry buffer): the caller hands that buffer
 // back untouched, and a buffer that has been re-used by a later forward call belongs to that call.  A backward call that finds
 // nothing (a buffer copied elsewhere, more than 256 frames in flight) takes the exact contraction.
-struct FrameNote { int device; const void* geom; float axis_ratio; };      // axis_ratio: 0 no visible Gaussian with a long axis, 1 some
+struct FrameNote { int device; const void* geom; float axis_ratio; };      // axis_ratio: 0 no visible Gaussian with a long axis, 1 some, 2 ask the device (a captured frame)
 std::mutex g_frames_mu;
 std::vector<FrameNote> g_frames;
 void note_frame(const void* geom, float axis_ratio) {
@@ -613,9 +613,10 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
         if (N <= cap) break;
     }
     if (capturing) {
-        // nothing of this frame is known to the host: the contraction of the blend backward provides for a long axis, and the
-        // caller gets the last count this thread read on the device (>= 1: the backward call only asks whether anything was listed)
-        note_frame(geom_ptr, 1.f);
+        // nothing of this frame is known to the host: the blend backward of bwd_bf16 = -1 lets the DEVICE's long-axis word pick its
+        // first window (note 2: both shapes are launched, one runs), and the caller gets the last count this thread read on the
+        // device (>= 1: the backward call only asks whether anything was listed)
+        note_frame(geom_ptr, 2.f);
         n_ref = std::max(1u, hint.ref);
     }
     if (num_rendered) *num_rendered = (int)n_ref;
@@ -701,11 +702,12 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     if (options().bwd_bf16 < 0) {
         float long_axis = 1.f;       // what the forward call of this frame noted (against bwd_bf16_max_ratio as it was THEN)
         contraction = (frame_axis_ratio(geom_buffer, &long_axis) && long_axis == 0.f) ? 1 : 2;
+        if (long_axis == 2.f) contraction = 3;     // a captured frame: decided on the device (GeomState::counters[2])
     }
     if (R > 0) {
         const int ran = launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,
                                                dL_dpix, dL_dfeaturepix, dL_depths, grec, dL_dsemantic_feature, img.tile_len, img.tile_order,
-                                               lowres.gx ? &lowres : nullptr, contraction, s);
+                                               lowres.gx ? &lowres : nullptr, contraction, geom.counters + 2, s);
         g_last_bwd_bf16.store(ran);
     }
     if ((rc = check_debug(debug, s, "render backward"))) return rc;

@@ -307,13 +307,15 @@ struct LowresGrad {
 // `tile_len` / `tile_order`: the pixel-lane kernel takes its tiles longest walk first (order built here, one small launch)
 // `dL_dfeat` may be null when `lowres` carries the feature-map gradient (given both, the kernel adds them)
 // `contraction` of the pixel-lane kernel (api.hip decides; see option bwd_bf16): 1 bf16 matrix instructions with two-term operands,
-// 2 the hybrid shape (first window: bf16 feature / colour blocks, the moment block in exact fp32), 0 exact fp32.
-// Returns what ran: 1 / 2 the pixel-lane kernel in that shape, 0 anything exact (its fp32 shape, the instance-lane kernel).
+// 2 the hybrid shape (first window: bf16 feature / colour blocks, the moment block in exact fp32), 0 exact fp32, 3 (a frame the
+// host never read: inside a graph) 1 or 2 by the device word `gate` (GeomState::counters + 2: != 0 = a visible Gaussian has a
+// long axis) - both first-window kernels are launched, the workgroups of one leave at once.
+// Returns what ran: 1 / 2 / 3 the pixel-lane kernel in that shape, 0 anything exact (its fp32 shape, the instance-lane kernel).
 int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, const uint32_t* point_list,
                            const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                            const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
-                           int contraction, hipStream_t s);
+                           int contraction, const uint32_t* gate, hipStream_t s);
 struct BwdArgs;
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s);     // render_bwd_pl.hip
 void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, hipStream_t s);

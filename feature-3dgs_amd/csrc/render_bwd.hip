@@ -687,10 +687,11 @@ int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, con
                            const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                            const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
-                           int contraction, hipStream_t s) {
+                           int contraction, const uint32_t* gate, hipStream_t s) {
     const bool bf16 = contraction != 0;
     BwdArgs a;
     a.order = nullptr;
+    a.gate = contraction == 3 ? gate : nullptr; a.gate_want = 0;
     a.glow = nullptr; a.gscale = nullptr; a.gHg = a.gWg = 0; a.gsy = a.gsx = 0.f;
     a.m44 = 0; a.split16 = 0; a.bf16 = 0; a.neg_half_w = a.neg_half_h = 0.f;
     const bool low = lowres && lowres->gx && C > 0;

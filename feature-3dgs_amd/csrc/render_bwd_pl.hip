@@ -996,10 +996,14 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 
 template <bool GEO, int P1_NE, bool P1_PREF, bool M44 = false, bool BF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel(BwdArgs a) {
+    if constexpr (GEO && BF) {       // (BwdArgs::gate: one of two launches of a captured frame runs)
+        if (a.gate && ((*a.gate != 0u) != (a.gate_want != 0))) return;
+    }
     render_backward_pl_body<GEO, P1_NE, P1_PREF, M44, BF>(a);
 }
 // first window, hybrid shape (see S32 in the body)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) render_backward_pl_kernel_hyb(BwdArgs a) {
+    if (a.gate && ((*a.gate != 0u) != (a.gate_want != 0))) return;
     render_backward_pl_body<true, 1, true, false, true, 4, true>(a);
 }
 // later windows of more than 64 channels, bf16 shape: eight waves per tile (see NWV in the body)
@@ -1058,6 +1062,14 @@ void launch_pl(const BwdArgs& a, hipStream_t s) {
     if (variant == 5) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 2, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
 #endif
     if constexpr (GEO) {
+        if (a.bf16 == 3) {       // a captured frame: the device's long-axis word picks the shape (both launched, one runs)
+            BwdArgs b = a;
+            b.bf16 = 1; b.gate_want = 0;
+            hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true, false, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, b);
+            b.bf16 = 2; b.gate_want = 1;
+            hipLaunchKernelGGL(render_backward_pl_kernel_hyb, dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, b);
+            return;
+        }
         if (a.bf16 == 2) { hipLaunchKernelGGL(render_backward_pl_kernel_hyb, dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
     }
     if (a.bf16) { hipLaunchKernelGGL((render_backward_pl_kernel<GEO, 1, true, false, true>), dim3(a.gx * a.gy), dim3(256), sizeof(PlShared), s, a); return; }
@@ -1084,7 +1096,8 @@ void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s) {
     // with option bwd_bf16 = -1 they contract on bf16 instructions whatever the frame's conditioning made of the FIRST window
     // (measured: every blend-level tensor within 0.3 of the gradient bound of the exact contraction at any axis ratio,
     // profiles/r06_ratio_sweep.txt); bwd_bf16 = 0 keeps them exact.
-    if (options().bwd_bf16 < 0 || a.bf16 == 2) a.bf16 = 1;
+    if (options().bwd_bf16 < 0 || a.bf16 >= 2) a.bf16 = 1;
+    a.gate = nullptr;
     // later windows: 64 channels on four waves; with the bf16 shape up to 128 channels on eight waves where more than 64 remain
     // (option bwd_wide8, default 1) - every window re-evaluates the blend weights of the whole list
     const bool wide8 = a.bf16 && options().bwd_wide8 != 0;

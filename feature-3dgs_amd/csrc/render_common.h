@@ -108,6 +108,11 @@ struct BwdArgs {
     int m44;                 // pixel-lane kernel, first window: the colour wave on 4 x 4 matrix blocks
     int split16;             // pixel-lane kernel, up to 16 channels: feature and moment blocks split over the waves by quadrants
     int bf16;                // pixel-lane kernel: contractions on bf16 matrix instructions, operands split into two bf16 terms
+    // first window of the pixel-lane kernel inside a graph (contraction 3, api.hip): BOTH the bf16 and the hybrid kernel are
+    // launched and the frame's long-axis word (GeomState::counters[2]) lets exactly one of them run: a workgroup leaves at once
+    // unless (*gate != 0) == (gate_want != 0).  Null: no gate.
+    const uint32_t* gate;
+    int gate_want;
     float neg_half_w, neg_half_h;   // pixel-lane kernel: -W / 2, -H / 2 (the NDC scale of dL/dmean2D, Q8)
     // pixel-lane kernel: feature-map gradient at the loss's resolution, (gHg gWg, C) pixel-major (null: none); dL_dfeat may
     // then be null.  gsy / gsx: the resize scales (H - 1) / (gHg - 1), (W - 1) / (gWg - 1); gscale: device scalar or null

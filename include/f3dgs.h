@@ -120,7 +120,8 @@ const char* f3dgs_last_error(void);
  *                    bit-identical to sync_free = 0.  With sync_free = 1 the call may also run on a stream that is being
  *                    CAPTURED into a HIP graph (hipStreamBeginCapture / torch.cuda.graph): then nothing is read on the host,
  *                    *num_rendered receives the last count this thread read on the device (at least 1), the blend backward of
- *                    bwd_bf16 = -1 provides for a long axis (hybrid first window), and a replayed frame that finds no room is
+ *                    bwd_bf16 = -1 launches both shapes of its first window and the frame's long-axis word lets one of them
+ *                    run on the device, and a replayed frame that finds no room is
  *                    VOID: it raises word [4] of f3dgs_forward_counts(), which the owner of the graph checks after a replay
  *                    (and captures again with more room).  Capturing needs one eager forward call on the same host thread and
  *                    device beforehand (pinned count words, a provision); "debug", "profile" and "sort_onesweep" are not
@@ -133,8 +134,10 @@ int f3dgs_set_option(const char* name, int value);
 int f3dgs_get_option(const char* name, int* value /* host pointer, out */);
 
 /* Which contraction the last f3dgs_backward of this PROCESS (any thread: PyTorch runs the backward pass on an autograd thread)
- * ran its blend stage with: 1 the pixel-lane kernel in its two-term bf16 shape, 0 an exact-fp32 shape (pixel-lane fp32 or the
- * instance-lane kernel), -1 no backward call yet.  A diagnostic for tests and benchmarks. */
+ * ran its blend stage with: 1 the pixel-lane kernel in its two-term bf16 shape, 2 its hybrid shape (first window: feature and
+ * colour blocks on bf16, the moment block on exact-fp32 matrix instructions), 3 one of those two chosen ON THE DEVICE by the
+ * frame's long-axis word (a frame captured into a graph), 0 an exact-fp32 shape (pixel-lane fp32 or the instance-lane kernel),
+ * -1 no backward call yet.  A diagnostic for tests and benchmarks. */
 int f3dgs_last_backward_contraction(void);
 /* The pinned host words the most recent f3dgs_forward of this THREAD reports its frame in (kernel-written unless said otherwise;
  * NULL before the first call): [0] entries of the instance lists, [1] the reference's num_rendered, [2] != 0: a visible Gaussian

@@ -151,8 +151,19 @@ def test_captured_step_replays_the_eager_step(name, option):
     o_want, g_want = _snapshot(outs, grads)
     fn()
     _o, g_again = _snapshot(outs, grads)
-    step = CapturedStep(fn).capture()
-    assert _C.get_option("sync_free") == 0, "the capture leaves the caller's options as they were"
+    # list lengths of the three contents this test replays (scales x 1, x 1.08, x 2.16): the provision sits between the last two
+    n_entries = []
+    with torch.no_grad():
+        base = L["scales"].detach().clone()
+        for f in (1.0, 1.08, 2.16):
+            L["scales"].copy_(base * f)
+            fn()
+            torch.cuda.synchronize()
+            n_entries.append(_C.forward_counts()[0])
+        L["scales"].copy_(base)
+    assert n_entries[0] < n_entries[1] < n_entries[2] - 1, n_entries
+    step = CapturedStep(fn, capacity=(n_entries[1] + n_entries[2]) // 2).capture()
+    assert _C.get_option("sync_free") == 0 and _C.get_option("instance_capacity") == 0, "the capture leaves the caller's options as they were"
     graph_outs = dict(outs)          # the tensors the graph writes (an eager call of fn puts new ones into `outs`)
     for v in grads.values():
         v.zero_()
@@ -164,7 +175,7 @@ def test_captured_step_replays_the_eager_step(name, option):
         assert np.array_equal(o_got[k], o_want[k]), k
     _close(g_got, g_want, g_again, "replay")
     c = step.counts()
-    assert c[0] > 0 and c[3] >= c[0] and c[4] == 0
+    assert c[0] == n_entries[0] and c[3] == (n_entries[1] + n_entries[2]) // 2 and c[4] == 0
 
     # new contents of the static inputs, same graph: every Gaussian eight percent larger - more list entries, inside the provision
     with torch.no_grad():
@@ -176,7 +187,7 @@ def test_captured_step_replays_the_eager_step(name, option):
     step.replay()
     assert step.check() and step.captures == 1
     o_got2, g_got2 = _snapshot(graph_outs, grads)
-    assert step.counts()[0] > c[0]
+    assert step.counts()[0] == n_entries[1]
     for k in o_want2:
         assert np.array_equal(o_got2[k], o_want2[k]), k
     _close(g_got2, g_want2, g_again2, "replay of new contents")
@@ -189,7 +200,7 @@ def test_captured_step_replays_the_eager_step(name, option):
     fn()
     _o, g_again3 = _snapshot(outs, grads)
     step.replay()
-    assert step.counts()[4] == 1 and step.counts()[0] > step.counts()[3]
+    assert step.counts()[4] == 1 and step.counts()[0] == n_entries[2] > step.counts()[3]
     assert step.check() is False and step.captures == 2
     o_got3, g_got3 = _snapshot(outs, grads)         # (the new capture ran fn: `outs` holds the new graph's tensors)
     for k in o_want3:
@@ -198,28 +209,39 @@ def test_captured_step_replays_the_eager_step(name, option):
     assert step.check() and step.captures == 2
 
 
-def test_a_captured_backward_provides_for_a_long_axis():
+@pytest.mark.parametrize("kind", ["benign", "needles"])
+def test_a_captured_backward_picks_its_contraction_on_the_device(kind):
     """bwd_bf16 = -1 (default) chooses the contraction of the blend backward by a word the HOST reads from the frame; a captured
-    frame is never read, so its backward takes the hybrid first window (moment block in exact fp32) whatever the scene holds."""
+    frame is never read.  Its backward launches BOTH shapes of the first window - bf16 two-term and hybrid (moment block in exact
+    fp32) - and the frame's long-axis word lets exactly one of them run: the replayed gradients are the eager default's (which
+    took the bf16 shape on the benign scene, the hybrid on the needles) up to the order of the sums."""
     from graph_step import CapturedStep
     from diff_gaussian_rasterization import _C
+    from test_gpu_parity import _needle_scene
     assert _C.get_option("bwd_bf16") == -1
-    scene = _scene(**SCENES["small-features"])
+    scene = _scene(**SCENES["small-features"]) if kind == "benign" else _needle_scene(64, "needle", P=4000, C=16)
     fn, _L, _outs, grads = _static_step(scene)
     fn()
     torch.cuda.synchronize()
-    assert _C.last_backward_contraction() == 1
+    assert _C.last_backward_contraction() == (1 if kind == "benign" else 2)
     _o, g_want = _snapshot({}, grads)
+    fn()
+    _o, g_again = _snapshot({}, grads)
     step = CapturedStep(fn).capture()
-    assert _C.last_backward_contraction() == 2
-    step.replay()
-    assert step.check()
+    assert _C.last_backward_contraction() == 3
+    for _ in range(2):
+        step.replay()
+    assert step.check() and step.counts()[2] == (0 if kind == "benign" else 1)
     _o, g_got = _snapshot({}, grads)
-    for k, v in g_want.items():      # the two shapes agree to well inside the gradient tolerance on a benign scene
+    for k, v in g_want.items():
         if v.size == 0:
             continue
         bound = 1e-3 * np.abs(v) + 1e-5 * np.abs(v).max()
-        assert (np.abs(g_got[k] - v) <= 0.5 * bound + 1e-30).all(), k
+        noise = float((np.abs(g_again[k] - v) / bound).max())
+        worst = float((np.abs(g_got[k] - v) / bound).max())
+        # the same kernel on the same sums: apart as far as two eager runs are (on needles the covariance chain spreads those)
+        slack = 1.0 if (kind == "needles" and k in ("scales", "rotations")) else 0.25
+        assert worst <= slack + 4.0 * noise, (k, worst, noise)
 
 
 def test_a_capture_without_the_option_is_refused_loudly(option):
