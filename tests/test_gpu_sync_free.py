@@ -153,14 +153,14 @@ def test_captured_step_replays_the_eager_step(name, option):
     _o, g_again = _snapshot(outs, grads)
     # list lengths of the three contents this test replays (scales x 1, x 1.08, x 2.16): the provision sits between the last two
     n_entries = []
-    with torch.no_grad():
-        base = L["scales"].detach().clone()
-        for f in (1.0, 1.08, 2.16):
+    base = L["scales"].detach().clone()
+    for f in (1.0, 1.08, 2.16, 1.0):
+        with torch.no_grad():
             L["scales"].copy_(base * f)
-            fn()
-            torch.cuda.synchronize()
-            n_entries.append(_C.forward_counts()[0])
-        L["scales"].copy_(base)
+        fn()
+        torch.cuda.synchronize()
+        n_entries.append(_C.forward_counts()[0])
+    assert n_entries.pop() == n_entries[0]
     assert n_entries[0] < n_entries[1] < n_entries[2] - 1, n_entries
     step = CapturedStep(fn, capacity=(n_entries[1] + n_entries[2]) // 2).capture()
     assert _C.get_option("sync_free") == 0 and _C.get_option("instance_capacity") == 0, "the capture leaves the caller's options as they were"
