@@ -428,6 +428,7 @@ sort_prologue_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __re
         if (threadIdx.x == 0) {
             counters[1] = shc[0][0] + shc[0][1] + shc[0][2] + shc[0][3];
             counters[0] = shc[1][0] + shc[1][1] + shc[1][2] + shc[1][3];
+            counters[3] = 0u;      // "carved for exactly counters[0] entries" (f3dgs_debug_read; the three-kernel flavour: run_totals_job)
         }
     }
 }
