@@ -31,6 +31,7 @@ thread_local void* g_rows_ready_ctx = nullptr;
 thread_local int g_rows_ready_chunks = 1;
 thread_local int g_feature_accumulate = 0;
 thread_local LowresGrad g_lowres;      // consumed by the next f3dgs_backward of this thread
+thread_local int g_band_begin = 0, g_band_end = 0;     // f3dgs_set_tile_band: tile rows the forward calls of this thread list (0, 0: all)
 std::atomic<int> g_last_bwd_bf16{-1};  // contraction of the process's last blend backward (PyTorch runs it on an autograd thread): 1 bf16 two-term, 0 exact fp32, -1 none yet
 
 // What f3dgs_forward learned about a frame that the matching f3dgs_backward needs on the HOST: the largest axis ratio among
@@ -221,6 +222,7 @@ void fill_view(ViewParams& vp, const float* view, const float* proj, const float
     vp.fx = W / (2.0f * tanx); vp.fy = H / (2.0f * tany);
     vp.W = W; vp.H = H;
     vp.gx = (W + TILE - 1) / TILE; vp.gy = (H + TILE - 1) / TILE;
+    vp.band0 = 0; vp.band1 = vp.gy;
     vp.scale_modifier = mod;
     vp.max_axis_ratio = 0.f;
 }
@@ -411,6 +413,11 @@ int f3dgs_set_feature_grad_lowres(const float* gx, int Hg, int Wg, const float* 
     return F3DGS_OK;
 }
 
+void f3dgs_set_tile_band(int tile_row_begin, int tile_row_end) {
+    g_band_begin = tile_row_begin;
+    g_band_end = tile_row_end;
+}
+
 void f3dgs_set_grad_rows_ready_callback(f3dgs_rows_fn fn, void* ctx, int chunks) {
     g_rows_ready_fn = fn;
     g_rows_ready_ctx = ctx;
@@ -467,6 +474,11 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     fill_view(vp, viewmatrix, projmatrix, cam_pos, background, tan_fovx, tan_fovy, width, height, scale_modifier);
     // (one part in a thousand of slack on the ratio: a scene built with scales of exactly 16 : 1 stays on the bf16 side)
     vp.max_axis_ratio = 1.001f * (float)options().bwd_bf16_max_ratio;
+    if (g_band_end > g_band_begin) {      // a tile band of the view (f3dgs.h: f3dgs_set_tile_band)
+        vp.band0 = std::min(std::max(g_band_begin, 0), vp.gy);
+        vp.band1 = std::min(std::max(g_band_end, vp.band0), vp.gy);
+    }
+    const int2 band = make_int2(vp.band0, vp.band1);
     const size_t tiles = (size_t)vp.gx * vp.gy;
 
     size_t geom_bytes = 0, img_bytes = 0, bin_bytes = 0;
@@ -578,7 +590,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
         if (onesweep) {
             HIP_TRY(hipMemsetAsync(img.tile_len, 0, tiles * sizeof(uint32_t), s));
             // emits, builds the tile digit histograms, presets the ranges
-            launch_emit_scan(P, geom, bin, order, vp.gx, vp.gy, cull, in_tile, in_id, N, bin.ranges_enc, s);
+            launch_emit_scan(P, geom, bin, order, vp.gx, vp.gy, band, cull, in_tile, in_id, N, bin.ranges_enc, s);
             if ((rc = check_debug(debug, s, "emit"))) return rc;
             tm.mark("emit");
             launch_tile_sort_onesweep(geom, bin, N, passes, bin.ranges_enc, s);   // the final pass also records the tile ranges
@@ -591,7 +603,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
         } else {
             // presets the ranges too; a captured frame that finds no room raises the slot's sticky word (the host of an eager frame
             // learns it from the count)
-            launch_emit_instances(P, geom, order, vp.gx, vp.gy, cull, in_tile, in_id, bin.ranges_enc, img.tile_len, n_carve,
+            launch_emit_instances(P, geom, order, vp.gx, vp.gy, band, cull, in_tile, in_id, bin.ranges_enc, img.tile_len, n_carve,
                                   known ? nullptr : geom.counters, capturing ? rb.dev + 4 : nullptr, s);
             if ((rc = check_debug(debug, s, "emit"))) return rc;
             tm.mark("emit");

@@ -518,6 +518,8 @@ PYBIND11_MODULE(_C, m) {
           "callable(row_begin, row_end, grads: dict) run inside rasterize_gaussians_backward after each of `chunks` row ranges of the "
           "per-Gaussian gradients is final on the stream; None removes it");
     m.def("set_option", [](const std::string& name, int value) { check_status(f3dgs_set_option(name.c_str(), value), "set_option"); });
+    m.def("set_tile_band", [](int row_begin, int row_end) { f3dgs_set_tile_band(row_begin, row_end); }, py::arg("tile_row_begin"), py::arg("tile_row_end"),
+          "forward calls of this thread list and blend only tile rows [begin, end) of the view (0, 0: the whole view); include/f3dgs.h");
     m.def("forward_counts", []() -> py::object {
         const uint32_t* w = f3dgs_forward_counts();
         if (!w) return py::none();

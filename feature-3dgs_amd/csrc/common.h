@@ -202,6 +202,7 @@ struct ViewParams {
     const float* bg;      // 3 floats
     float tanx, tany, fx, fy;
     int W, H, gx, gy;
+    int band0, band1;       // forward only: tile rows [band0, band1) this call lists and blends (0, gy: the whole view; f3dgs_set_tile_band)
     float scale_modifier;
     float max_axis_ratio;   // forward only: preprocess reports whether a visible Gaussian is longer than this times its width
 };
@@ -236,12 +237,12 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
 // `cap`: entries the instance arrays hold.  `n_dev` (null: cap IS the list length): the device's count - a frame whose count
 // exceeds cap stores nothing and raises `overflow` (device-visible host word, may be null).  The capacity is left in
 // GeomState::counters[3] for readers of the binning buffer.
-void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
+void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int2 band, int cull,
                            uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, uint32_t cap,
                            const uint32_t* n_dev, uint32_t* overflow, hipStream_t s);
 // single-pass flavour (option sort_onesweep): offsets by decoupled look-back inside the emit kernel, which also
 // produces the tile digit histograms, presets `ranges` for the final sort pass and zero-fills b.tile_status
-void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,
+void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int2 band, int cull,
                       uint32_t* inst_tile, uint32_t* inst_id, uint32_t N, uint2* ranges, hipStream_t s);
 void launch_sort_prologue(const GeomState& g, size_t P, hipStream_t s);
 void launch_depth_sort_onesweep(const GeomState& g, size_t n, hipStream_t s);

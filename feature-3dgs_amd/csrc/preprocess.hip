@@ -54,12 +54,15 @@ __device__ __forceinline__ V3 xform3(const float* m, V3 p) {
 
 __device__ __forceinline__ float ndc_to_pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
-__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1,
+// `band` = tile rows [band.x, band.y) this call lists (the whole grid: 0, gy - the reference's rectangle; a tile band of a view
+// that is split over several GPUs, f3dgs_set_tile_band: the rectangle is clipped to the band's rows, so the count, the emission
+// and the reference-style total all speak of the band's tiles only)
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int2 band, int& x0, int& y0, int& x1,
                                           int& y1) {
     x0 = min(gx, max(0, (int)((px - radius) / TILE)));
-    y0 = min(gy, max(0, (int)((py - radius) / TILE)));
+    y0 = min(band.y, max(band.x, (int)((py - radius) / TILE)));
     x1 = min(gx, max(0, (int)((px + radius + TILE - 1) / TILE)));
-    y1 = min(gy, max(0, (int)((py + radius + TILE - 1) / TILE)));
+    y1 = min(band.y, max(band.x, (int)((py + radius + TILE - 1) / TILE)));
 }
 
 
@@ -329,7 +332,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         const float l1 = mid + root, l2 = mid - root;
         rad = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
         px = ndc_to_pix(projx, vp.W); py = ndc_to_pix(projy, vp.H);
-        tile_rect(px, py, (int)rad, vp.gx, vp.gy, x0, y0, x1, y1);
+        tile_rect(px, py, (int)rad, vp.gx, make_int2(vp.band0, vp.band1), x0, y0, x1, y1);
         if ((x1 - x0) * (y1 - y0) == 0) break;
         depth = pv.z;
         alive = true;
@@ -464,12 +467,12 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
 // One splat of many tiles emitted by a whole wave: lane = tile row for the closed-form spans (a wave scan over the row counts),
 // then row by row lane = tile column, consecutive lanes storing consecutive entries - the order of the per-lane walk (rows
 // ascending, columns ascending).  `o`: the splat's first position in the list.
-__device__ __forceinline__ void emit_big_splat(uint32_t gb, uint32_t o, const SplatRec* __restrict__ rec, int gx, int gy, int cull,
+__device__ __forceinline__ void emit_big_splat(uint32_t gb, uint32_t o, const SplatRec* __restrict__ rec, int gx, int gy, int2 band, int cull,
                                                uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_id, int lane) {
     const float4 b0 = rec[gb].q0, b1 = rec[gb].q1;            // (one request: every lane asks for the same record)
     const int bradius = __float_as_int(rec[gb].q2.z);
     int bx0, by0, bx1, by1;
-    tile_rect(b0.x, b0.y, bradius, gx, gy, bx0, by0, bx1, by1);
+    tile_rect(b0.x, b0.y, bradius, gx, band, bx0, by0, bx1, by1);
     const CullParams bk = make_cull(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
     const float bdet_inv = __builtin_amdgcn_rcpf(b0.z * b1.x - b0.w * b0.w);
     for (int yb = by0; yb < by1; yb += 64) {
@@ -509,7 +512,7 @@ __device__ __forceinline__ bool emit_big_claim(uint32_t* big_ctl, uint32_t slot,
     if (lane == 0) was = atomicCAS(&big_ctl[4 + slot], 1u, 2u);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)was) == 1u;
 }
-__device__ __forceinline__ void emit_big_steal(uint32_t* big_ctl, const uint2* big_items, const SplatRec* __restrict__ rec, int gx, int gy,
+__device__ __forceinline__ void emit_big_steal(uint32_t* big_ctl, const uint2* big_items, const SplatRec* __restrict__ rec, int gx, int gy, int2 band,
                                                int cull, uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_id, int lane) {
     for (;;) {
         const uint32_t handed = min(big_load(&big_ctl[0]), (uint32_t)BIGQ_CAP);
@@ -521,7 +524,7 @@ __device__ __forceinline__ void emit_big_steal(uint32_t* big_ctl, const uint2* b
         if (emit_big_claim(big_ctl, i, lane)) {                  // (a slot handed out but not yet published is left to its owner)
             __threadfence();
             const uint32_t gb = big_load(&big_items[i].x), o = big_load(&big_items[i].y);
-            emit_big_splat(gb, o, rec, gx, gy, cull, inst_tile, inst_id, lane);
+            emit_big_splat(gb, o, rec, gx, gy, band, cull, inst_tile, inst_id, lane);
         }
     }
 }
@@ -531,7 +534,7 @@ constexpr int EMIT_BIG = 512;       // tiles from which on a splat is emitted by
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_sums,
                       const uint32_t* __restrict__ sub, const uint32_t* __restrict__ tiles_touched,
-                      const SplatRec* __restrict__ rec, int gx, int gy, int cull, uint32_t* __restrict__ inst_tile,
+                      const SplatRec* __restrict__ rec, int gx, int gy, int2 band, int cull, uint32_t* __restrict__ inst_tile,
                       uint32_t* __restrict__ inst_id, uint2* __restrict__ ranges_enc, uint32_t* __restrict__ tile_len,
                       uint32_t* __restrict__ big_ctl, uint2* __restrict__ big_items, uint32_t cap, uint32_t* __restrict__ cap_word,
                       const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ overflow) {
@@ -595,7 +598,7 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
             const float4 d0 = rec[g].q0, d1 = rec[g].q1;
             const int dradius = __float_as_int(rec[g].q2.z);
             int dx0, dy0, dx1, dy1;
-            tile_rect(d0.x, d0.y, dradius, gx, gy, dx0, dy0, dx1, dy1);
+            tile_rect(d0.x, d0.y, dradius, gx, band, dx0, dy0, dx1, dy1);
             const CullParams dk = make_cull(d0.x, d0.y, d0.z, d0.w, d1.x, d1.y);
             const float ddet_inv = __builtin_amdgcn_rcpf(d0.z * d1.x - d0.w * d0.w);
             for (int y = dy0; y < dy1; y++) {
@@ -608,12 +611,12 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
                 }
             }
         }
-        emit_big_steal(big_ctl, big_items, rec, gx, gy, cull, inst_tile, inst_id, lane);
+        emit_big_steal(big_ctl, big_items, rec, gx, gy, band, cull, inst_tile, inst_id, lane);
         for (unsigned long long m = bigm; m != 0ull; m &= m - 1ull) {          // what nobody took (or what found the queue full)
             const int b = __builtin_ctzll(m);
             const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)myslot, b);
             if (slot >= (uint32_t)BIGQ_CAP || emit_big_claim(big_ctl, slot, lane))
-                emit_big_splat((uint32_t)__builtin_amdgcn_readlane((int)g, b), (uint32_t)__builtin_amdgcn_readlane((int)off0, b), rec, gx, gy,
+                emit_big_splat((uint32_t)__builtin_amdgcn_readlane((int)g, b), (uint32_t)__builtin_amdgcn_readlane((int)off0, b), rec, gx, gy, band,
                                cull, inst_tile, inst_id, lane);
         }
         return;
@@ -632,7 +635,7 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
     if (cnt != 0) {
         q0 = rec[g].q0; q1 = rec[g].q1;
         const int radius = __float_as_int(rec[g].q2.z);  // integer bits stored by preprocess_kernel
-        tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
+        tile_rect(q0.x, q0.y, radius, gx, band, x0, y0, x1, y1);
         ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
         cdet_inv = __builtin_amdgcn_rcpf(q0.z * q1.x - q0.w * q0.w);
     }
@@ -654,7 +657,7 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
             inst_tile[base + k] = s_tile[w][k];
             inst_id[base + k] = s_id[w][k];
         }
-        emit_big_steal(big_ctl, big_items, rec, gx, gy, cull, inst_tile, inst_id, lane);       // (two loads where no view holds a big splat)
+        emit_big_steal(big_ctl, big_items, rec, gx, gy, band, cull, inst_tile, inst_id, lane);       // (two loads where no view holds a big splat)
         return;
     }
     int y = y0 - 1, x = 0, xb = -1;          // "row exhausted": the first step advances to row y0
@@ -683,7 +686,7 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
         }
         __builtin_amdgcn_wave_barrier();          // the window is re-used
     }
-    emit_big_steal(big_ctl, big_items, rec, gx, gy, cull, inst_tile, inst_id, lane);
+    emit_big_steal(big_ctl, big_items, rec, gx, gy, band, cull, inst_tile, inst_id, lane);
 }
 
 
@@ -698,7 +701,7 @@ constexpr int HIST_COPIES = 64;
 
 __global__ void __launch_bounds__(256)
 emit_scan_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
-                 const SplatRec* __restrict__ rec, int gx, int gy, int cull, uint32_t* __restrict__ inst_tile,
+                 const SplatRec* __restrict__ rec, int gx, int gy, int2 band, int cull, uint32_t* __restrict__ inst_tile,
                  uint32_t* __restrict__ inst_id, uint32_t* __restrict__ tickets, uint32_t* __restrict__ status,
                  uint32_t* __restrict__ hist_copies, uint32_t* __restrict__ zero_words, size_t n_zero,
                  uint32_t* __restrict__ tile_hist, uint2* __restrict__ ranges) {
@@ -731,7 +734,7 @@ emit_scan_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __re
         const float4 q0 = rec[g].q0, q1 = rec[g].q1;
         const int radius = __float_as_int(rec[g].q2.z);  // integer bits stored by preprocess_kernel
         int x0, y0, x1, y1;
-        tile_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
+        tile_rect(q0.x, q0.y, radius, gx, band, x0, y0, x1, y1);
         const CullParams ck = make_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
         const float cdet_inv = __builtin_amdgcn_rcpf(q0.z * q1.x - q0.w * q0.w);
         for (int y = y0; y < y1; y++) {
@@ -1104,18 +1107,18 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
                            g.depth_key, cull, g.ref_partial, g.depth_hist, g.big_ctl);
 }
 
-void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int cull,
+void launch_emit_instances(int P, const GeomState& g, const uint32_t* order, int gx, int gy, int2 band, int cull,
                            uint32_t* inst_tile, uint32_t* inst_id, uint2* ranges_enc, uint32_t* tile_len, uint32_t cap,
                            const uint32_t* n_dev, uint32_t* overflow, hipStream_t s) {
     hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, g.scan_tmp, g.scan_sub,
-                       g.tiles_touched, g.rec, gx, gy, cull, inst_tile, inst_id, ranges_enc, tile_len, g.big_ctl, g.big_items,
+                       g.tiles_touched, g.rec, gx, gy, band, cull, inst_tile, inst_id, ranges_enc, tile_len, g.big_ctl, g.big_items,
                        cap, g.counters + 3, n_dev, overflow);
 }
 
-void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int cull,
+void launch_emit_scan(int P, const GeomState& g, const BinState& b, const uint32_t* order, int gx, int gy, int2 band, int cull,
                       uint32_t* inst_tile, uint32_t* inst_id, uint32_t N, uint2* ranges, hipStream_t s) {
     const size_t n_zero = 2 * sort_blocks(N) * 256;
-    hipLaunchKernelGGL(emit_scan_kernel, dim3(emit_blocks(P)), dim3(256), 0, s, P, order, g.tiles_touched, g.rec, gx, gy,
+    hipLaunchKernelGGL(emit_scan_kernel, dim3(emit_blocks(P)), dim3(256), 0, s, P, order, g.tiles_touched, g.rec, gx, gy, band,
                        cull, inst_tile, inst_id, g.tickets, g.emit_status, g.hist_copies, b.tile_status, n_zero,
                        g.tile_hist, ranges);
 }

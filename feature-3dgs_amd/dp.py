@@ -531,6 +531,45 @@ def reduce_densification_stats(grad_norm_accum: torch.Tensor, denom: torch.Tenso
         w.wait()
 
 
+# ---- one view split over the ranks by tile rows ("alternative for single huge views") -------------------------
+# View sharding needs as many views per step as GPUs.  Where there are fewer - a 4K evaluation render, the last views of an
+# epoch - ONE view can be split instead: rank r lists and blends only tile rows band_rows(r) of the 16 x 16 grid
+# (`_C.set_tile_band`, include/f3dgs.h), the bands are gathered into the whole image for the loss, every rank back-propagates
+# the upstream gradient through ITS band, and the per-Gaussian gradients are summed by the same exchange a view-sharded step
+# ends with.  Inside a band the images are bit-identical to the whole view's; the per-Gaussian stages (projection, depth sort)
+# are repeated on every rank - they are P-proportional and small beside the blend (c5: 0.53 of 9.5 ms).
+
+def band_rows(height: int, rank: int, world: int, tile: int = 16):
+    """(tile_row_begin, tile_row_end, pixel_row_begin, pixel_row_end) of rank `rank`'s band: the tile rows of the image split
+    into `world` consecutive bands of (nearly) equal height.  Ranks beyond the number of tile rows get an empty band."""
+    gy = (height + tile - 1) // tile
+    per, extra = divmod(gy, world)
+    r0 = rank * per + min(rank, extra)
+    r1 = r0 + per + (1 if rank < extra else 0)
+    return r0, r1, min(height, r0 * tile), min(height, r1 * tile)
+
+
+def gather_bands(image: torch.Tensor, group=None, tile: int = 16) -> torch.Tensor:
+    """`image` (..., H, W): this rank's render of its band (anything outside the band is ignored).  Returns the whole image
+    with every band taken from the rank that rendered it; differentiable - the gradient of the result flows back into this
+    rank's band rows only (the other ranks' rows are constants here and are back-propagated there)."""
+    if not _active(group):
+        return image
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    H = image.shape[-2]
+    spans = [band_rows(H, r, world, tile)[2:] for r in range(world)]
+    hmax = max(y1 - y0 for y0, y1 in spans)
+    y0, y1 = spans[rank]
+    slab = image.new_zeros(image.shape[:-2] + (hmax, image.shape[-1]))
+    slab[..., : y1 - y0, :] = image[..., y0:y1, :].detach()
+    slabs = [torch.empty_like(slab) for _ in range(world)]
+    dist.all_gather(slabs, slab, group=group)
+    parts = []
+    for r, (a, b) in enumerate(spans):
+        parts.append(image[..., a:b, :] if r == rank else slabs[r][..., : b - a, :])
+    return torch.cat(parts, dim=-2)
+
+
 def dp_step(render_and_backward: Callable[[int], None], leaves: Dict[str, torch.Tensor], view_ids: Iterable[int],
             group=None, buckets: Optional[GradBuckets] = None, overlap: bool = False,
             feature_key: str = "semantic_feature", rows_leaves: Optional[Dict[str, Sequence[str]]] = None,

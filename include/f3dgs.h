@@ -145,6 +145,16 @@ int f3dgs_last_backward_contraction(void);
  * [4] sticky - an emit wave of a CAPTURED frame found no room (the caller clears it).  They are final once the frame's work has
  * completed (synchronise first); a replayed graph writes the words of the call it was captured from. */
 const uint32_t* f3dgs_forward_counts(void);
+/* ONE view split over several GPUs by tile rows (no counterpart in the reference; SURVEY.md 8(e), "alternative for single huge
+ * views"): from this call on the f3dgs_forward calls of this THREAD list and blend only the tiles of rows [tile_row_begin,
+ * tile_row_end) of the 16 x 16 tile grid (clipped to the grid; (0, 0) restores the whole view).  Inside the band the images,
+ * final T and n_contrib are bit-identical to the whole view's; outside it the outputs hold the background / zeros.  A Gaussian
+ * whose rectangle misses the band is invisible to the call (radius 0, no gradient); *num_rendered counts the band's tiles: over
+ * a partition of the rows the counts add up to the whole view's, the element-wise maximum of the radii is the whole view's,
+ * and the SUM of the band calls' gradients (each given the upstream gradient of its own rows) is the whole view's gradient -
+ * the same all-reduce a view-sharded step ends with (dp.py: band_rows, gather_bands).  The matching f3dgs_backward needs
+ * nothing: it reads the band's lists from the forward call's buffers. */
+void f3dgs_set_tile_band(int tile_row_begin, int tile_row_end);
 /* Enumeration: the name of option `index` (0, 1, ...), NULL past the end. */
 const char* f3dgs_option_name(int index);
 

@@ -452,3 +452,40 @@ def test_direct_all_reduce_equals_all_reduce(tmp_path):
     mp.spawn(_direct_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     ok = np.load(os.path.join(tmp_path, "direct_ok.npy"))
     assert ok.all(), ok
+
+
+# ---- one view split over the ranks by tile rows (dp.band_rows, dp.gather_bands) ----------------------------------------------
+
+def _band_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "feature-3dgs_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dp
+    H, W = 72, 40          # five tile rows: bands of 3 + 2 rows at world 2 (48 + 24 pixel rows)
+    r0, r1, y0, y1 = dp.band_rows(H, rank, world)
+    g = torch.Generator().manual_seed(5)
+    whole = torch.randn(3, H, W, generator=g)                      # what a whole-view render would give (same on every rank)
+    local = torch.full((3, H, W), -7.0)                            # this rank's render: its band right, the rest "background"
+    local[:, y0:y1] = whole[:, y0:y1]
+    local.requires_grad_(True)
+    full = dp.gather_bands(local)
+    assert torch.equal(full.detach(), whole)
+    up = torch.randn(3, H, W, generator=g)
+    (full * up).sum().backward()
+    want = torch.zeros(3, H, W)
+    want[:, y0:y1] = up[:, y0:y1]                                  # the gradient reaches this rank's band rows only
+    assert torch.equal(local.grad, want)
+    np.savez(os.path.join(out_dir, f"band{rank}.npz"), rows=np.array([r0, r1, y0, y1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_band_gather(tmp_path):
+    """A view split by tile rows: every rank ends with the whole image, its own rows still attached to its graph."""
+    port = _free_port()
+    mp.spawn(_band_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(tmp_path / f"band{r}.npz")["rows"] for r in range(2))
+    assert a.tolist() == [0, 3, 0, 48] and b.tolist() == [3, 5, 48, 72]
