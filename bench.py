@@ -549,6 +549,7 @@ def main():
                     help="V views of the same Gaussians per step over all GPUs (V / N per rank, pipelined over two streams, "
                          "gradients accumulated across the views): total work is fixed as N grows - the line says scaling: strong")
     ap.add_argument("--graph", action="store_true", help="also time the step replayed from a HIP graph (always done for c1)")
+    ap.add_argument("--band-split", type=int, default=0, help="also time the view split into this many tile-row bands, band by band on this GPU")
     ap.add_argument("--valu", action="store_true",
                     help="library option feature_mfma = 0: every blend kernel on the vector pipe only (the north-star-literal configuration)")
     ap.add_argument("--densify-every", type=int, default=0,
@@ -810,6 +811,30 @@ def main():
         for i in range(2):
             step(i)
 
+    # ONE view split over W GPUs by tile rows (f3dgs_set_tile_band, dp.band_rows): this GPU plays every rank in turn - the step of
+    # band r with the upstream gradients of its own rows.  What an W-GPU split of the view would take per step, exchange excluded,
+    # is the slowest band; the per-Gaussian stages are repeated on every rank.
+    band_split = None
+    if not STUB and dist is None and not V and args.band_split > 1:
+        import dp as _dp
+        per_band = []
+        try:
+            for r in range(args.band_split):
+                r0, r1, _y0, _y1 = _dp.band_rows(H, r, args.band_split)
+                _C.set_tile_band(r0, r1) if r1 > r0 else _C.set_tile_band(1 << 20, 1 << 20)
+                for i in range(3):
+                    step(i)
+                el_b, _ = timed(args.steps, per_step_events=False)
+                per_band.append(1e3 * el_b / args.steps)
+        finally:
+            _C.set_tile_band(0, 0)
+        for i in range(2):
+            step(i)
+        band_split = {"world": args.band_split, "ms_per_band": per_band, "slowest_band_ms": max(per_band),
+                      "whole_view_ms": 1e3 * elapsed / args.steps,
+                      "note": "each band timed on THIS GPU with the whole view's upstream gradients (rows outside the band meet empty "
+                              "tile lists); compute only - the gradient exchange of a W-GPU split is the view-sharded step's"}
+
     views_breakdown = None
     if V:
         # the same K steps with the views strictly one after the other (one stream, one gradient tensor per view), and one view
@@ -1064,6 +1089,7 @@ def main():
             "blend_backward_contraction": "bf16 two-term" if bwd_bf16_active else
                                           ("hybrid: bf16 feature / colour blocks, exact-fp32 moment block" if bwd_hybrid else "exact fp32"),
             "graph_replay": graph_replay,
+            "band_split": band_split,
             "ms_per_step_fp32_exact": fp32_exact["ms_per_step"] if fp32_exact else (ms_per_step if not bwd_bf16_active else None),
             "fp32_exact": ({**fp32_exact,
                             "value_mpix_s": world * W * H / 1e6 / (fp32_exact["ms_per_step"] * 1e-3),

@@ -474,7 +474,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     fill_view(vp, viewmatrix, projmatrix, cam_pos, background, tan_fovx, tan_fovy, width, height, scale_modifier);
     // (one part in a thousand of slack on the ratio: a scene built with scales of exactly 16 : 1 stays on the bf16 side)
     vp.max_axis_ratio = 1.001f * (float)options().bwd_bf16_max_ratio;
-    if (g_band_end > g_band_begin) {      // a tile band of the view (f3dgs.h: f3dgs_set_tile_band)
+    if (g_band_begin != 0 || g_band_end != 0) {      // a tile band of the view (f3dgs.h: f3dgs_set_tile_band); begin >= end: an empty one
         vp.band0 = std::min(std::max(g_band_begin, 0), vp.gy);
         vp.band1 = std::min(std::max(g_band_end, vp.band0), vp.gy);
     }

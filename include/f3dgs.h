@@ -147,7 +147,8 @@ int f3dgs_last_backward_contraction(void);
 const uint32_t* f3dgs_forward_counts(void);
 /* ONE view split over several GPUs by tile rows (no counterpart in the reference; SURVEY.md 8(e), "alternative for single huge
  * views"): from this call on the f3dgs_forward calls of this THREAD list and blend only the tiles of rows [tile_row_begin,
- * tile_row_end) of the 16 x 16 tile grid (clipped to the grid; (0, 0) restores the whole view).  Inside the band the images,
+ * tile_row_end) of the 16 x 16 tile grid (clipped to the grid; (0, 0) restores the whole view; any other pair with begin >= end
+ * is an EMPTY band - the share of a rank beyond the last tile row).  Inside the band the images,
  * final T and n_contrib are bit-identical to the whole view's; outside it the outputs hold the background / zeros.  A Gaussian
  * whose rectangle misses the band is invisible to the call (radius 0, no gradient); *num_rendered counts the band's tiles: over
  * a partition of the rows the counts add up to the whole view's, the element-wise maximum of the radii is the whole view's,
