@@ -40,24 +40,29 @@ std::atomic<int> g_last_bwd_bf16{-1};  // contraction of the process's last blen
 // thread of its own) - so the value is kept here, process-wide, keyed by (device, geometry buffer): the caller hands that buffer
 // back untouched, and a buffer that has been re-used by a later forward call belongs to that call.  A backward call that finds
 // nothing (a buffer copied elsewhere, more than 256 frames in flight) takes the exact contraction.
-struct FrameNote { int device; const void* geom; float axis_ratio; };      // axis_ratio: 0 no visible Gaussian with a long axis, 1 some, 2 ask the device (a captured frame)
+struct FrameNote { int device; const void* geom; float axis_ratio; int band0, band1; };      // band: the tile rows the forward call listed (f3dgs_set_tile_band)      // axis_ratio: 0 no visible Gaussian with a long axis, 1 some, 2 ask the device (a captured frame)
 std::mutex g_frames_mu;
 std::vector<FrameNote> g_frames;
-void note_frame(const void* geom, float axis_ratio) {
+void note_frame(const void* geom, float axis_ratio, int band0, int band1) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_frames_mu);
     for (FrameNote& f : g_frames)
-        if (f.device == dev && f.geom == geom) { f.axis_ratio = axis_ratio; return; }
+        if (f.device == dev && f.geom == geom) { f.axis_ratio = axis_ratio; f.band0 = band0; f.band1 = band1; return; }
     if (g_frames.size() >= 256) g_frames.erase(g_frames.begin());
-    g_frames.push_back({dev, geom, axis_ratio});
+    g_frames.push_back({dev, geom, axis_ratio, band0, band1});
 }
-bool frame_axis_ratio(const void* geom, float* axis_ratio) {
+bool frame_axis_ratio(const void* geom, float* axis_ratio, int* band0 = nullptr, int* band1 = nullptr) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_frames_mu);
     for (const FrameNote& f : g_frames)
-        if (f.device == dev && f.geom == geom) { *axis_ratio = f.axis_ratio; return true; }
+        if (f.device == dev && f.geom == geom) {
+            *axis_ratio = f.axis_ratio;
+            if (band0) *band0 = f.band0;
+            if (band1) *band1 = f.band1;
+            return true;
+        }
     return false;
 }
 
@@ -413,6 +418,16 @@ int f3dgs_set_feature_grad_lowres(const float* gx, int Hg, int Wg, const float* 
     return F3DGS_OK;
 }
 
+int f3dgs_debug_band_order(int gx, int gy, int tile_row_begin, int tile_row_end, uint32_t* tiles_out) {
+    if (gx <= 0 || gy <= 0 || !tiles_out) return fail(F3DGS_ERR_INVALID_ARGUMENT, "bad grid");
+    const int b0r = std::min(std::max(tile_row_begin, 0), gy), b1r = std::min(std::max(tile_row_end, b0r), gy);
+    uint32_t b0 = 0, tb = 0;
+    band_perm_params(gx, gy, b0r, b1r, &b0, &tb);
+    const uint32_t T = (uint32_t)gx * (uint32_t)gy;
+    for (uint32_t v = 0; v < T; v++) tiles_out[v] = band_perm(v, T, b0, tb);
+    return tb != 0 ? 1 : 0;
+}
+
 void f3dgs_set_tile_band(int tile_row_begin, int tile_row_end) {
     g_band_begin = tile_row_begin;
     g_band_end = tile_row_end;
@@ -555,7 +570,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     auto read_counts = [&]() -> int {
         HIP_TRY(hipEventSynchronize(rb.done));
         N = rb.host[0]; n_ref = rb.host[1];
-        note_frame(geom_ptr, (onesweep || rb.host[2] != 0u) ? 1.f : 0.f);
+        note_frame(geom_ptr, (onesweep || rb.host[2] != 0u) ? 1.f : 0.f, vp.band0, vp.band1);
         hint.known = true; hint.own = N; hint.ref = n_ref;
         known = true;
         if (N >= (1u << 30) || n_ref >= (1u << 31)) return fail(F3DGS_ERR_UNSUPPORTED, "more than 2^30 instances");
@@ -628,7 +643,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
         // nothing of this frame is known to the host: the blend backward of bwd_bf16 = -1 lets the DEVICE's long-axis word pick its
         // first window (note 2: both shapes are launched, one runs), and the caller gets the last count this thread read on the
         // device (>= 1: the backward call only asks whether anything was listed)
-        note_frame(geom_ptr, 2.f);
+        note_frame(geom_ptr, 2.f, vp.band0, vp.band1);
         n_ref = std::max(1u, hint.ref);
     }
     if (num_rendered) *num_rendered = (int)n_ref;
@@ -711,10 +726,15 @@ int f3dgs_backward(int P, int D, int M, int C, int R, const float* background, i
     // 1: bf16 two-term everywhere; 2: hybrid - bf16 feature / colour blocks, the moment block (what the chain amplifies) on exact
     // fp32 matrix instructions; 0: exact fp32 everywhere (option bwd_bf16 = 0 only)
     int contraction = options().bwd_bf16 > 0 ? 1 : 0;
-    if (options().bwd_bf16 < 0) {
+    {
         float long_axis = 1.f;       // what the forward call of this frame noted (against bwd_bf16_max_ratio as it was THEN)
-        contraction = (frame_axis_ratio(geom_buffer, &long_axis) && long_axis == 0.f) ? 1 : 2;
-        if (long_axis == 2.f) contraction = 3;     // a captured frame: decided on the device (GeomState::counters[2])
+        int b0 = 0, b1 = vp.gy;      // ... and the tile rows it listed (a note that is gone: the whole grid - right, only unbalanced)
+        const bool noted = frame_axis_ratio(geom_buffer, &long_axis, &b0, &b1);
+        if (noted) { vp.band0 = std::min(std::max(b0, 0), vp.gy); vp.band1 = std::min(std::max(b1, vp.band0), vp.gy); }
+        if (options().bwd_bf16 < 0) {
+            contraction = (noted && long_axis == 0.f) ? 1 : 2;
+            if (noted && long_axis == 2.f) contraction = 3;     // a captured frame: decided on the device (GeomState::counters[2])
+        }
     }
     if (R > 0) {
         const int ran = launch_render_backward(vp, C, img.ranges, point_list, geom.rec, img.final_T, img.n_contrib,

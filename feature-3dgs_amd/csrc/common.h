@@ -4,6 +4,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -297,7 +298,7 @@ void launch_knn_mean_dist2(int P, const float* points, float* out, char* scratch
 void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc, uint2* ranges, const uint32_t* point_list,
                            const SplatRec* rec, const float* feat, float* final_T,
                            uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, uint32_t* tile_len,
-                           hipStream_t s);
+                           hipStream_t s);      // (vp.band0 / band1: see band_perm)
 // The feature-map gradient at the resolution of the loss (f3dgs_set_feature_grad_lowres): (Hg Wg, C) pixel-major; the blend
 // backward applies the transposed bilinear resize while it stages a tile.  `scale`: device scalar multiplied in, or null.
 struct LowresGrad {
@@ -316,10 +317,10 @@ int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, con
                            const SplatRec* rec, const float* final_T, const uint32_t* n_contrib,
                            const float* dL_dpix, const float* dL_dfeat, const float* dL_ddepth, float* grec,
                            float* dL_dfeature, const uint32_t* tile_len, uint32_t* tile_order, const LowresGrad* lowres,
-                           int contraction, const uint32_t* gate, hipStream_t s);
+                           int contraction, const uint32_t* gate, hipStream_t s);      // (vp.band0 / band1: the forward call's band, see band_perm)
 struct BwdArgs;
 void launch_render_backward_pl(BwdArgs a, int C, hipStream_t s);     // render_bwd_pl.hip
-void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, hipStream_t s);
+void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, uint32_t band_b0, uint32_t band_tb, hipStream_t s);
 
 // ---- device helpers --------------------------------------------------------------------------------
 #if defined(__HIPCC__)
@@ -333,6 +334,33 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + k;
 }
+// A view of which only a band of tile rows is listed (f3dgs_set_tile_band): the band is a contiguous eighth (or less) of the
+// tile ids, i.e. ONE XCD's run under xcd_remap - seven XCDs would blend nothing.  band_perm relabels the tiles so that every
+// XCD's run of VIRTUAL ids holds a contiguous eighth of the band's tiles followed by an eighth of the others: a bijection of
+// [0, T); tb = 0: identity.  (b0 = first tile of the band, tb = tiles in it; the caller guarantees T / 8 - tb / 8 >= 8.)
+__host__ __device__ __forceinline__ uint32_t band_perm(uint32_t v, uint32_t T, uint32_t b0, uint32_t tb) {
+    if (tb == 0) return v;
+    constexpr uint32_t X = 8;
+    const uint32_t q = T / X, r = T % X;
+    const uint32_t x = v < r * (q + 1) ? v / (q + 1) : r + (v - r * (q + 1)) / q;
+    const uint32_t f = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    const uint32_t k = v - f;
+    const uint32_t qb = tb / X, rb = tb % X;
+    const uint32_t bf = x < rb ? x * (qb + 1) : rb * (qb + 1) + (x - rb) * qb;
+    const uint32_t nb = x < rb ? qb + 1 : qb;
+    if (k < nb) return b0 + bf + k;
+    const uint32_t j = (f - bf) + (k - nb);      // index among the tiles outside the band
+    return j < b0 ? j : j + tb;
+}
 #endif
+// host side: (first tile, tiles) of the band for band_perm, or (0, 0) where the relabelling is off (whole view, a band of
+// more than half the grid, a grid too small to matter)
+inline void band_perm_params(int gx, int gy, int band0, int band1, uint32_t* b0, uint32_t* tb) {
+    *b0 = 0; *tb = 0;
+    if (band0 <= 0 && band1 >= gy) return;
+    const uint32_t T = (uint32_t)gx * (uint32_t)gy, n = (uint32_t)gx * (uint32_t)std::max(0, band1 - band0);
+    if (n == 0 || T / 8 < n / 8 + 8) return;
+    *b0 = (uint32_t)gx * (uint32_t)band0; *tb = n;
+}
 
 }  // namespace f3dgs

@@ -200,7 +200,7 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
         part = (int)(j % PARTS);
     } else {
         const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
-        tile = wg / PARTS;
+        tile = band_perm(wg / PARTS, (uint32_t)(a.gx * a.gy), a.band_b0, a.band_tb);
         part = (int)(wg % PARTS);
     }
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -692,6 +692,7 @@ int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, con
     BwdArgs a;
     a.order = nullptr;
     a.gate = contraction == 3 ? gate : nullptr; a.gate_want = 0;
+    band_perm_params(vp.gx, vp.gy, vp.band0, vp.band1, &a.band_b0, &a.band_tb);
     a.glow = nullptr; a.gscale = nullptr; a.gHg = a.gWg = 0; a.gsy = a.gsx = 0.f;
     a.m44 = 0; a.split16 = 0; a.bf16 = 0; a.neg_half_w = a.neg_half_h = 0.f;
     const bool low = lowres && lowres->gx && C > 0;
@@ -733,7 +734,7 @@ int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, con
     // instance-lane / pixel-lane: C = 0 0.445 / 0.491, 3 0.567 / 0.509, 4 0.566 / 0.510, 8 0.650 / 0.519)
     if (low || ((opt.bwd_pl > 0 || (opt.bwd_pl < 0 && C > (bf16 ? 0 : 4))) && opt.feature_mfma)) {
         if (opt.bwd_order && tile_len && tile_order) {
-            launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, s);
+            launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, a.band_b0, a.band_tb, s);
             a.order = tile_order;
         }
         a.half = 0;
@@ -763,7 +764,7 @@ int launch_render_backward(const ViewParams& vp, int C, const uint2* ranges, con
     // differ by an order of magnitude (the order is built once per call, every channel window uses it)
     // (c2: 0.677 -> 0.660 ms including the order launch; below ~1000 tiles the launch costs more than the tail it removes)
     if (opt.bwd_order && tile_len && tile_order && (size_t)vp.gx * vp.gy >= 1024) {
-        launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, s);
+        launch_tile_order(tile_len, (size_t)vp.gx * vp.gy, tile_order, a.band_b0, a.band_tb, s);
         a.order = tile_order;
     }
     if (C == 0) {

@@ -175,7 +175,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
 
     // longest walks first: the launch is ~8 rounds of workgroups whose lifetimes differ by an order of magnitude, and a long
     // one that starts late has the CU to itself at the end (c3: 0.708 -> 0.667 ms in a development build)
-    const uint32_t tile = a.order ? a.order[blockIdx.x] : xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t tile = a.order ? a.order[blockIdx.x] : band_perm(xcd_remap(blockIdx.x, gridDim.x), gridDim.x, a.band_b0, a.band_tb);
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 rg = a.ranges[tile];
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
@@ -1015,18 +1015,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 // run of tiles (neighbouring tiles share splat records and feature rows behind one L2) but takes it longest walk first.
 // One workgroup per XCD: counting sort of its run on min(len, 4095) / 4 (1024 buckets); the k-th tile of XCD x goes to
 // order[8 k + x].  The order inside a bucket is whatever the atomics make of it - only the launch order depends on it.
+// (band_b0 / band_tb: the runs are runs of band_perm's VIRTUAL tile ids - a listed band is spread over all eight XCDs)
 __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ tile_len, uint32_t tiles_all,
-                                                          uint32_t* __restrict__ order) {
+                                                          uint32_t* __restrict__ order, uint32_t band_b0, uint32_t band_tb) {
     __shared__ uint32_t bucket[1024];
     __shared__ uint32_t wsum[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t x = blockIdx.x, q = tiles_all / 8, r = tiles_all % 8;
     const uint32_t first = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;      // as xcd_remap
     const uint32_t tiles = x < r ? q + 1 : q;
-    tile_len += first;
+    auto real = [&](uint32_t t) { return band_perm(first + t, tiles_all, band_b0, band_tb); };
     bucket[tid] = 0;
     __syncthreads();
-    for (uint32_t t = tid; t < tiles; t += 1024) atomicAdd(&bucket[1023u - (min(tile_len[t], 4095u) >> 2)], 1u);
+    for (uint32_t t = tid; t < tiles; t += 1024) atomicAdd(&bucket[1023u - (min(tile_len[real(t)], 4095u) >> 2)], 1u);
     __syncthreads();
     // exclusive scan of the 1024 bucket counts (bucket 0 = longest walks)
     const uint32_t c = bucket[tid];
@@ -1043,8 +1044,10 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __rest
     __syncthreads();
     bucket[tid] = base + inc - c;
     __syncthreads();
-    for (uint32_t t = tid; t < tiles; t += 1024)
-        order[8u * atomicAdd(&bucket[1023u - (min(tile_len[t], 4095u) >> 2)], 1u) + x] = first + t;
+    for (uint32_t t = tid; t < tiles; t += 1024) {
+        const uint32_t rt = real(t);
+        order[8u * atomicAdd(&bucket[1023u - (min(tile_len[rt], 4095u) >> 2)], 1u) + x] = rt;
+    }
 }
 
 template <bool GEO>
@@ -1081,8 +1084,8 @@ void launch_pl(const BwdArgs& a, hipStream_t s) {
 
 }  // namespace
 
-void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, hipStream_t s) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, s, tile_len, (uint32_t)tiles, order);
+void launch_tile_order(const uint32_t* tile_len, size_t tiles, uint32_t* order, uint32_t band_b0, uint32_t band_tb, hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, s, tile_len, (uint32_t)tiles, order, band_b0, band_tb);
 }
 
 // Channel windows: the first carries the geometric sums and up to 32 channels, later ones up to 64 channels.

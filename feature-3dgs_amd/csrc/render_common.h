@@ -113,6 +113,7 @@ struct BwdArgs {
     // unless (*gate != 0) == (gate_want != 0).  Null: no gate.
     const uint32_t* gate;
     int gate_want;
+    uint32_t band_b0, band_tb;   // band_perm (common.h): the forward call's band, (0, 0) = whole view
     float neg_half_w, neg_half_h;   // pixel-lane kernel: -W / 2, -H / 2 (the NDC scale of dL/dmean2D, Q8)
     // pixel-lane kernel: feature-map gradient at the loss's resolution, (gHg gWg, C) pixel-major (null: none); dL_dfeat may
     // then be null.  gsy / gsx: the resize scales (H - 1) / (gHg - 1), (W - 1) / (gWg - 1); gscale: device scalar or null

@@ -52,6 +52,7 @@ struct FwdArgs {
     int write_base;  // 1: also write colour / depth / final_T / n_contrib
     uint32_t* tile_len;   // per tile: max n_contrib of its pixels (first window's launch; zero-filled beforehand)
     int solo;        // one quadrant per wave: 64-thread workgroups, grid = 4 x tiles
+    uint32_t band_b0, band_tb;   // band_perm (common.h): first tile / tiles of the listed band, (0, 0) = whole view
     int dev;         // development builds: work-skipping bits (128: no feature gathers  256: no matrix instructions  512: no alpha evaluation skip)
 };
 
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
     const int wave = solo ? (int)(vb & 3u) : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     FwdChunk<CH>& ck = reinterpret_cast<FwdChunk<CH>*>(smem)[(NW > 1 && !solo) ? wave : 0];
 
-    const uint32_t tile = solo ? vb >> 2 : vb;
+    const uint32_t tile = band_perm(solo ? vb >> 2 : vb, (uint32_t)(a.gx * a.gy), a.band_b0, a.band_tb);
     const int tx = tile % a.gx, ty = tile / a.gx;
     uint2 rg;
     if (a.write_base) {   // first channel window: decode {min, UINT_MAX - (max + 1)}; untouched = empty tile
@@ -297,7 +298,7 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     const int wave = solo ? (int)(vb & 3u) : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     FwdChunkMF<CH, CHK>& ck = reinterpret_cast<FwdChunkMF<CH, CHK>*>(smem)[(NW > 1 && !solo) ? wave : 0];
 
-    const uint32_t tile = solo ? vb >> 2 : vb;
+    const uint32_t tile = band_perm(solo ? vb >> 2 : vb, (uint32_t)(a.gx * a.gy), a.band_b0, a.band_tb);
     const int tx = tile % a.gx, ty = tile / a.gx;
     uint2 rg;
     if (a.write_base) {   // first channel window: decode {min, UINT_MAX - (max + 1)}; untouched = empty tile
@@ -599,6 +600,7 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     a.W = vp.W; a.H = vp.H; a.gx = vp.gx; a.gy = vp.gy; a.C = C;
     a.solo = options().fwd_solo;
     a.tile_len = tile_len;
+    band_perm_params(vp.gx, vp.gy, vp.band0, vp.band1, &a.band_b0, &a.band_tb);
 #ifdef F3DGS_DEV
     a.dev = options().dev;
 #else

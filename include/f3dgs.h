@@ -156,6 +156,12 @@ const uint32_t* f3dgs_forward_counts(void);
  * the same all-reduce a view-sharded step ends with (dp.py: band_rows, gather_bands).  The matching f3dgs_backward needs
  * nothing: it reads the band's lists from the forward call's buffers. */
 void f3dgs_set_tile_band(int tile_row_begin, int tile_row_end);
+/* Host-only diagnostic (no GPU needed): the order in which the blend kernels' workgroups take the tiles of a gx x gy grid when
+ * rows [begin, end) are listed - tiles_out[v] = tile of virtual id v (gx * gy entries).  A band is a contiguous run of tile ids,
+ * i.e. one XCD's share under the whole-view mapping; with a band the ids are relabelled so that every XCD's run of virtual ids
+ * starts with an eighth of the band's tiles.  Returns 1 if the relabelling is on, 0 for the identity (whole view, a band of
+ * more than about half the grid, a tiny grid), < 0 on error. */
+int f3dgs_debug_band_order(int gx, int gy, int tile_row_begin, int tile_row_end, uint32_t* tiles_out /* host, gx * gy */);
 /* Enumeration: the name of option `index` (0, 1, ...), NULL past the end. */
 const char* f3dgs_option_name(int index);
 

@@ -5,6 +5,7 @@ import os
 import re
 
 import pytest
+import numpy as np
 import torch
 
 from util import ROOT
@@ -122,3 +123,34 @@ def test_no_cpu_fallback():
     with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
         r(means3D=sc["means3D"], means2D=torch.zeros(50, 3), opacities=sc["opacities"], shs=sc["shs"],
           semantic_feature=sc["semantic_feature"], scales=sc["scales"])
+
+
+def test_band_relabelling_is_a_bijection_that_spreads_the_band():
+    """f3dgs_set_tile_band lists a contiguous run of tile ids - one XCD's share under the whole-view workgroup -> tile mapping.
+    The blend kernels therefore relabel the tiles (common.h: band_perm); host-side restatement through the C ABI, no GPU: every
+    tile exactly once, and every XCD's run of virtual ids (a contiguous eighth) starts with its eighth of the band."""
+    import ctypes
+    lib = ctypes.CDLL(_ensure_built())
+    lib.f3dgs_debug_band_order.restype = ctypes.c_int
+    lib.f3dgs_debug_band_order.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    for gx, gy, r0, r1 in [(120, 68, 0, 9), (120, 68, 27, 36), (120, 68, 60, 68), (240, 135, 17, 34), (240, 135, 118, 135),
+                           (37, 29, 3, 5), (120, 68, 0, 68), (120, 68, 10, 60), (8, 6, 2, 3), (63, 41, 40, 41), (120, 68, 30, 30)]:
+        T = gx * gy
+        out = np.zeros(T, np.uint32)
+        on = lib.f3dgs_debug_band_order(gx, gy, r0, r1, out.ctypes.data_as(ctypes.c_void_p))
+        assert on in (0, 1)
+        assert np.array_equal(np.sort(out), np.arange(T, dtype=np.uint32)), (gx, gy, r0, r1)
+        nb = gx * (r1 - r0)
+        if not on:
+            assert np.array_equal(out, np.arange(T, dtype=np.uint32))
+            assert nb == 0 or nb == T or T // 8 < nb // 8 + 8
+            continue
+        in_band = (out >= gx * r0) & (out < gx * r1)
+        q, r = divmod(T, 8)
+        first = 0
+        for x in range(8):
+            n = q + (1 if x < r else 0)
+            run = in_band[first:first + n]
+            want = nb // 8 + (1 if x < nb % 8 else 0)
+            assert int(run.sum()) == want and run[:want].all(), (gx, gy, r0, r1, x)
+            first += n

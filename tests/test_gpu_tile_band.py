@@ -27,8 +27,11 @@ CASES = {"ragged-C16": dict(P=20000, width=333, height=215, C=16, seed=41, scale
          "wide-C200": dict(P=6000, width=200, height=160, C=200, seed=43, scale_lo=0.01, scale_hi=0.08)}
 
 
-@pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("world", [2, 3, 8])
+# a grid large enough for the blend kernels' band relabelling (common.h: band_perm; off below ~64 tiles per XCD): 8160 tiles
+CASES["1080p-C8"] = dict(P=120000, width=1920, height=1080, C=8, seed=44, scale_lo=0.004, scale_hi=0.04)
+
+
+@pytest.mark.parametrize("name,world", [(n, w) for n in sorted(CASES) for w in ((8,) if n == "1080p-C8" else (2, 3, 8))])
 def test_bands_add_up_to_the_whole_view(name, world, band, option):
     import dp
     scene = _scene(**CASES[name])

@@ -41,8 +41,13 @@ def step():
 
 for setting in settings:
     added = []
+    _C.set_tile_band(0, 0)
     for kv in setting.split():
         k, v = kv.split("=")
+        if k == "band":           # "band=9:18": tile rows [9, 18) only (f3dgs_set_tile_band)
+            a, b = v.split(":")
+            _C.set_tile_band(int(a), int(b))
+            continue
         added.append((k, _C.get_option(k)))
         _C.set_option(k, int(v))
     for _ in range(10):
