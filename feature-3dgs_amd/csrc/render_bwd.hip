@@ -205,6 +205,7 @@ __device__ __forceinline__ void render_backward_body(const BwdArgs& a) {
     }
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 rg = a.ranges[tile];
+    if (rg.x >= rg.y) return;     // an empty list (every tile outside a listed band): nothing to stage, nothing to add
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
     const size_t HW = (size_t)a.W * a.H;
     // pixel block of this wave: one 8x8 quadrant of the tile

@@ -178,6 +178,7 @@ __device__ __forceinline__ void render_backward_pl_body(const BwdArgs& a) {
     const uint32_t tile = a.order ? a.order[blockIdx.x] : band_perm(xcd_remap(blockIdx.x, gridDim.x), gridDim.x, a.band_b0, a.band_tb);
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 rg = a.ranges[tile];
+    if (rg.x >= rg.y) return;     // (workgroup-uniform) an empty list - every tile outside a listed band: nothing to stage, nothing to add
     const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x);
     const size_t HW = (size_t)a.W * a.H;
     const int tx0 = tx * TILE, ty0 = ty * TILE;

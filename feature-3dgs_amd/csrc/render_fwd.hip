@@ -53,6 +53,8 @@ struct FwdArgs {
     uint32_t* tile_len;   // per tile: max n_contrib of its pixels (first window's launch; zero-filled beforehand)
     int solo;        // one quadrant per wave: 64-thread workgroups, grid = 4 x tiles
     uint32_t band_b0, band_tb;   // band_perm (common.h): first tile / tiles of the listed band, (0, 0) = whole view
+    int band_r0, band_r1;        // tile rows of the listed band; outside them a workgroup only records the empty range - the
+                                 // pixels there are written by fill_outside_band_kernel (whole view: 0, gy)
     int dev;         // development builds: work-skipping bits (128: no feature gathers  256: no matrix instructions  512: no alpha evaluation skip)
 };
 
@@ -76,6 +78,10 @@ __global__ void __launch_bounds__(256 / PPL) render_forward_kernel(FwdArgs a) {
 
     const uint32_t tile = band_perm(solo ? vb >> 2 : vb, (uint32_t)(a.gx * a.gy), a.band_b0, a.band_tb);
     const int tx = tile % a.gx, ty = tile / a.gx;
+    if (ty < a.band_r0 || ty >= a.band_r1) {      // (workgroup-uniform) a tile outside the listed band: see FwdArgs::band_r0
+        if (a.write_base && threadIdx.x == 0 && (!solo || wave == 0)) a.ranges[tile] = make_uint2(0u, 0u);
+        return;
+    }
     uint2 rg;
     if (a.write_base) {   // first channel window: decode {min, UINT_MAX - (max + 1)}; untouched = empty tile
         const uint2 e = a.ranges_enc[tile];
@@ -300,6 +306,10 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
 
     const uint32_t tile = band_perm(solo ? vb >> 2 : vb, (uint32_t)(a.gx * a.gy), a.band_b0, a.band_tb);
     const int tx = tile % a.gx, ty = tile / a.gx;
+    if (ty < a.band_r0 || ty >= a.band_r1) {      // (workgroup-uniform) a tile outside the listed band: see FwdArgs::band_r0
+        if (a.write_base && threadIdx.x == 0 && (!solo || wave == 0)) a.ranges[tile] = make_uint2(0u, 0u);
+        return;
+    }
     uint2 rg;
     if (a.write_base) {   // first channel window: decode {min, UINT_MAX - (max + 1)}; untouched = empty tile
         const uint2 e = a.ranges_enc[tile];
@@ -588,6 +598,25 @@ void launch_one(const FwdArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// A call that lists a band of tile rows only (f3dgs_set_tile_band): every output pixel outside the band's rows - background
+// colour, zero depth and features, final T = 1, no contributor - in whole-row runs (the blend kernels would write them 32 bytes
+// at a time: at c5, C = 128, 2.3 ms for seven eighths of nothing).  Plane 0..2 colour, 3 depth, 4 final T, 5 n_contrib, 6.. features.
+struct BandFill {
+    float* color; float* depth; float* feat; float* final_T; uint32_t* n_contrib; const float* bg;
+};
+__global__ void __launch_bounds__(256) fill_outside_band_kernel(BandFill f, size_t HW, size_t lo, size_t hi) {
+    const int plane = blockIdx.y;
+    float* base;
+    float v = 0.f;
+    if (plane < 3) { base = f.color + (size_t)plane * HW; v = f.bg[plane]; }
+    else if (plane == 3) base = f.depth;
+    else if (plane == 4) { base = f.final_T; v = 1.f; }
+    else if (plane == 5) base = reinterpret_cast<float*>(f.n_contrib);        // (0.f is the zero word)
+    else base = f.feat + (size_t)(plane - 6) * HW;
+    const size_t n = HW - (hi - lo), e1 = min(n, ((size_t)blockIdx.x + 1) * 2048);
+    for (size_t e = (size_t)blockIdx.x * 2048 + threadIdx.x; e < e1; e += 256) base[e < lo ? e : e + (hi - lo)] = v;
+}
+
 void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc, uint2* ranges, const uint32_t* point_list,
                            const SplatRec* rec, const float* feat, float* final_T,
                            uint32_t* n_contrib, float* out_color, float* out_feat, float* out_depth, uint32_t* tile_len,
@@ -601,6 +630,16 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     a.solo = options().fwd_solo;
     a.tile_len = tile_len;
     band_perm_params(vp.gx, vp.gy, vp.band0, vp.band1, &a.band_b0, &a.band_tb);
+    a.band_r0 = vp.band0; a.band_r1 = vp.band1;
+    if (vp.band0 > 0 || vp.band1 < vp.gy) {
+        const size_t HW = (size_t)vp.W * vp.H;
+        const size_t lo = (size_t)min(vp.H, vp.band0 * TILE) * vp.W, hi = (size_t)min(vp.H, vp.band1 * TILE) * vp.W;
+        const size_t n = HW - (hi - lo);
+        if (n) {
+            const BandFill f = {out_color, out_depth, out_feat, final_T, n_contrib, vp.bg};
+            hipLaunchKernelGGL(fill_outside_band_kernel, dim3((unsigned)((n + 2047) / 2048), (unsigned)(6 + C)), dim3(256), 0, s, f, HW, lo, hi);
+        }
+    }
 #ifdef F3DGS_DEV
     a.dev = options().dev;
 #else
