@@ -8,6 +8,9 @@ ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 # 1. bench lines: c3 full (driver contract), the other BASELINE configs single-GPU
 timeout 300 python bench.py > $OUT/${TAG}_bench_c3.json 2> $OUT/bench_c3.err
 for c in c1 c2 c4 c5; do timeout 200 python bench.py --config $c --no-cpu-baseline --steps 20 --warmup 5 > $OUT/${TAG}_bench_$c.json 2> $OUT/bench_$c.err; done
+# 1a'. round 6: the step replayed from a HIP graph at c2 / c3 (the c1 line above carries its own graph_replay), one view as eight tile-row bands
+for c in c2 c3; do timeout 200 python bench.py --config $c --graph --no-cpu-baseline --steps 20 --warmup 5 > $OUT/${TAG}_bench_${c}_graph.json 2> $OUT/bench_${c}_graph.err; done
+for c in c3 c4 c5; do timeout 300 python bench.py --config $c --band-split 8 --no-cpu-baseline --steps 10 --warmup 3 > $OUT/${TAG}_bench_${c}_bands8.json 2> $OUT/bench_${c}_bands8.err; done
 # 1b. the north-star-literal configuration (no matrix pipe anywhere), config c5 with densification on, several views per GPU
 timeout 200 python bench.py --no-cpu-baseline --valu > $OUT/${TAG}_bench_c3_valu.json 2> $OUT/bench_c3_valu.err
 timeout 300 python bench.py --config c5 --densify-every 5 --steps 40 --warmup 10 > $OUT/${TAG}_bench_c5_densify.json 2> $OUT/bench_c5_densify.err
