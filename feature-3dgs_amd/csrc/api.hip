@@ -467,9 +467,10 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     if (!out_color || !out_depth || (C > 0 && !out_feature_map)) return fail(F3DGS_ERR_INVALID_ARGUMENT, "null output");
     const size_t HW = (size_t)width * height;
     if (P == 0) {  // rasterize_points.cu:84: outputs stay zero
-        HIP_TRY(hipMemsetAsync(out_color, 0, 3 * HW * sizeof(float), s));
-        HIP_TRY(hipMemsetAsync(out_depth, 0, HW * sizeof(float), s));
-        if (C) HIP_TRY(hipMemsetAsync(out_feature_map, 0, (size_t)C * HW * sizeof(float), s));
+        const bool cap0 = stream_is_capturing(s);      // (inside a graph: a kernel node, see zero_fill)
+        HIP_TRY(zero_fill(out_color, 3 * HW * sizeof(float), cap0, s));
+        HIP_TRY(zero_fill(out_depth, HW * sizeof(float), cap0, s));
+        if (C) HIP_TRY(zero_fill(out_feature_map, (size_t)C * HW * sizeof(float), cap0, s));
         return F3DGS_OK;
     }
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !background)
