@@ -738,6 +738,11 @@ def main():
     # THE timed region: HIP events around the two blend kernels (the roofline's kernel duration is measured HERE, on
     # the op's stream)
     _C.set_option("profile", 2)
+    # (the library creates its HIP events on first use and pools them: an untimed pass of the same K steps creates the 4 K events
+    # the timed region records, so that no hipEventCreate - one run in ten read 1.38 instead of 1.26 ms at c3, a 2.4 ms stall in
+    # its first profiled pass - falls inside it; counted in steps_run_before_the_timed_region)
+    timed(args.steps, per_step_events=False)
+    _C.profile_read()
     _C.profile_reset()
     elapsed, _ = timed(args.steps, per_step_events=False)
     blend = {name: (ms, calls) for name, ms, calls in _C.profile_read()}
@@ -1109,8 +1114,9 @@ def main():
                        f"view-sharded dp{world} + RCCL all-reduce of (59+C) floats per Gaussian"
                        + ("" if args.no_overlap else ", feature and SH all-reduces started inside the backward pass")},
             # order of the runs in this process: W warm-up steps, K steps without any event (reported as
-            # step_ms.ms_per_step_without_events), THEN the K timed steps of `value` - the same order as in every earlier round
-            "steps_run_before_the_timed_region": args.warmup + args.steps,
+            # step_ms.ms_per_step_without_events), K untimed steps with the timed region's events (they create the library's
+            # event pool), THEN the K timed steps of `value`
+            "steps_run_before_the_timed_region": args.warmup + 2 * args.steps,
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "n": len(per),
                         "source": "HIP event pair per step on the op's stream, rank 0, in the auxiliary run with all stage events",
                         "ms_per_step_without_events": 1e3 * el_plain / args.steps,
