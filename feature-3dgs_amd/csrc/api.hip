@@ -256,7 +256,6 @@ const OptionDesc kOptions[] = {
     {"bwd_wide8", "F3DGS_BWD_WIDE8", &Options::bwd_wide8, 1},
     {"fwd_wide", "F3DGS_FWD_WIDE", &Options::fwd_wide, 1},
     {"fwd_solo", "F3DGS_FWD_SOLO", &Options::fwd_solo, 1},
-    {"fwd_share", "F3DGS_FWD_SHARE", &Options::fwd_share, 1},
     {"sort_onesweep", "F3DGS_SORT_ONESWEEP", &Options::sort_onesweep, 0},
     {"sync_free", "F3DGS_SYNC_FREE", &Options::sync_free, 0},
     {"instance_capacity", "F3DGS_INSTANCE_CAPACITY", &Options::instance_capacity, 0},

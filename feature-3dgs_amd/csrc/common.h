@@ -183,7 +183,6 @@ struct Options {
     int bwd_wide8;       // pixel-lane blend backward, bf16 shape: later channel windows of up to 128 channels on eight waves per tile where more than 64 channels remain (default 1)
     int bwd_pl;          // blend backward: pixel-lane formulation with all sums on the matrix pipe: 1 always, 0 never, -1 (default) for C > 0 (C > 4 with bwd_bf16 = 0); needs feature_mfma
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
-    int fwd_share;       // blend forward, more than 128 channels: one walk per quadrant, the blend weights shared between a producer wave and the waves of the later channel windows (default 1)
     int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)
     int sort_onesweep;   // 1: single-pass radix passes with decoupled look-back (measured slower on MI355X; default 0)
     int sync_free;       // 1: the forward call never waits for the instance count in the middle of its enqueue - binning buffers of a CAPACITY, kernels that read the count on the device, the count checked behind the last launch (one retry) - and can be captured in a HIP graph (default 0)

@@ -36,13 +36,9 @@ struct FwdPixels {
 
 // Entries ent[j .. j + GI) (a count that is not a multiple of GI is padded with null entries by the caller); feat: the chunk's
 // feature rows, row-major [entry][CH]; chunk_base / b_stride / b_off: where a lane's B column lives when CH == 16 (see the caller).
-// WOUT (render_forward_share_body): the group's blend weights are also left in LDS, w_out[64 (j + e) + lane], for the waves that
-// contract the later channel windows of the same quadrant.
-template <int CH, int PPL, int GI, bool BASE, bool WOUT = false>
+template <int CH, int PPL, int GI, bool BASE>
 __device__ __forceinline__ void fwd_blend_group(const FwdEntry* ent, const float* feat, const float* chunk_base, int j, int lane,
-                                                int b_stride, int b_off, bool skip_mfma, FwdPixels<CH, PPL>& px,
-                                                float* __restrict__ w_out = nullptr) {
-    static_assert(!WOUT || PPL == 1, "one quadrant per wave");
+                                                int b_stride, int b_off, bool skip_mfma, FwdPixels<CH, PPL>& px) {
     constexpr int NB = (CH + 31) / 32;
     constexpr bool CDB = BASE && CH == 16;
     constexpr int NP = GI / 2;        // instance pairs (MFMA K = 2) per group
@@ -141,10 +137,6 @@ __device__ __forceinline__ void fwd_blend_group(const FwdEntry* ent, const float
                 }
             }
         }
-    }
-    if constexpr (WOUT) {
-#pragma unroll
-        for (int e = 0; e < GI; e++) w_out[64 * (j + e) + lane] = w[e][0];
     }
 }
 

@@ -538,275 +538,6 @@ __device__ __forceinline__ void render_forward_mfma_body(const FwdArgs& a) {
     }
 }
 
-// =====================================================================================================================
-// Wide features (C > 128), round 6: ONE walk of the list per quadrant, whatever the width.
-//
-// Every channel window of the shapes above re-evaluates the blend weights of the whole list (136 vector cycles per entry and
-// wave at two waves per SIMD, beside 4 x 74 cycles of exact-fp32 matrix instructions per 128 channels - the two exclude each
-// other on a SIMD).  Here a workgroup of NWV waves takes one 8 x 8 quadrant: wave 0 (the PRODUCER) is the base launch -
-// compaction, alpha, transmittance, colour, depth and channels 0..127 - and leaves the weights of every entry it evaluates in
-// LDS; waves 1.. (CONSUMERS) contract channels 128 w .. 128 w + 127 against those weights and evaluate nothing.  Chunks of 16
-// list entries, one workgroup barrier per chunk: while the producer blends chunk k (writing w[k & 1]) and compacts chunk k + 1
-// (writing ent[(k + 1) & 1]), a consumer contracts chunk k - 1 (w[(k - 1) & 1], its feature rows of that parity) and requests
-// the feature rows of chunk k (ent[k & 1]).  The weights are the producer's own fp32 values and every channel sums over the
-// entries in list order, so the images are bit-identical to the window-by-window kernels (a null entry pads odd counts: it
-// adds +0 to every sum).
-constexpr int SH_CHK = 16;
-constexpr int SH_FT = 32 * 65;       // floats: the feature rows of a chunk [16][128] (2048), reused as the epilogue's transpose tile [32][65]
-template <int NWV>
-struct FwdShareLds {
-    FwdEntry ent[2][SH_CHK];         // compacted entries of a chunk, by chunk parity
-    int cnt[2];                      // entries of the chunk (-1: the walk is over)
-    int pad_[2];
-    float w[2][SH_CHK * 64];         // blend weights [entry][pixel lane], by chunk parity
-    float feat0[SH_FT];              // the producer's feature rows
-    float featc[NWV - 1][2][SH_FT];  // the consumers', by chunk parity
-};
-
-// feature rows of `cnt` staged entries, channels [c0, c0 + nc) -> dst row-major [entry][128] (as render_forward_mfma_body); the
-// LDS-direct requests are NOT waited for here
-__device__ __forceinline__ void share_gather_rows(const FwdArgs& a, const FwdEntry* ent, int cnt, int c0, int nc, float* dst, int lane) {
-    constexpr int CH = 128, CHV = CH / 4;
-    const bool vec_ok = (a.C & 3) == 0 && (c0 & 3) == 0;
-    if (vec_ok && nc == CH) {
-        using lds_ptr = __attribute__((address_space(3))) void*;
-        using gbl_ptr = const __attribute__((address_space(1))) void*;
-#pragma unroll
-        for (int it = 0; it < SH_CHK * CHV / 64; it++) {
-            const int e = it * 64 + lane;
-            if (e < cnt * CHV) {
-                const uint32_t g = ent[e / CHV].id;
-                const float* src = a.feat + (size_t)g * a.C + c0 + 4 * (e % CHV);
-                __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)&dst[it * 256], 16, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-        for (int e = lane; e < cnt * CHV; e += 64) {
-            const int inst = e / CHV, v = e % CHV;
-            const uint32_t g = ent[inst].id;
-            const float* src = a.feat + (size_t)g * a.C + c0 + 4 * v;
-            float4 f;
-            if (vec_ok && 4 * v + 3 < nc) {
-                f = *reinterpret_cast<const float4*>(src);
-            } else {
-                f.x = 4 * v + 0 < nc ? src[0] : 0.f;
-                f.y = 4 * v + 1 < nc ? src[1] : 0.f;
-                f.z = 4 * v + 2 < nc ? src[2] : 0.f;
-                f.w = 4 * v + 3 < nc ? src[3] : 0.f;
-            }
-            *reinterpret_cast<float4*>(&dst[inst * CH + 4 * v]) = f;
-        }
-    }
-    if (cnt & 1)          // the null entry that pads an odd count: a zero row (its weights are zero, the products must be too)
-        for (int c = lane; c < CH; c += 64) dst[cnt * CH + c] = 0.0f;
-}
-
-// the wave's 128 accumulated channels -> out_feat, through the [32][65] transpose tile (as the epilogue of render_forward_mfma_body)
-__device__ __forceinline__ void share_store_features(const FwdArgs& a, const f32x16 (&acc)[2][4], float* tile, int c0, int nc, bool inside,
-                                                     int pix_id, int lane) {
-    constexpr int TS = 65;
-    const size_t HW = (size_t)a.W * a.H;
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int i = 32 * h + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                tile[(lane & 31) * TS + i] = acc[h][nb][r];
-            }
-        __builtin_amdgcn_wave_barrier();
-        if (inside) {
-#pragma unroll 8
-            for (int n = 0; n < 32; n++)
-                if (32 * nb + n < nc) a.out_feat[(size_t)(c0 + 32 * nb + n) * HW + (size_t)pix_id] = tile[n * TS + lane];
-        }
-    }
-}
-
-template <int NWV>
-__device__ __forceinline__ void render_forward_share_body(const FwdArgs& a) {
-    constexpr int CH = 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    FwdShareLds<NWV>& L = *reinterpret_cast<FwdShareLds<NWV>*>(smem);
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);          // four consecutive virtual ids = the quadrants of one tile
-    const int q = (int)(vb & 3u);
-    const uint32_t tile = band_perm(vb >> 2, (uint32_t)(a.gx * a.gy), a.band_b0, a.band_tb);
-    const int tx = tile % a.gx, ty = tile / a.gx;
-    if (ty < a.band_r0 || ty >= a.band_r1) {      // (workgroup-uniform) a tile outside the listed band: see FwdArgs::band_r0
-        if (threadIdx.x == 0 && q == 0) a.ranges[tile] = make_uint2(0u, 0u);
-        return;
-    }
-    const uint2 enc = a.ranges_enc[tile];
-    const uint2 rg = enc.x == 0xFFFFFFFFu ? make_uint2(0u, 0u) : make_uint2(enc.x, 0xFFFFFFFFu - enc.y);
-    if (threadIdx.x == 0) a.ranges[tile] = rg;
-    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((int)rg.x), r_hi = __builtin_amdgcn_readfirstlane((int)rg.y);
-    const int lx = lane & 7, ly = lane >> 3;
-    const int x = tx * TILE + (q & 1) * 8 + lx, y = ty * TILE + (q >> 1) * 8 + ly;
-    const bool inside = x < a.W && y < a.H;
-    const int pix_id = y * a.W + x;
-    const int c0 = CH * wv, nc = min(CH, a.C - c0);          // this wave's channels
-
-    if (wv != 0) {
-        // ---- consumer ------------------------------------------------------------------------------------------------------
-        f32x16 acc[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int nb = 0; nb < 4; nb++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[h][nb][r] = 0.f;
-        float* const fbuf = &L.featc[wv - 1][0][0];
-        __syncthreads();                    // chunk 0 is compacted
-        int cnt_prev = 0;
-        for (int k = 0;; k++) {
-            const int b = k & 1;
-            if (k > 0) {                    // contract chunk k - 1: its rows were requested in the previous round
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const float* wb = L.w[b ^ 1];
-                const float* fb = fbuf + (size_t)(b ^ 1) * SH_FT;
-                for (int j = 0; j < cnt_prev; j += 2) {
-                    const float w0 = wb[64 * j + lane], w1 = wb[64 * (j + 1) + lane];
-                    if (__builtin_amdgcn_ballot_w64(w0 != -w1) == 0ull) continue;        // (the weights are >= 0)
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(w0), __float_as_int(w1), false, false);
-                    const float X = __int_as_float(sw[0]), Y = __int_as_float(sw[1]);
-                    const float* row = fb + (j + (lane >> 5)) * CH + (lane & 31);
-#pragma unroll
-                    for (int nb = 0; nb < 4; nb++) {
-                        const float Bv = row[32 * nb];
-                        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bv, acc[0][nb], 0, 0, 0);
-                        acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y, Bv, acc[1][nb], 0, 0, 0);
-                    }
-                }
-            }
-            const int cnt = __builtin_amdgcn_readfirstlane(L.cnt[b]);
-            if (cnt < 0) break;             // the walk is over: nothing more is exchanged
-            share_gather_rows(a, L.ent[b], cnt, c0, nc, fbuf + (size_t)b * SH_FT, lane);
-            cnt_prev = cnt;
-            __syncthreads();                // the producer has blended chunk k and compacted chunk k + 1
-        }
-        share_store_features(a, acc, fbuf, c0, nc, inside, pix_id, lane);
-        return;
-    }
-
-    // ---- producer: the base launch of render_forward_mfma_body in chunks of 16, its weights left in L.w -----------------------
-    const int iwx0 = tx * TILE + (q & 1) * 8, iwx1 = iwx0 + 7;
-    const int iwy0 = ty * TILE + (q >> 1) * 8, iwy1 = iwy0 + 7;
-    FwdPixels<CH, 1> px;
-    px.pxf[0] = (float)x; px.pyf[0] = (float)y;
-    px.T[0] = inside ? 1.0f : -1.0f; px.dep[0] = 0.f; px.last[0] = 0;
-    px.col[0][0] = px.col[0][1] = px.col[0][2] = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int nb = 0; nb < 4; nb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) px.acc[0][h][nb][r] = 0.f;
-    // software pipeline of the list: records of chunk k + 1 and ids of chunk k + 2 are in flight while chunk k is blended
-    uint32_t n_id = 0, f_id = 0;
-    float4 n_q0 = make_float4(0, 0, 0, 0), n_q1 = n_q0;
-    float2 n_q2 = make_float2(0, 0);
-    if (lane < SH_CHK && r_lo + lane < r_hi) n_id = a.point_list[r_lo + lane];
-    if (lane < SH_CHK && r_lo + SH_CHK + lane < r_hi) f_id = a.point_list[r_lo + SH_CHK + lane];
-    if (lane < SH_CHK && r_lo + lane < r_hi) {
-        const SplatRec* rp = a.rec + n_id;
-        n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = *reinterpret_cast<const float2*>(&rp->q2);
-    }
-    // compaction of the chunk that starts at list position `base` into parity b; false: the walk is over (cnt = -1)
-    auto compact = [&L, &n_id, &f_id, &n_q0, &n_q1, &n_q2, &a, lane, r_lo, r_hi, iwx0, iwx1, iwy0, iwy1](uint32_t base, int b, bool live) -> bool {
-        if (base >= r_hi || !__any(live)) {
-            if (lane == 0) L.cnt[b] = -1;
-            return false;
-        }
-        const int cnt_in = (int)min((uint32_t)SH_CHK, r_hi - base);
-        const bool hit = lane < cnt_in && rect_hit(n_q0.x, n_q0.y, n_q0.z, n_q0.w, n_q1.x, n_q1.y, (float)sgpr_opaque(iwx0),
-                                                   (float)sgpr_opaque(iwx1), (float)sgpr_opaque(iwy0), (float)sgpr_opaque(iwy1));
-        const unsigned long long hmask = __ballot(hit);
-        const int cnt = __popcll(hmask);
-        const int slot = __popcll(hmask & ((1ull << lane) - 1ull));
-        if (hit) {
-            FwdEntry en;
-            en.geo = make_float4(n_q0.x, n_q0.y, n_q0.z * CONIC_SCALE_AC, n_q0.w * CONIC_SCALE_B);
-            en.cd = make_float4(n_q1.z, n_q1.w, n_q2.x, n_q2.y);
-            en.co_c = n_q1.x * CONIC_SCALE_AC; en.co_o = n_q1.y;
-            en.pos = base - r_lo + lane + 1;
-            en.id = n_id;
-            L.ent[b][slot] = en;
-        }
-        if ((cnt & 1) && lane < 12) reinterpret_cast<float*>(&L.ent[b][cnt])[lane] = 0.0f;      // the null entry of an odd count
-        if (lane == 0) L.cnt[b] = cnt;
-        n_id = f_id;
-        if (lane < SH_CHK && base + SH_CHK + lane < r_hi) {
-            const SplatRec* rp = a.rec + n_id;
-            n_q0 = rp->q0; n_q1 = rp->q1; n_q2 = *reinterpret_cast<const float2*>(&rp->q2);
-        }
-        if (lane < SH_CHK && base + 2 * SH_CHK + lane < r_hi) f_id = a.point_list[base + 2 * SH_CHK + lane];
-        return true;
-    };
-    uint32_t base = r_lo;
-    bool more = compact(base, 0, px.T[0] > 0.0f);
-    __syncthreads();                        // chunk 0 is compacted
-    for (int k = 0; more; k++) {
-        const int b = k & 1;
-        const int cnt = __builtin_amdgcn_readfirstlane(L.cnt[b]);
-        share_gather_rows(a, L.ent[b], cnt, 0, min(CH, a.C), L.feat0, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        for (int j = 0; j < cnt; j += 2)
-            fwd_blend_group<CH, 1, 2, true, true>(L.ent[b], L.feat0, nullptr, j, lane, 0, 0, false, px, L.w[b]);
-        __builtin_amdgcn_wave_barrier();
-        base += SH_CHK;
-        more = compact(base, b ^ 1, px.T[0] > 0.0f);
-        __syncthreads();                    // chunk k is blended (w[b]), chunk k + 1 compacted (ent[b ^ 1], cnt[b ^ 1])
-    }
-    {   // the tile's longest walk, the pixel's colour, depth, final T and last contributor (as the base launch)
-        uint32_t m = wave_max_u32(px.last[0]);
-        if (lane == 0 && m) atomicMax(&a.tile_len[tile], m);
-        if (inside) {
-            const size_t HW = (size_t)a.W * a.H, pid = (size_t)pix_id;
-            const float Tf = fabsf(px.T[0]);
-            a.final_T[pid] = Tf;
-            a.n_contrib[pid] = px.last[0];
-            a.out_color[pid] = px.col[0][0] + Tf * a.bg[0];
-            a.out_color[HW + pid] = px.col[0][1] + Tf * a.bg[1];
-            a.out_color[2 * HW + pid] = px.col[0][2] + Tf * a.bg[2];
-            a.out_depth[pid] = px.dep[0];
-        }
-    }
-    share_store_features(a, px.acc[0], L.feat0, 0, min(CH, a.C), inside, pix_id, lane);
-}
-
-template <int NWV>
-__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))) render_forward_share_kernel(FwdArgs a) {
-    render_forward_share_body<NWV>(a);
-}
-
-template <int NWV>
-bool share_shape_usable() {
-    constexpr int MAX_DEV = 64;
-    static std::atomic<int> state[MAX_DEV];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
-    if (state[dev].load(std::memory_order_acquire) == 0) {
-        hipError_t e = hipSuccess;
-        if (sizeof(FwdShareLds<NWV>) > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_forward_share_kernel<NWV>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FwdShareLds<NWV>));
-        if (e != hipSuccess) (void)hipGetLastError();
-        state[dev].store(e == hipSuccess ? 1 : -1, std::memory_order_release);
-    }
-    return state[dev].load(std::memory_order_acquire) > 0;
-}
-template <int NWV>
-void launch_share(const FwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(render_forward_share_kernel<NWV>, dim3(4 * a.gx * a.gy), dim3(64 * NWV), sizeof(FwdShareLds<NWV>), s, a);
-}
-
 // Entry points by occupancy target over one body.  32 channels, one quadrant per wave, 32-instance chunks: 135 registers and
 // 5.7 KB of LDS per wave - squeezed into the four-waves-per-SIMD budget (128) it is the fastest shape at c3 (0.39 ms; 0.45
 // at three waves, 0.42-0.43 for two quadrants per wave with 64-instance chunks at three waves: 168 registers, 11.4 KB).
@@ -924,19 +655,7 @@ void launch_render_forward(const ViewParams& vp, int C, const uint2* ranges_enc,
     // blend weights of the whole list: fewer, wider windows - two waves per SIMD, the matrix pipe hides the rest)
     const bool wide_ok = mf && options().fwd_wide != 0 && C > 64 && wide_shape_usable<true>() && wide_shape_usable<false>();
     const int wide = wide_ok ? 128 : 64;
-    // more than 128 channels: ONE walk per quadrant, the blend weights shared between the waves of a workgroup (option fwd_share;
-    // render_forward_share_body) - up to 512 channels in one launch, anything beyond in later windows of the shapes below
-    int c_first = 0;
-    if (wide_ok && options().fwd_share != 0 && C > 128) {
-        const int nwv = (min(C, 512) + 127) / 128;
-        const bool usable = nwv == 2 ? share_shape_usable<2>() : nwv == 3 ? share_shape_usable<3>() : share_shape_usable<4>();
-        if (usable) {
-            a.c0 = 0; a.nc = min(C, 512); a.write_base = 1;
-            if (nwv == 2) launch_share<2>(a, s); else if (nwv == 3) launch_share<3>(a, s); else launch_share<4>(a, s);
-            c_first = min(C, 512);
-        }
-    }
-    for (int c0 = c_first; c0 < C;) {
+    for (int c0 = 0; c0 < C;) {
         const int win = (C - c0 > 64) ? wide : 64;
         a.c0 = c0; a.nc = min(win, C - c0); a.write_base = (c0 == 0);
         c0 += win;

@@ -111,9 +111,6 @@ const char* f3dgs_last_error(void);
  *                    sums added in the flush), 0 by columns only
  *   "fwd_wide"       blend forward: 1 (default) 128-channel windows where more than 64 channels remain
  *   "fwd_solo"       blend forward: 1 (default) one 64-thread workgroup per quadrant wave
- *   "fwd_share"      blend forward, more than 128 feature channels: 1 (default) one walk of the list per quadrant - a producer
- *                    wave evaluates the blend weights (and colour, depth, channels 0..127) and leaves them in LDS for the waves
- *                    of the later 128-channel windows of the same workgroup; 0: every window re-evaluates them (bit-identical)
  *   "sync_free"      0 (default): f3dgs_forward waits for the instance count where the reference does
  *                    (rasterizer_impl.cu:283; here behind the enqueue of the depth sort) and carves the binning buffer for
  *                    exactly that length.  1: SYNC-FREE FORWARD - the binning buffer is carved for a provision

@@ -461,20 +461,17 @@ def test_later_channel_windows_stay_on_the_bf16_contraction_on_needle_frames(opt
     assert float(np.abs(fa[:, 32:] - f0[:, 32:]).max()) > 0.0
 
 
-@pytest.mark.parametrize("name", ["fwd_solo", "fwd_wide", "fwd_share", "bwd_order", "bwd_m44", "bwd_wide8"])
+@pytest.mark.parametrize("name", ["fwd_solo", "fwd_wide", "bwd_order", "bwd_m44", "bwd_wide8"])
 @pytest.mark.parametrize("C", [16, 32, 200, 512])
 def test_scheduling_options_keep_the_results(name, C, option):
-    """Options fwd_solo (one workgroup per quadrant wave), fwd_wide (128-channel forward windows), fwd_share (more than 128
-    channels: one walk per quadrant, the blend weights handed from a producer wave to the later windows' waves), bwd_order (tiles longest
+    """Options fwd_solo (one workgroup per quadrant wave), fwd_wide (128-channel forward windows), bwd_order (tiles longest
     walk first in the backward), bwd_m44 (colour sums of the pixel-lane backward on 4 x 4 matrix blocks) and bwd_wide8 (later
     channel windows of the bf16 pixel-lane backward: 128 channels on eight waves per tile instead of 64 on four) select between
     complete code paths that do the same arithmetic: the forward images
     are bit-identical with the option off, the gradients equal up to the order of their atomic sums."""
     from synth import make_scene
-    if C == 512 and name not in ("bwd_wide8", "fwd_share"):
+    if C == 512 and name != "bwd_wide8":
         pytest.skip("the LSeg width is exercised for the channel-window options only")
-    if name == "fwd_share" and C <= 128:
-        pytest.skip("fwd_share concerns more than 128 channels")
     sc = make_scene(P=30000 if C < 512 else 8000, C=C, width=333, height=208, seed=31)
     if name == "bwd_m44":
         option("bwd_bf16", 0)        # the 4 x 4 colour blocks belong to the fp32 shape of the pixel-lane kernel
