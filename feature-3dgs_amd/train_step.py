@@ -117,3 +117,66 @@ def dp_train_step(render: Callable, loss_fn: Callable, model, cameras: Iterable,
             mr[seen] = torch.maximum(mr[seen], radii[seen].to(mr.dtype))
     total = torch.stack(losses).sum() if losses else torch.zeros((), device=device)
     return StepResult(total, len(cameras), grads)
+
+
+def _default_set_band(r0: int, r1: int) -> None:
+    from diff_gaussian_rasterization import _C
+    _C.set_tile_band(r0, r1)
+
+
+def dp_train_step_bands(render: Callable, loss_fn: Callable, model, camera, pipe, background: torch.Tensor, group=None,
+                        param_names: Sequence[str] = REFERENCE_PARAM_NAMES, densification_stats: bool = True,
+                        image_keys: Sequence[str] = ("render", "feature_map", "depth"), reduce: bool = True,
+                        set_band: Callable[[int, int], None] = _default_set_band) -> StepResult:
+    """ONE view split over the ranks by tile rows ("alternative for single huge views"; include/f3dgs.h:
+    f3dgs_set_tile_band) - for steps that have fewer views than GPUs.  Every rank renders the same `camera` restricted to its
+    band of 16-pixel tile rows (`dp.band_rows`), the bands are gathered into whole images (`dp.gather_bands` on
+    `render_pkg[k]` for k in `image_keys`: the images the loss reads), `loss_fn(render_pkg, camera)` sees the whole view on
+    every rank - so window-based terms such as SSIM are exact at the band borders - and its backward pass reaches this rank's
+    rows only; the gradients of the ranks then SUM to the whole view's gradient (`dp.all_reduce_gaussian_grads`), the radii MAX
+    to the whole view's, and the densification statistics are those of ONE view: |sum of the screen-space gradients| and one
+    visibility count per Gaussian seen in any band (scene/gaussian_model.py:436-438).  The loss returned is the whole view's, the
+    same on every rank."""
+    params = {n: getattr(model, n) for n in param_names if getattr(model, n, None) is not None}
+    P = next(iter(params.values())).shape[0]
+    device = next(iter(params.values())).device
+    world = torch.distributed.get_world_size(group) if dp._active(group) else 1
+    rank = torch.distributed.get_rank(group) if world > 1 else 0
+    H = int(camera.image_height)
+    r0, r1, _y0, _y1 = dp.band_rows(H, rank, world)
+    for p in params.values():
+        p.grad = None
+    if world > 1:       # (1 << 20: "an empty band", the share of a rank beyond the last tile row)
+        set_band(r0, r1) if r1 > r0 else set_band(1 << 20, 1 << 20)
+    try:
+        pkg = render(camera, model, pipe, background)
+    finally:
+        if world > 1:
+            set_band(0, 0)
+    whole = dict(pkg)
+    for k in image_keys:
+        if k in whole and isinstance(whole[k], torch.Tensor) and whole[k].dim() >= 2 and whole[k].numel():
+            whole[k] = dp.gather_bands(whole[k], group=group)
+    loss = loss_fn(whole, camera)
+    loss.backward()
+    grads = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in params.items()}
+    for n, p in params.items():
+        p.grad = grads[n]
+    if reduce and world > 1:
+        dp.all_reduce_gaussian_grads(grads, group=group)
+    if densification_stats:
+        with torch.no_grad():
+            vsp = pkg["viewspace_points"]
+            g2 = (vsp.grad if vsp.grad is not None else torch.zeros_like(vsp))[:, :2].contiguous()
+            radii = pkg["radii"].float().clone()
+            if world > 1:       # one view: its screen-space gradient is the SUM over the bands, its radii their MAX
+                torch.distributed.all_reduce(g2, op=torch.distributed.ReduceOp.SUM, group=group)
+                torch.distributed.all_reduce(radii, op=torch.distributed.ReduceOp.MAX, group=group)
+            seen = radii > 0
+            norm = torch.zeros(P, 1, device=device)
+            norm[seen] = torch.norm(g2[seen], dim=-1, keepdim=True)
+            model.xyz_gradient_accum += norm
+            model.denom += seen.float().unsqueeze(-1)
+            mr = model.max_radii2D
+            mr[seen] = torch.maximum(mr[seen], radii[seen].to(mr.dtype))
+    return StepResult(loss.detach(), 1, grads)
