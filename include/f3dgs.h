@@ -116,7 +116,9 @@ const char* f3dgs_last_error(void);
  *                    exactly that length.  1: SYNC-FREE FORWARD - the binning buffer is carved for a provision
  *                    ("instance_capacity"), the emit kernel and the tile sort read the count on the device, and the host reads
  *                    it only behind the last launch of the call (it has long been final by then); a frame that found no room
- *                    runs its binning and blend once more with the exact length before the call returns.  Results are
+ *                    runs its binning and blend once more with the exact length before the call returns (binning_resize is
+ *                    then called a SECOND time in the same forward call, while the first round's kernels may still be in
+ *                    flight on the stream: a hook that frees the old buffer must do so in stream order).  Results are
  *                    bit-identical to sync_free = 0.  With sync_free = 1 the call may also run on a stream that is being
  *                    CAPTURED into a HIP graph (hipStreamBeginCapture / torch.cuda.graph): then nothing is read on the host,
  *                    *num_rendered receives the last count this thread read on the device (at least 1), the blend backward of
