@@ -111,15 +111,17 @@ const char* f3dgs_last_error(void);
  *                    sums added in the flush), 0 by columns only
  *   "fwd_wide"       blend forward: 1 (default) 128-channel windows where more than 64 channels remain
  *   "fwd_solo"       blend forward: 1 (default) one 64-thread workgroup per quadrant wave
- *   "sync_free"      0 (default): f3dgs_forward waits for the instance count where the reference does
+ *   "sync_free"      0: f3dgs_forward waits for the instance count where the reference does
  *                    (rasterizer_impl.cu:283; here behind the enqueue of the depth sort) and carves the binning buffer for
- *                    exactly that length.  1: SYNC-FREE FORWARD - the binning buffer is carved for a provision
+ *                    exactly that length.  -1 (default): as 1 for scenes of up to 131,072 Gaussians - whose steps are bound by
+ *                    the host's enqueue time (c1: 0.19 -> 0.14 ms per eager step) - and inside a graph capture, as 0 for larger
+ *                    scenes (bound by the GPU: nothing to gain).  1: SYNC-FREE FORWARD - the binning buffer is carved for a provision
  *                    ("instance_capacity"), the emit kernel and the tile sort read the count on the device, and the host reads
  *                    it only behind the last launch of the call (it has long been final by then); a frame that found no room
  *                    runs its binning and blend once more with the exact length before the call returns (binning_resize is
  *                    then called a SECOND time in the same forward call, while the first round's kernels may still be in
  *                    flight on the stream: a hook that frees the old buffer must do so in stream order).  Results are
- *                    bit-identical to sync_free = 0.  With sync_free = 1 the call may also run on a stream that is being
+ *                    bit-identical to sync_free = 0.  With sync_free = 1 or -1 the call may also run on a stream that is being
  *                    CAPTURED into a HIP graph (hipStreamBeginCapture / torch.cuda.graph): then nothing is read on the host,
  *                    *num_rendered receives the last count this thread read on the device (at least 1), the blend backward of
  *                    bwd_bf16 = -1 launches both shapes of its first window and the frame's long-axis word lets one of them

@@ -51,9 +51,10 @@ def test_sync_free_forward_is_bit_identical(name, provision, option):
     """Whatever the provision: the same lists, ranges, images and radii as the blocking forward; the host's words say what the
     call provided for (a provision that was too small is replaced by the exact length in the second round of the call)."""
     scene = _scene(**SCENES[name])
+    option("sync_free", 0)
     want = _lists(scene)
     n = want["n_own"]
-    assert n > 0
+    assert n > 0 and want["counts"][3] == n
     option("sync_free", 1)
     cap = {"auto": 0, "generous": 4 * n + 1000, "exact": n, "one-short": n - 1, "tiny": 64}[provision]
     option("instance_capacity", cap)
@@ -75,6 +76,7 @@ def test_sync_free_forward_is_bit_identical(name, provision, option):
 @pytest.mark.parametrize("name", ["small-features", "mid"])
 def test_sync_free_step_has_the_blocking_steps_gradients(name, option):
     scene = _scene(**SCENES[name])
+    option("sync_free", 0)
     o0, g0 = run_hip(scene)
     _o, g0b = run_hip(scene)
     option("sync_free", 1)
@@ -163,7 +165,7 @@ def test_captured_step_replays_the_eager_step(name, option):
     assert n_entries.pop() == n_entries[0]
     assert n_entries[0] < n_entries[1] < n_entries[2] - 1, n_entries
     step = CapturedStep(fn, capacity=(n_entries[1] + n_entries[2]) // 2).capture()
-    assert _C.get_option("sync_free") == 0 and _C.get_option("instance_capacity") == 0, "the capture leaves the caller's options as they were"
+    assert _C.get_option("sync_free") == -1 and _C.get_option("instance_capacity") == 0, "the capture leaves the caller's options as they were"
     graph_outs = dict(outs)          # the tensors the graph writes (an eager call of fn puts new ones into `outs`)
     for v in grads.values():
         v.zero_()
@@ -244,9 +246,29 @@ def test_a_captured_backward_picks_its_contraction_on_the_device(kind):
         assert worst <= slack + 4.0 * noise, (k, worst, noise)
 
 
+def test_the_default_takes_the_sync_free_path_for_small_scenes_only(option):
+    """sync_free = -1 (default): scenes of up to 131,072 Gaussians - host-bound steps - take the sync-free path (the call provides
+    for 1.25 x the last count + 4096 entries), larger ones the blocking read (exactly the count)."""
+    from diff_gaussian_rasterization import _C
+    assert _C.get_option("sync_free") == -1
+    small = _scene(**SCENES["mid"])
+    for _ in range(2):
+        a = _lists(small)
+    assert a["counts"][3] == a["n_own"] + a["n_own"] // 4 + 4096
+    large = _scene(P=131073, width=320, height=200, C=0, seed=29, scale_lo=0.003, scale_hi=0.02)
+    for _ in range(2):
+        b = _lists(large)
+    assert b["counts"][3] == b["n_own"]
+    option("sync_free", 0)
+    c = _lists(small)
+    assert c["counts"][3] == c["n_own"]
+    _same_lists(c, a)
+
+
 def test_a_capture_without_the_option_is_refused_loudly(option):
     """sync_free = 0: the forward call must read the count on the host - inside a capture that is an error with a message, not a
     hang or a broken graph."""
+    option("sync_free", 0)
     scene = _scene(**SCENES["small"])
     fn, _L, _outs, _grads = _static_step(scene)
     fn()
