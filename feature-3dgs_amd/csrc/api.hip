@@ -515,13 +515,11 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // sort take the count from the device's word, and the count is read behind the LAST launch of the call (too small a
     // provision: the binning and the blend run once more with the exact length).  Under capture nothing is read at all.
     const bool capturing = stream_is_capturing(s);
-    // sync_free: 1 always, 0 never, -1 (default) for SMALL scenes and inside a capture - up to 131,072 Gaussians a step is bound by
-    // the host's enqueue time and the wait in the middle of the forward call is what the host can least afford (c1 eager: 0.194 ->
-    // 0.138 ms per step); large scenes are bound by the GPU and gain nothing (c3 1.26 either way; eight views per step on two
-    // streams lose 0.5 - 4 % to the larger provisions)
-    constexpr int SYNC_FREE_AUTO_MAX_P = 131072;
+    // sync_free: 1 always, 0 never (a capture is refused), -1 (default): inside a capture only.  Eager, the wait it removes was
+    // already hidden behind the depth sort: an A / B in one process (exp/c1_ab.py) reads 0.1925 / 0.1912 ms per step at c1 and
+    // 1.1315 / 1.1337 at c2 with the option off / on - nothing; what the option buys is the capture (c1: 0.19 -> 0.12 ms).
     const int sf_opt = options().sync_free;
-    const bool sync_free = !onesweep && (sf_opt > 0 || (sf_opt < 0 && (capturing || P <= SYNC_FREE_AUTO_MAX_P)));
+    const bool sync_free = !onesweep && (sf_opt > 0 || (sf_opt < 0 && capturing));
     if (capturing && !sync_free)
         return fail(F3DGS_ERR_UNSUPPORTED, "the stream is being captured into a graph: the forward call reads the instance count on the host "
                     "unless option sync_free is 1 or -1 (and sort_onesweep = 0)");

@@ -185,7 +185,7 @@ struct Options {
     int fwd_wide;        // blend forward: 128-channel windows where more than 64 channels remain (default 1)
     int fwd_solo;        // blend forward, one quadrant per wave: one 64-thread workgroup per quadrant (default 1; the waves never synchronise)
     int sort_onesweep;   // 1: single-pass radix passes with decoupled look-back (measured slower on MI355X; default 0)
-    int sync_free;       // -1 (default): as 1 for scenes of up to 131,072 Gaussians and inside a graph capture, as 0 otherwise; 1: the forward call never waits for the instance count in the middle of its enqueue - binning buffers of a CAPACITY, kernels that read the count on the device, the count checked behind the last launch (one retry) - and can be captured in a HIP graph; 0: the blocking read, capture refused
+    int sync_free;       // -1 (default): as 1 inside a graph capture, as 0 otherwise; 1: the forward call never waits for the instance count in the middle of its enqueue - binning buffers of a CAPACITY, kernels that read the count on the device, the count checked behind the last launch (one retry) - and can be captured in a HIP graph; 0: the blocking read, capture refused
     int instance_capacity;   // sync_free: entries of the instance lists to provide for (0, default: 1.25 x the thread's last count on the device + 4096)
 #ifdef F3DGS_DEV
     int dev;             // development builds only (make DEV=1): work-skipping experiments, never in a release library

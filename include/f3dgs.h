@@ -113,9 +113,8 @@ const char* f3dgs_last_error(void);
  *   "fwd_solo"       blend forward: 1 (default) one 64-thread workgroup per quadrant wave
  *   "sync_free"      0: f3dgs_forward waits for the instance count where the reference does
  *                    (rasterizer_impl.cu:283; here behind the enqueue of the depth sort) and carves the binning buffer for
- *                    exactly that length.  -1 (default): as 1 for scenes of up to 131,072 Gaussians - whose steps are bound by
- *                    the host's enqueue time (c1: 0.19 -> 0.14 ms per eager step) - and inside a graph capture, as 0 for larger
- *                    scenes (bound by the GPU: nothing to gain).  1: SYNC-FREE FORWARD - the binning buffer is carved for a provision
+ *                    exactly that length.  -1 (default): as 1 inside a graph capture, as 0 otherwise (eager, the wait is already
+ *                    hidden behind the depth sort: measured, the option changes nothing there).  1: SYNC-FREE FORWARD - the binning buffer is carved for a provision
  *                    ("instance_capacity"), the emit kernel and the tile sort read the count on the device, and the host reads
  *                    it only behind the last launch of the call (it has long been final by then); a frame that found no room
  *                    runs its binning and blend once more with the exact length before the call returns (binning_resize is
