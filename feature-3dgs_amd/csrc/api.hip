@@ -68,7 +68,7 @@ bool frame_axis_ratio(const void* geom, float* axis_ratio, int* band0 = nullptr,
 
 // Zero-fill inside a graph capture: hipMemsetAsync is captured as a memset node, and with the HIP runtime this library meets
 // under PyTorch (ROCm 7.0) such nodes fill with the wrong pattern from the graph's SECOND replay on (measured: every row of
-// dL_dsemantic_feature began with 16 bytes of a kernel-argument block; exp/graph_probe2.py).  A kernel node has no such
+// dL_dsemantic_feature began with 16 bytes of a kernel-argument block; tools/graph_memset_probe.py).  A kernel node has no such
 // problem, so a captured call clears its buffers with this kernel; eager calls keep hipMemsetAsync (6+ TB/s).
 __global__ void __launch_bounds__(256) zero_fill_kernel(uint4* __restrict__ p, size_t n16, int tail_words) {
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -516,7 +516,7 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // provision: the binning and the blend run once more with the exact length).  Under capture nothing is read at all.
     const bool capturing = stream_is_capturing(s);
     // sync_free: 1 always, 0 never (a capture is refused), -1 (default): inside a capture only.  Eager, the wait it removes was
-    // already hidden behind the depth sort: an A / B in one process (exp/c1_ab.py) reads 0.1925 / 0.1912 ms per step at c1 and
+    // already hidden behind the depth sort: an A / B in one process (tools/sync_free_ab.py) reads 0.1925 / 0.1912 ms per step at c1 and
     // 1.1315 / 1.1337 at c2 with the option off / on - nothing; what the option buys is the capture (c1: 0.19 -> 0.12 ms).
     const int sf_opt = options().sync_free;
     const bool sync_free = !onesweep && (sf_opt > 0 || (sf_opt < 0 && capturing));

@@ -248,7 +248,7 @@ def test_a_captured_backward_picks_its_contraction_on_the_device(kind):
 
 def test_the_default_is_the_blocking_read_outside_a_capture():
     """sync_free = -1 (default): an eager call carves the binning buffer for exactly the count it read (measured: eager, the
-    sync-free path buys nothing - exp/c1_ab.py); a capture takes the sync-free path (test_a_captured_backward... run under it)."""
+    sync-free path buys nothing - tools/sync_free_ab.py); a capture takes the sync-free path (test_a_captured_backward... run under it)."""
     from diff_gaussian_rasterization import _C
     assert _C.get_option("sync_free") == -1
     scene = _scene(**SCENES["mid"])
