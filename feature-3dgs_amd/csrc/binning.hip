@@ -456,7 +456,7 @@ void launch_offset_sums(const uint32_t* in, const uint32_t* gather, size_t n, ui
 // The pairs live in registers between passes; the LDS image is written out once at the end (with the tile ranges, RANGES).
 // (A first version of this idea - round 4, removed - ping-ponged the pairs through global memory behind fences: slower than the
 // launches it replaced.)
-constexpr int SMALL_SORT_MAX = 16384;
+// (SMALL_SORT_MAX = 16384: common.h)
 constexpr int SMALL_SORT_THREADS = 1024;
 constexpr int SMALL_SORT_ITEMS = SMALL_SORT_MAX / SMALL_SORT_THREADS;     // 16
 struct SmallSortLds {

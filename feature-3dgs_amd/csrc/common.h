@@ -52,6 +52,7 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 8;                                   // fewest keys per thread of any pass (sizes the histograms)
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;           // items per workgroup
 constexpr int SCAN_CHUNK = 256 * 16;
+constexpr int SMALL_SORT_MAX = 16384;                           // pairs the one-launch LDS-resident sort takes (binning.hip: small_sort_kernel)
 constexpr int BIGQ_CAP = 1024;                                  // slots of the big-splat queue of the emit kernel (4 x 256: zeroed by four workgroups)
 constexpr int DEPTH_SORT_ITEMS = 8;                             // onesweep depth passes: 2048 keys per workgroup
 
