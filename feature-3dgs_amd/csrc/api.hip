@@ -557,14 +557,16 @@ int f3dgs_forward(f3dgs_resize_fn geometry_resize, void* geometry_ctx, f3dgs_res
     // first kernel adds up the totals and stores them into the pinned host words itself (no totals / copy launches);
     // rb.done is recorded right behind that kernel.
     const TotalsJob tj = {geom.ref_partial, (P + 255) / 256, geom.counters, rb.dev, capturing ? nullptr : rb.done};
+    const OffsetSumsJob sums = {geom.tiles_touched, geom.scan_tmp, geom.scan_sub};
+    bool sums_done = false;         // small scenes: the one-workgroup depth sort leaves the list-offset sums as well
     if (onesweep) launch_depth_sort_onesweep(geom, (size_t)P, s);
-    else HIP_TRY(launch_depth_sort(geom.depth_key, geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, geom.hist, &tj, s));
+    else HIP_TRY(launch_depth_sort(geom.depth_key, geom.key_a, geom.val_a, geom.key_b, geom.val_b, (size_t)P, geom.hist, &tj, s, &sums, &sums_done));
     if ((rc = check_debug(debug, s, "depth sort"))) return rc;
     tm.mark("depth_sort");
     const uint32_t* order = geom.val_a;
 
     // instance offsets in depth order (three-kernel flavour only; the single-pass emit scans on the fly)
-    if (!onesweep)
+    if (!onesweep && !sums_done)
         launch_offset_sums(geom.tiles_touched, order, (size_t)P, geom.scan_tmp, geom.scan_sub, s);
 
     // [0] instances in our lists, [1] the reference's bounding-rectangle count,

@@ -469,7 +469,7 @@ template <bool RANGES>
 __global__ void __launch_bounds__(SMALL_SORT_THREADS)
 small_sort_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
                   uint32_t* __restrict__ vals_out, uint32_t n, int passes, TotalsJob tj, uint2* __restrict__ ranges_enc,
-                  const uint32_t* __restrict__ n_dev) {
+                  const uint32_t* __restrict__ n_dev, OffsetSumsJob os) {
     extern __shared__ __attribute__((aligned(16))) char small_sort_smem[];
     SmallSortLds& L = *reinterpret_cast<SmallSortLds*>(small_sort_smem);
     constexpr int ITEMS = SMALL_SORT_ITEMS, NW = SMALL_SORT_THREADS / 64;
@@ -571,6 +571,31 @@ small_sort_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restri
             if (RANGES) record_range(ranges_enc, kk, j == 0 || L.key[j - 1] != kk, j + 1 == n || L.key[j + 1] != kk, j);
         }
     }
+    if (os.tiles_touched) {
+        // The list offsets in the NEW order (scan_reduce_kernel's two levels), from the sorted ids still in LDS: step k of wave w
+        // covers items 1024 k + 64 w .. + 63 = run 16 k + w of the order, and a chunk of SCAN_CHUNK items is 64 consecutive runs.
+        static_assert(SCAN_CHUNK == 64 * 64 && SMALL_SORT_THREADS == 1024, "run = item / 64, chunk = run / 64");
+        const uint32_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        uint32_t* const runs = &L.cnt[0][0];          // (the counters are done with: the last pass's barriers are behind us)
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t j = (uint32_t)(k * SMALL_SORT_THREADS + tid);
+            uint32_t r = j < n ? os.tiles_touched[L.val[j]] : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) r += (uint32_t)__shfl_xor((int)r, d, 64);
+            const uint32_t run = (uint32_t)(16 * k + w);
+            if (lane == 0) {
+                runs[run] = r;
+                if (run < 64u * nchunks) os.sub[run] = r;
+            }
+        }
+        __syncthreads();
+        if ((uint32_t)tid < nchunks) {
+            uint32_t t = 0;
+            for (int q = 0; q < 64; q++) t += runs[64 * tid + q];
+            os.chunk_sums[tid] = t;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) totals_kernel(TotalsJob tj) { run_totals_job<256>(tj); }
@@ -633,10 +658,10 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
         const TotalsJob none = {nullptr, 0, nullptr, nullptr};
         if (ranges_enc)
             hipLaunchKernelGGL(small_sort_kernel<true>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, ki, vi, ko, vo,
-                               (uint32_t)n, passes, none, ranges_enc, n_dev);
+                               (uint32_t)n, passes, none, ranges_enc, n_dev, OffsetSumsJob{nullptr, nullptr, nullptr});
         else
             hipLaunchKernelGGL(small_sort_kernel<false>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, ki, vi, ko, vo,
-                               (uint32_t)n, passes, none, (uint2*)nullptr, n_dev);
+                               (uint32_t)n, passes, none, (uint2*)nullptr, n_dev, OffsetSumsJob{nullptr, nullptr, nullptr});
         return;
     }
     for (int p = 0; p < passes; p++) {
@@ -652,7 +677,8 @@ void launch_radix_sort_pairs(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, 
 // Depth sort of the Gaussians: 32-bit keys in `keys` (read-only), values = indices.  Three passes of 11/11/10
 // bits; the sorted ids end in val_a (and the sorted keys in key_a).
 hipError_t launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
-                             uint32_t* hist, const TotalsJob* tj, hipStream_t s) {
+                             uint32_t* hist, const TotalsJob* tj, hipStream_t s, const OffsetSumsJob* sums, bool* sums_done) {
+    if (sums_done) *sums_done = false;
     if (n == 0) return hipSuccess;
     if (n <= (size_t)SMALL_SORT_MAX && small_sort_usable<false>()) {
         // the totals the host waits for go out in a launch of their own, in FRONT of the sort: behind it the host would sit out the
@@ -667,7 +693,8 @@ hipError_t launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* va
         }
         hipLaunchKernelGGL(small_sort_kernel<false>, dim3(1), dim3(SMALL_SORT_THREADS), sizeof(SmallSortLds), s, keys, (const uint32_t*)nullptr,
                            key_a, val_a, (uint32_t)n, 4, (tj && tj->partial && !apart) ? *tj : TotalsJob{nullptr, 0, nullptr, nullptr},
-                           (uint2*)nullptr, (const uint32_t*)nullptr);
+                           (uint2*)nullptr, (const uint32_t*)nullptr, sums ? *sums : OffsetSumsJob{nullptr, nullptr, nullptr});
+        if (sums && sums_done) *sums_done = true;
         return rc;
     }
     if (n > 200000) {

@@ -251,6 +251,13 @@ void launch_depth_sort_onesweep(const GeomState& g, size_t n, hipStream_t s);
 void launch_tile_sort_onesweep(const GeomState& g, const BinState& b, size_t n, int passes, uint2* ranges, hipStream_t s);
 // `tj` (optional): the first kernel of the sort also produces the two instance totals from the per-workgroup partials of
 // preprocess_kernel - device counters and the host's pinned words - and `ready` is recorded right behind it.
+// The two-level list-offset sums of launch_offset_sums, produced by the depth sort's own launch where that is ONE workgroup
+// (up to SMALL_SORT_MAX Gaussians): a launch less per frame (c1: ~9 us of ~115 replayed).  All null: not wanted.
+struct OffsetSumsJob {
+    const uint32_t* tiles_touched;
+    uint32_t* chunk_sums;
+    uint32_t* sub;
+};
 struct TotalsJob {
     const uint32_t* partial;   // GeomState::ref_partial
     int n_partial;
@@ -258,8 +265,10 @@ struct TotalsJob {
     uint32_t* host;            // pinned, device-visible (may be null)
     hipEvent_t ready;          // host side only
 };
+// `sums` (optional) / `sums_done`: see OffsetSumsJob - *sums_done says whether this call produced them
 hipError_t launch_depth_sort(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, size_t n,
-                             uint32_t* hist, const TotalsJob* tj, hipStream_t s);
+                             uint32_t* hist, const TotalsJob* tj, hipStream_t s, const OffsetSumsJob* sums = nullptr,
+                             bool* sums_done = nullptr);
 void launch_iota(uint32_t* dst, size_t n, hipStream_t s);
 void launch_radix_sort_keys_to_order(const uint32_t* keys, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b,
                                      size_t n, int nbits, uint32_t* hist, hipStream_t s);
