@@ -45,7 +45,37 @@ def _leaves(dev):
     return {k: sc[k].to(dev).clone().requires_grad_(True) for k in KEYS}
 
 
-def _worker(rank, world, port, out_dir):
+def _band_step(rank, world, dev):
+    """ONE view (view 0) split over the ranks by tile rows: band render, bands gathered, the loss on the whole image, backward
+    into the own rows, gradients summed (dp.band_rows / gather_bands; include/f3dgs.h: f3dgs_set_tile_band)."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
+    import dp
+    sc = _scene(0)
+    t = lambda x: x.to(dev)
+    leaves = _leaves(dev)
+    st = dgr.GaussianRasterizationSettings(sc["image_height"], sc["image_width"], sc["tanfovx"], sc["tanfovy"], t(sc["bg"]), 1.0,
+                                           t(sc["viewmatrix"]), t(sc["projmatrix"]), 3, t(sc["campos"]), False, False)
+    r0, r1, _y0, _y1 = dp.band_rows(sc["image_height"], rank, world)
+    _C.set_tile_band(r0, r1)
+    try:
+        color, feat, radii, depth = dgr.GaussianRasterizer(st)(means2D=torch.zeros(sc["P"], 3, device=dev), **leaves)
+    finally:
+        _C.set_tile_band(0, 0)
+    color, feat = dp.gather_bands(color), dp.gather_bands(feat)
+    loss = (color * t(sc["dL_dcolor"])).sum() + (feat * t(sc["dL_dfeature"])).sum()
+    loss.backward()
+    grads = {k: leaves[k].grad for k in KEYS}
+    dp.all_reduce_gaussian_grads(grads)
+    rad = radii.float()
+    import torch.distributed as dist
+    dist.all_reduce(rad, op=dist.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    return {**{f"band_{k}": grads[k].cpu().numpy() for k in KEYS}, "band_color": color.detach().cpu().numpy(),
+            "band_feat": feat.detach().cpu().numpy(), "band_radii": rad.cpu().numpy(), "band_loss": float(loss)}
+
+
+def _worker(rank, world, port, out_dir, backend="nccl"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "feature-3dgs_amd"), os.path.join(root, "tests")):
         sys.path.insert(0, p)
@@ -54,7 +84,10 @@ def _worker(rank, world, port, out_dir):
     dev = torch.device("cuda", rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     try:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         probe = torch.ones(4, device=dev)
         dist.all_reduce(probe)          # RCCL builds that refuse two ranks on one device fail here
         torch.cuda.synchronize()
@@ -79,17 +112,25 @@ def _worker(rank, world, port, out_dir):
     rad = torch.arange(100, dtype=torch.float32, device=dev) * (rank + 1)
     dp.reduce_densification_stats(acc, den, rad)
     res.update(acc=acc.cpu().numpy(), den=den.cpu().numpy(), rad=rad.cpu().numpy())
+    res.update(_band_step(rank, world, dev))
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_rccl(tmp_path):
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_two_ranks_rccl(tmp_path, backend):
+    """backend "nccl": two ranks over RCCL (two devices where there are two; skipped where both ranks land on one).  backend
+    "gloo": the SAME two-process step with the real op on whatever devices there are - on a one-GPU box two processes share
+    cuda:0 and gloo carries the device tensors through the host: every collective call, side stream, in-backward hook and the
+    band split run for real at world size 2 (only the transport is not RCCL's)."""
     world = 2
     os.environ.setdefault("NCCL_DEBUG", "WARN")
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
     skips = [f for f in os.listdir(tmp_path) if f.startswith("skip")]
     if skips:
+        if backend == "gloo":
+            pytest.fail("the gloo process group failed: " + open(os.path.join(tmp_path, skips[0])).read()[:300])
         pytest.skip("RCCL refused two ranks on one device: " + open(os.path.join(tmp_path, skips[0])).read()[:300])
     dev = torch.device("cuda", 0)
     want = None
@@ -106,6 +147,25 @@ def test_two_ranks_rccl(tmp_path):
                 err = np.abs(got[f"{mode}_{k}"] - w).max()
                 assert err <= 1e-4 * np.abs(w).max() + 1e-12, (mode, k, rank, err)   # atomics reorder fp32 sums
         assert np.allclose(got["acc"], 3.0) and np.allclose(got["den"], 2.0) and np.allclose(got["rad"], np.arange(100) * 2.0)
+    # ---- one view as two tile-row bands against the whole view in one process ---------------------------------------------
+    import diff_gaussian_rasterization as dgr
+    sc = _scene(0)
+    t = lambda x: x.to(dev)
+    leaves = _leaves(dev)
+    st = dgr.GaussianRasterizationSettings(sc["image_height"], sc["image_width"], sc["tanfovx"], sc["tanfovy"], t(sc["bg"]), 1.0,
+                                           t(sc["viewmatrix"]), t(sc["projmatrix"]), 3, t(sc["campos"]), False, False)
+    color, feat, radii, depth = dgr.GaussianRasterizer(st)(means2D=torch.zeros(sc["P"], 3, device=dev), **leaves)
+    loss = (color * t(sc["dL_dcolor"])).sum() + (feat * t(sc["dL_dfeature"])).sum()
+    loss.backward()
+    for rank in range(world):
+        got = np.load(os.path.join(tmp_path, f"r{rank}.npz"))
+        assert np.array_equal(got["band_color"], color.detach().cpu().numpy()) and np.array_equal(got["band_feat"], feat.detach().cpu().numpy())
+        assert np.array_equal(got["band_radii"], radii.float().cpu().numpy())
+        assert abs(float(got["band_loss"]) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach())) + 1e-9
+        for k in KEYS:
+            w = leaves[k].grad.cpu().numpy()
+            err = np.abs(got[f"band_{k}"] - w).max()
+            assert err <= 1e-4 * np.abs(w).max() + 1e-12, ("band", k, rank, err)
 
 
 def _solo_worker(rank, port, out_dir):
