@@ -53,6 +53,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # replaced by a few torch operations.  The line says "data": "stub" and carries no measurement; it exists so that the first real
 # multi-GPU lease (driver-run, not debuggable) does not die in plumbing.
 STUB = os.environ.get("F3DGS_BENCH_STUB", "0") == "1"
+# rehearsal of the multi-rank flow with the real op on ONE GPU (all ranks on cuda:0, gloo as transport): not a measurement
+ONE_DEVICE = os.environ.get("F3DGS_BENCH_ONE_DEVICE", "0") == "1"
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_ACHIEVABLE_GBS = 6290.0   # MI355X_MICROARCH.md "Chip-level parameters": what a float4 copy reaches
@@ -564,7 +566,7 @@ def main():
     if world == 0 and args.gpus > 1:
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus and not STUB:
+        if have < args.gpus and not STUB and not ONE_DEVICE:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to report fewer")
         raise SystemExit(respawn_under_torchrun(args))
     world = max(world, 1)
@@ -582,14 +584,17 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        # F3DGS_BENCH_ONE_DEVICE=1 (a rehearsal, never a measurement: the line says so): every rank on cuda:0, gloo as transport -
+        # the whole multi-rank flow of this file with the REAL op on a one-GPU box
+        local_dev = 0 if ONE_DEVICE else local_rank
+        torch.cuda.set_device(local_dev)
+        dev = torch.device("cuda", local_dev)
         sync = torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if STUB:
+        if STUB or ONE_DEVICE:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -700,7 +705,7 @@ def main():
                     os.environ.pop("NCCL_PROTO", None)
                 label = f"NCCL_ALGO={algo}" + (f",NCCL_PROTO={proto}" if proto else "")
                 try:
-                    g = dist.new_group(backend="gloo" if STUB else "nccl")
+                    g = dist.new_group(backend="gloo" if (STUB or ONE_DEVICE) else "nccl")
                     t = time_group(g)
                     sweep[label] = {"ms": 1e3 * t / args.steps, "algbw_GBps": nbytes / (t / args.steps) / 1e9}
                     dist.destroy_process_group(g)
@@ -1088,7 +1093,7 @@ def main():
             "metric": f"rendered Mpix/s of rasterizer fwd+bwd (train-step ms in ms_per_step), {config_label(P, W, H, C)}",
             "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if V else "weak", "vs_baseline": None,
-            "dtype": dtype_label, "data": "stub" if STUB else "synthetic",
+            "dtype": dtype_label, "data": "stub" if STUB else ("synthetic; REHEARSAL: all ranks share cuda:0, gloo as transport - not a measurement" if ONE_DEVICE and world > 1 else "synthetic"),
             "blend_kernels": blend_label,
             "options": {k: _C.get_option(k) for k in ("feature_mfma", "bwd_bf16", "bwd_bf16_max_ratio", "bwd_pl", "tile_cull", "sync_free")},
             "blend_backward_contraction": "bf16 two-term" if bwd_bf16_active else
