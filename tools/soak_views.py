@@ -42,6 +42,10 @@ for i in range(steps):
     if i == 2 * len(rasts):
         torch.cuda.synchronize(); m0 = torch.cuda.memory_allocated()
 torch.cuda.synchronize()
+# a fingerprint of the first pass's images (exact: integer sum of the float bits) - equal between runs under different options
+# (F3DGS_SYNC_FREE=1: the provision of a view comes from the previous view's count, so rotating views exercise the retry)
+fp = sum(int(first[j][0].view(torch.int32).to(torch.int64).sum()) + int(first[j][1].view(torch.int32).to(torch.int64).sum()) for j in sorted(first))
+print("image fingerprint", fp)
 ok = all(bool(torch.isfinite(v.grad).all()) for v in leaves.values() if v.grad is not None)
 print(f"{cfg}: {steps} steps over {len(rasts)} views, {1e3 * (time.perf_counter() - t0) / steps:.3f} ms/step; finite gradients: {ok}; "
       f"allocated MB at step {2 * len(rasts)} / end: {m0 >> 20} / {torch.cuda.memory_allocated() >> 20}; images of every view bit-identical at the end")
