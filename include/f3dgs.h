@@ -95,9 +95,11 @@ const char* f3dgs_last_error(void);
  *                    -1 (default): by the frame - bf16 while no visible Gaussian is longer than "bwd_bf16_max_ratio" times
  *                    its width (3D scales and screen-space footprint; f3dgs_forward notes per geometry buffer whether
  *                    the frame holds such a Gaussian - against the ratio in force at that call -, f3dgs_backward looks it
- *                    up), exact fp32 otherwise and when the note is gone: the covariance
- *                    chain behind the blend amplifies an error of the blend-level sums by the square of that ratio
- *                    (measured: within a third of the gradient bound up to 16, outside it from 32 on);
+ *                    up), otherwise - and when the note is gone - the HYBRID first window: its moment block (the six
+ *                    geometric sums) on exact-fp32 matrix instructions, feature and colour blocks on bf16.  The covariance
+ *                    chain behind the blend amplifies an error of the MOMENT sums by the square of that ratio
+ *                    (measured: the bf16 shape within a third of the gradient bound up to 16, outside it from 32 on);
+ *                    a frame replayed from a graph launches both shapes and the frame's word lets one run on the device;
  *                    the later channel windows of wide features (C > 32: feature sums only, nothing amplifies them) stay on
  *                    the bf16 contraction under -1 whatever the first window took
  *   "bwd_bf16_max_ratio"  (default 16) the axis ratio up to which bwd_bf16 = -1 takes the bf16 contraction
